@@ -1,0 +1,704 @@
+"""CPU oracle: a torch-CPU (fp32 / fp64) restatement of big_vision's SigLIP/ViT step.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+The product (`big_vision_amd/`) never imports anything from `oracle/`.
+
+PARITY STATUS: **parity unpinned against the JAX reference itself** — jax/flax/
+optax are not installed in this image and the reference ships no golden vectors
+or tests for models/vit.py, two_towers.py, text_transformer.py or the sigmoid
+loss.  What pins this oracle instead:
+  * `oracle/make_golden.py` cross-checks the forward pass and the loss against
+    HuggingFace `transformers.SiglipModel` (an independent PyTorch port of the
+    same big_vision model) with weights copied across; the resulting fixtures
+    live in `tests/golden/` and are re-checked by `tests/test_oracle.py`.
+  * the reference's own known-answer tests for the pieces that HAVE them are
+    restated verbatim in `tests/test_oracle.py`: LR schedules
+    (big_vision/utils_test.py:258-281), `steps()` (utils_test.py:228-255) and
+    the optimizer chain closed forms (big_vision/optax_test.py:103-299).
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference/big_vision/).  Parameters are nested dicts of torch tensors
+with the exact Flax names/shapes of the reference.
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+Tree = Dict[str, Any]
+
+# -----------------------------------------------------------------------------
+# Variant table — models/vit.py:284-303 (decode_variant)
+# -----------------------------------------------------------------------------
+_WIDTH = {"mu": 32, "Ti": 192, "S": 384, "M": 512, "B": 768, "L": 1024, "So400m": 1152, "H": 1280, "g": 1408, "g-opt": 1536, "G": 1664, "G-opt": 1536, "e": 1792}
+_DEPTH = {"mu": 1, "Ti": 12, "S": 12, "M": 12, "B": 12, "L": 24, "So400m": 27, "H": 32, "g": 40, "g-opt": 40, "G": 48, "G-opt": 48, "e": 56}
+_MLP = {"mu": 128, "Ti": 768, "S": 1536, "M": 2048, "B": 3072, "L": 4096, "So400m": 4304, "H": 5120, "g": 6144, "g-opt": 6144, "G": 8192, "G-opt": 8192, "e": 15360}
+_HEADS = {"mu": 2, "Ti": 3, "S": 6, "M": 8, "B": 12, "L": 16, "So400m": 16, "H": 16, "g": 16, "g-opt": 16, "G": 16, "G-opt": 16, "e": 16}
+
+
+def decode_variant(variant: Optional[str]) -> dict:
+  """models/vit.py:284-303."""
+  if variant is None:
+    return {}
+  v, patch = variant, {}
+  if "/" in variant:
+    v, p = variant.split("/")
+    patch = {"patch_size": (int(p), int(p))}
+  return {"width": _WIDTH[v], "depth": _DEPTH[v], "mlp_dim": _MLP[v],
+          "num_heads": _HEADS[v], **patch}
+
+
+# -----------------------------------------------------------------------------
+# Primitive layers (Flax semantics, SURVEY.md §8c "Flax facts")
+# -----------------------------------------------------------------------------
+def layernorm(x, p, eps=1e-6):
+  """flax.linen.LayerNorm as used at models/vit.py:92,103,160,181.
+
+  eps=1e-6, stats over the last axis, var = E[x^2] - E[x]^2 clamped at 0.
+  """
+  mu = x.mean(-1, keepdim=True)
+  var = ((x * x).mean(-1, keepdim=True) - mu * mu).clamp_min(0.0)
+  return (x - mu) * torch.rsqrt(var + eps) * p["scale"] + p["bias"]
+
+
+def dense(x, p):
+  """flax.linen.Dense: y = x @ kernel + bias (models/vit.py:72,77)."""
+  return x @ p["kernel"] + p["bias"]
+
+
+def gelu_tanh(x):
+  """flax.linen.gelu default approximate=True (models/vit.py:75)."""
+  return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def mha(xq, xkv, p, num_heads):
+  """flax.linen.MultiHeadDotProductAttention (models/vit.py:93-98, :176-178).
+
+  q/k/v kernels (D,H,Dh) + bias (H,Dh); out kernel (H,Dh,D) + bias (D).
+  query scaled by 1/sqrt(Dh) before the dot; softmax over keys; no mask.
+  """
+  q = torch.einsum("nld,dhk->nlhk", xq, p["query"]["kernel"]) + p["query"]["bias"]
+  k = torch.einsum("nld,dhk->nlhk", xkv, p["key"]["kernel"]) + p["key"]["bias"]
+  v = torch.einsum("nld,dhk->nlhk", xkv, p["value"]["kernel"]) + p["value"]["bias"]
+  dh = q.shape[-1]
+  q = q / math.sqrt(dh)
+  s = torch.einsum("nqhd,nkhd->nhqk", q, k)
+  a = torch.softmax(s, dim=-1)
+  o = torch.einsum("nhqk,nkhd->nqhd", a, v)
+  return torch.einsum("nlhk,hkd->nld", o, p["out"]["kernel"]) + p["out"]["bias"]
+
+
+def mlp_block(x, p):
+  """models/vit.py:57-78 (MlpBlock)."""
+  return dense(gelu_tanh(dense(x, p["Dense_0"])), p["Dense_1"])
+
+
+def encoder_block(x, p, num_heads):
+  """models/vit.py:81-112 (Encoder1DBlock), dropout=0."""
+  out = {}
+  y = layernorm(x, p["LayerNorm_0"])
+  y = out["sa"] = mha(y, y, p["MultiHeadDotProductAttention_0"], num_heads)
+  x = out["+sa"] = x + y
+  y = layernorm(x, p["LayerNorm_1"])
+  y = out["mlp"] = mlp_block(y, p["MlpBlock_0"])
+  x = out["+mlp"] = x + y
+  return x, out
+
+
+def encoder(x, p, depth, num_heads):
+  """models/vit.py:115-160 (Encoder); accepts loop and scan param layouts."""
+  out = {}
+  if "encoderblock" in p:  # scan layout: leading depth axis (vit.py:129-148)
+    for lyr in range(depth):
+      pl = tree_map(lambda t, l=lyr: t[l], p["encoderblock"])
+      x, out[f"block{lyr:02d}"] = encoder_block(x, pl, num_heads)
+  else:
+    for lyr in range(depth):
+      x, out[f"block{lyr:02d}"] = encoder_block(x, p[f"encoderblock_{lyr}"], num_heads)
+    out["pre_ln"] = x
+  return layernorm(x, p["encoder_norm"]), out
+
+
+def map_head(x, p, num_heads):
+  """models/vit.py:163-183 (MAPHead)."""
+  n = x.shape[0]
+  probe = p["probe"].expand(n, -1, -1)
+  x = mha(probe, x, p["MultiHeadDotProductAttention_0"], num_heads)
+  y = layernorm(x, p["LayerNorm_0"])
+  x = x + mlp_block(y, p["MlpBlock_0"])
+  return x[:, 0]
+
+
+def posemb_sincos_2d(h, w, width, temperature=10_000.0, dtype=torch.float32):
+  """models/vit.py:34-44."""
+  y, x = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+  assert width % 4 == 0
+  omega = torch.arange(width // 4, dtype=torch.float64) / (width // 4 - 1)
+  omega = 1.0 / (temperature ** omega)
+  y = y.flatten().to(torch.float64)[:, None] * omega[None, :]
+  x = x.flatten().to(torch.float64)[:, None] * omega[None, :]
+  pe = torch.cat([torch.sin(x), torch.cos(x), torch.sin(y), torch.cos(y)], dim=1)
+  return pe.to(dtype)[None]
+
+
+def extract_patches(image, patch):
+  """NHWC image -> [n, h*w, ph*pw*3] in HWIO flattening order (row, col, chan).
+
+  Equivalent to the strided VALID conv of models/vit.py:212-217 (also
+  models/proj/flexi/vit_test.py:40-42: NHWC x HWIO).
+  """
+  n, H, W, C = image.shape
+  ph, pw = patch
+  h, w = H // ph, W // pw
+  x = image[:, :h * ph, :w * pw, :].reshape(n, h, ph, w, pw, C)
+  x = x.permute(0, 1, 3, 2, 4, 5).reshape(n, h * w, ph * pw * C)
+  return x, (h, w)
+
+
+# -----------------------------------------------------------------------------
+# Models
+# -----------------------------------------------------------------------------
+def vit_forward(params, image, *, num_classes=None, patch_size=(16, 16), width=768,
+                depth=12, mlp_dim=None, num_heads=12, posemb="learn",
+                rep_size=False, pool_type="gap", **_unused):
+  """models/vit.py:206-276 (_Model.__call__)."""
+  out = {}
+  patches, (h, w) = extract_patches(image, patch_size)
+  kern = params["embedding"]["kernel"]
+  x = patches @ kern.reshape(-1, kern.shape[-1]) + params["embedding"]["bias"]
+  out["stem"] = x.reshape(x.shape[0], h, w, -1)
+  if posemb == "learn":
+    pe = params["pos_embedding"]
+  elif posemb == "sincos2d":
+    pe = posemb_sincos_2d(h, w, width, dtype=x.dtype)
+  else:
+    raise ValueError(f"Unknown posemb type: {posemb}")
+  x = out["with_posemb"] = x + pe
+  n = x.shape[0]
+  if pool_type == "tok":
+    x = torch.cat([params["cls"].expand(n, -1, -1), x], dim=1)
+  x, out["encoder"] = encoder(x, params["Transformer"], depth, num_heads)
+  encoded = out["encoded"] = x
+  if pool_type == "map":
+    x = out["head_input"] = map_head(x, params["MAPHead_0"], num_heads)
+  elif pool_type == "gap":
+    x = out["head_input"] = x.mean(dim=1)
+  elif pool_type == "0":
+    x = out["head_input"] = x[:, 0]
+  elif pool_type == "tok":
+    x = out["head_input"] = x[:, 0]
+    encoded = encoded[:, 1:]
+  elif pool_type == "none":
+    pass
+  else:
+    raise ValueError(f"Unknown pool type: '{pool_type}'")
+  x_2d = encoded.reshape(n, h, w, -1)
+  if rep_size:
+    x_2d = torch.tanh(dense(x_2d, params["pre_logits"]))
+    x = torch.tanh(dense(x, params["pre_logits"]))
+  out["pre_logits_2d"] = x_2d
+  out["pre_logits"] = x
+  if num_classes:
+    x_2d = out["logits_2d"] = dense(x_2d, params["head"])
+    x = out["logits"] = dense(x, params["head"])
+  return x, out
+
+
+def text_forward(params, text, *, num_classes, width=512, depth=12, mlp_dim=2048,
+                 num_heads=8, vocab_size=32_000, pool_type="last", **_unused):
+  """models/proj/image_text/text_transformer.py:55-99."""
+  out = {}
+  emb = params["Embed_0"]["embedding"]
+  x = out["embedded"] = emb[text]
+  x = x + params["pos_embedding"]
+  x, enc_out = encoder(x, params["Encoder_0"], depth, num_heads)
+  out.update({"transformed": x, **enc_out})
+  out["vocab_logits"] = x @ emb.T
+  if pool_type == "last":
+    x = out["pre_logits"] = x[:, -1, :]
+  elif pool_type == "first":
+    x = out["pre_logits"] = x[:, 0, :]
+  elif pool_type in ("mean", "gap"):
+    x = out["pre_logits"] = x.mean(dim=1)
+  elif pool_type in ("max", "gmp"):
+    x = out["pre_logits"] = x.max(dim=1).values
+  elif pool_type == "map":
+    x = out["pre_logits"] = map_head(x, params["MAPHead_0"], num_heads)
+  else:
+    raise NotImplementedError(f"Cannot do pooling '{pool_type}'")
+  if num_classes:
+    x = out["logits"] = dense(x, params["head"])
+  return x, out
+
+
+def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim,
+                       **_unused):
+  """models/proj/image_text/two_towers.py:39-90."""
+  out = {}
+  out_dims = (out_dim, out_dim) if isinstance(out_dim, int) else tuple(out_dim)
+  zimg = ztxt = None
+  if text is not None:
+    kw = {**decode_variant(text_cfg.get("variant")),
+          **{k: v for k, v in text_cfg.items() if k != "variant"}}
+    ztxt, o = text_forward(params["txt"], text, num_classes=out_dims[1], **kw)
+    out.update({f"txt/{k}": v for k, v in o.items()})
+    out["txt/norm"] = torch.linalg.norm(ztxt, dim=1, keepdim=True)
+    out["txt/normalized"] = ztxt = ztxt / (out["txt/norm"] + 1e-8)
+  if image is not None:
+    kw = {**decode_variant(image_cfg.get("variant")),
+          **{k: v for k, v in image_cfg.items() if k != "variant"}}
+    zimg, o = vit_forward(params["img"], image, num_classes=out_dims[0], **kw)
+    out.update({f"img/{k}": v for k, v in o.items()})
+    out["img/norm"] = torch.linalg.norm(zimg, dim=1, keepdim=True)
+    out["img/normalized"] = zimg = zimg / (out["img/norm"] + 1e-8)
+  out["t"] = torch.exp(params["t"])
+  out["t/parameter"] = params["t"]
+  if "b" in params:
+    out["b"] = params["b"]
+  return zimg, ztxt, out
+
+
+# -----------------------------------------------------------------------------
+# Losses
+# -----------------------------------------------------------------------------
+def log_sigmoid(x):
+  """jax.nn.log_sigmoid = -softplus(-x), stable form."""
+  return torch.clamp(x, max=0.0) - torch.log1p(torch.exp(-x.abs()))
+
+
+def siglip_loss_global(zimg, ztxt, t, b):
+  """trainers/proj/image_text/siglip.py:291-306 (global-batch sigmoid loss)."""
+  logits = zimg @ ztxt.T * t + b
+  eye = torch.eye(zimg.shape[0], dtype=logits.dtype)
+  m1_diag1 = -torch.ones_like(logits) + 2 * eye
+  loglik = log_sigmoid(m1_diag1 * logits)
+  nll = -loglik.sum(dim=-1)
+  return nll.mean(), logits
+
+
+def sigmoid_loss_per_device(zimg_r, ztxt_shards, r, t, b=0.0):
+  """trainers/proj/image_text/_deprecated_contrastive.py:117-141 on "device" r.
+
+  `ztxt_shards` is the list of every device's local ztxt; device r keeps its
+  own chunk as "me" and sees the others rolled so that r's chunk would come
+  first and is dropped (all_gather(only_others=True), :67-77).
+  """
+  N = len(ztxt_shards)
+  ztxt_me = ztxt_shards[r]
+  others = [ztxt_shards[(r + k) % N] for k in range(1, N)]
+  logits_me = zimg_r @ ztxt_me.T * t + b
+  eye = torch.eye(zimg_r.shape[0], dtype=logits_me.dtype)
+  m1_diag1 = -torch.ones_like(logits_me) + 2 * eye
+  nll_me = -log_sigmoid(m1_diag1 * logits_me).sum(dim=-1)
+  l = nll_me.mean()
+  if others:
+    ztxt_ot = torch.cat(others, 0)
+    logits_ot = zimg_r @ ztxt_ot.T * t + b
+    l = l + (-log_sigmoid(-logits_ot).sum(dim=-1)).mean()
+  return l
+
+
+def chunked_sigmoid_loss_per_device(zimg_r, ztxt_shards, r, t, b=0.0):
+  """_deprecated_contrastive.py:168-200 (one broadcast per other device)."""
+  logits_me = zimg_r @ ztxt_shards[r].T * t + b
+  eye = torch.eye(zimg_r.shape[0], dtype=logits_me.dtype)
+  l = (-log_sigmoid((-torch.ones_like(logits_me) + 2 * eye) * logits_me).sum(-1)).mean()
+  for d, z in enumerate(ztxt_shards):
+    if d == r:
+      continue
+    logits_ot = zimg_r @ z.T * t + b
+    l = l + (-log_sigmoid(-logits_ot).sum(-1)).mean()
+  return l
+
+
+def softmax_loss_per_device(zimg_r, ztxt_r, zimg_shards, ztxt_shards, r, t):
+  """_deprecated_contrastive.py:80-101 (CLIP loss; before the pmean)."""
+  N = len(ztxt_shards)
+
+  def uni(z1, shards):
+    z2 = torch.cat([shards[(r + k) % N] for k in range(N)], 0)
+    logits = z1 @ z2.T * t
+    return -(torch.diagonal(logits) - torch.logsumexp(logits, dim=-1)).mean()
+
+  return 0.5 * uni(zimg_r, ztxt_shards) + 0.5 * uni(ztxt_r, zimg_shards)
+
+
+def softmax_xent(logits, labels):
+  """utils.py:276-281."""
+  return (-(labels * torch.log_softmax(logits, dim=-1)).sum(-1)).mean()
+
+
+def mixup(a, *things):
+  """utils.py:1146-1154 with a given mixing coefficient a (already max(a,1-a))."""
+  return tuple(a * t + (1 - a) * torch.roll(t, shifts=1, dims=0) for t in things)
+
+
+# -----------------------------------------------------------------------------
+# Tree helpers — utils.py:616-700, :1169-1212
+# -----------------------------------------------------------------------------
+def tree_map(f, tree, *rest):
+  if isinstance(tree, dict):
+    return {k: tree_map(f, tree[k], *[r[k] for r in rest]) for k in tree}
+  return f(tree, *rest)
+
+
+def tree_flatten_with_names(tree, prefix=""):
+  """utils.py:616-641: sorted-key traversal, '/'-joined names."""
+  if isinstance(tree, dict):
+    res = []
+    for k in sorted(tree.keys()):
+      res += tree_flatten_with_names(tree[k], f"{prefix}{k}/")
+    return res
+  return [(prefix.rstrip("/"), tree)]
+
+
+def recover_tree(names_and_vals):
+  tree = {}
+  for name, v in names_and_vals:
+    node = tree
+    parts = name.split("/")
+    for p in parts[:-1]:
+      node = node.setdefault(p, {})
+    node[parts[-1]] = v
+  return tree
+
+
+def make_masks(names: Sequence[str], patterns: Sequence[str]):
+  """utils.py:1195-1212: first-match-wins boolean masks, regex fullmatch."""
+  comp = []
+  for p in patterns:
+    assert not p.startswith("/"), p
+    comp.append(re.compile(p))
+  masks = [dict() for _ in patterns]
+  for n in names:
+    hit = False
+    for i, c in enumerate(comp):
+      m = (not hit) and bool(c.fullmatch(n))
+      masks[i][n] = m
+      hit = hit or m
+  return masks
+
+
+# -----------------------------------------------------------------------------
+# Schedules — utils.py:1002-1143
+# -----------------------------------------------------------------------------
+def steps(prefix, config, data_size=None, batch_size=None, total_steps=None,
+          default=ValueError):
+  """utils.py:1002-1067."""
+  suffixes = {"steps", "examples", "epochs", "percent"}
+  matches = {f"{prefix}_{s}" for s in suffixes
+             if (x := config.get(f"{prefix}_{s}")) is not None and x >= 0}
+  assert len(matches) <= 1, f"Only one of '{matches}' should be defined."
+  if f"{prefix}_steps" in matches:
+    return config[f"{prefix}_steps"]
+
+  def to_integer(x):
+    return max(1, round(x)) if x else 0
+
+  if batch_size and f"{prefix}_examples" in matches:
+    return to_integer(config[f"{prefix}_examples"] / batch_size)
+  if batch_size and data_size and f"{prefix}_epochs" in matches:
+    return to_integer(config[f"{prefix}_epochs"] * data_size / batch_size)
+  if total_steps and f"{prefix}_percent" in matches:
+    pct = config[f"{prefix}_percent"]
+    assert 0.0 <= pct <= 1.0
+    return to_integer(pct * total_steps)
+  if default is ValueError:
+    raise ValueError(f"Cannot convert {prefix} to steps")
+  return default
+
+
+def create_learning_rate_schedule(total_steps, batch_size=None, data_size=None,
+                                  base=1.0, decay_type="stair",
+                                  scale_with_batchsize=False, **kw):
+  """utils.py:1070-1143; returns step -> float (float64 python math)."""
+
+  def to_steps(name, default=0):
+    return steps(name, kw, data_size, batch_size, total_steps, default=default)
+
+  warmup_steps = to_steps("warmup")
+  cooldown_steps = to_steps("cooldown")
+  assert (total_steps <= 1) or (warmup_steps < total_steps)
+
+  def step_fn(step):
+    lr = base
+    if scale_with_batchsize:
+      lr = lr * batch_size / 256.0
+    progress = (step - warmup_steps) / float(total_steps - warmup_steps)
+    progress = min(max(progress, 0.0), 1.0)
+    if decay_type in ("linear", "polynomial"):
+      power = kw.get("power", 1)
+      zero = kw.get("end", kw.get("linear_end", 0))
+      lr = zero + (lr - zero) * (1.0 - progress) ** power
+    elif decay_type == "cosine":
+      lr = lr * 0.5 * (1.0 + math.cos(math.pi * progress))
+    elif decay_type == "rsqrt":
+      t = to_steps("timescale", default=kw.get("timescale", 10_000))
+      shift = to_steps("shift", default=kw.get("shift", 0))
+      if warmup_steps <= step:
+        lr = lr / math.sqrt(1 + (step + shift - warmup_steps) / t)
+      else:
+        lr = lr / math.sqrt(1 + shift / t)
+    elif decay_type == "stair":
+      i = int(np.searchsorted(np.array(kw.get("steps", [])), step + 1))
+      lr = lr * ([1.0] + list(kw.get("mults", [])))[i]
+    else:
+      raise ValueError(f"Unknown lr type {decay_type}")
+    if warmup_steps:
+      lr = lr * min(1.0, step / warmup_steps)
+    if cooldown_steps:
+      lr = lr * min(1.0, (total_steps - step) / cooldown_steps)
+    return float(np.float32(lr))
+
+  return step_fn
+
+
+# -----------------------------------------------------------------------------
+# Optimizer chain — optax.py:75-149 (bv_optax.make) restated on flat name->tensor
+# -----------------------------------------------------------------------------
+class OptaxOracle:
+  """Functional restatement of `bv_optax.make(config, params, sched_kw=...)`.
+
+  Chain order (optax.py:143-149): clip_by_global_norm(not frozen) ->
+  optimizer(not frozen) -> scale(lr) -> lr_mults -> add_decayed_weights ->
+  per-group scale_by_schedule / set_to_zero(frozen) -> scale(-1).
+  Supports optax_name in {"scale", "scale_by_adam", "identity"}.
+  """
+
+  def __init__(self, config: dict, params: Tree, *, sched_kw: dict):
+    self.config = config
+    flat = tree_flatten_with_names(params)
+    self.names = [n for n, _ in flat]
+    schedule = config.get("schedule", {})
+    if not isinstance(schedule, (tuple, list)):
+      schedule = [(".*", schedule)]
+    pats, scheds = zip(*schedule)
+    masks = make_masks(self.names, pats)
+    not_covered = [n for n in self.names if not any(m[n] for m in masks)]
+    assert not not_covered, f"All params must be covered: {not_covered}"
+    self.frozen = {n: any(m[n] for m, s in zip(masks, scheds) if s is None)
+                   for n in self.names}
+    self.sched_of = {}
+    self.schedule_fns = []
+    kw = dict(sched_kw)
+    if "global_batch_size" in kw:  # name used by optax_test.py:120
+      kw["batch_size"] = kw.pop("global_batch_size")
+    for m, s in zip(masks, scheds):
+      if s is None:
+        continue
+      s = dict(s)
+      mult = s.pop("mult", 1.0)
+      fn = create_learning_rate_schedule(base=mult, **kw, **s)
+      self.schedule_fns.append(fn)
+      for n in self.names:
+        if m[n]:
+          self.sched_of[n] = fn
+    self.lr_mult = {n: 1.0 for n in self.names}
+    if config.get("lr_mults"):
+      pats, mults = zip(*config["lr_mults"])
+      assert all(m > 0 for m in mults)
+      for m, mult in zip(make_masks(self.names, pats), mults):
+        for n in self.names:
+          if m[n]:
+            self.lr_mult[n] = mult
+    self.wd = {n: 0.0 for n in self.names}
+    if config.get("wd"):
+      wd_mults = config.get("wd_mults", [(".*/kernel$", 1.0)])
+      pats, mults = zip(*wd_mults)
+      for m, mult in zip(make_masks(self.names, pats), mults):
+        for n in self.names:
+          if m[n]:
+            self.wd[n] = config["wd"] * mult
+    self.name = config["optax_name"]
+    self.okw = dict(config.get("optax", {}))
+    self.count = 0
+    self.mu = {}
+    self.nu = {}
+    if self.name == "scale_by_adam":
+      for n, p in flat:
+        if not self.frozen[n]:  # optax_test.py:301-318: no state for frozen
+          self.mu[n] = torch.zeros_like(p)
+          self.nu[n] = torch.zeros_like(p)
+
+  def update(self, grads: Tree, params: Optional[Tree] = None) -> Tree:
+    g = dict(tree_flatten_with_names(grads))
+    p = dict(tree_flatten_with_names(params)) if params is not None else None
+    step = self.count
+    # clip_by_global_norm over not-frozen leaves (optax.py:100-105)
+    if (c := self.config.get("grad_clip_norm")):
+      sq = sum((g[n].double() ** 2).sum() for n in self.names if not self.frozen[n])
+      norm = torch.sqrt(sq)
+      factor = torch.clamp(c / norm, max=1.0).to(next(iter(g.values())).dtype) \
+          if float(norm) > 0 else torch.tensor(1.0)
+      g = {n: (g[n] if self.frozen[n] else g[n] * factor) for n in self.names}
+    upd = {}
+    for n in self.names:
+      if self.frozen[n]:
+        upd[n] = torch.zeros_like(g[n])
+        continue
+      u = g[n]
+      if self.name == "scale":
+        u = u * self.okw["step_size"]
+      elif self.name == "scale_by_adam":
+        b1 = self.okw.get("b1", 0.9)
+        b2 = self.okw.get("b2", 0.999)
+        eps = self.okw.get("eps", 1e-8)
+        mu = b1 * self.mu[n].to(u.dtype) + (1 - b1) * u
+        nu = b2 * self.nu[n] + (1 - b2) * u * u
+        k = step + 1
+        mu_hat = mu / (1 - b1 ** k)
+        nu_hat = nu / (1 - b2 ** k)
+        mu_dtype = self.okw.get("mu_dtype")
+        self.mu[n] = mu.to(torch.bfloat16) if mu_dtype == "bfloat16" else mu
+        self.nu[n] = nu
+        u = mu_hat / (torch.sqrt(nu_hat) + eps)
+      elif self.name == "identity":
+        pass
+      else:
+        raise NotImplementedError(self.name)
+      u = u * self.config["lr"] * self.lr_mult[n]
+      if self.wd[n]:
+        u = u + self.wd[n] * p[n]
+      u = u * self.sched_of[n](step)
+      upd[n] = -u
+    self.count += 1
+    return recover_tree([(n, upd[n]) for n in self.names])
+
+
+# -----------------------------------------------------------------------------
+# Parameter initialisation following the Flax initialisers
+# -----------------------------------------------------------------------------
+def _xavier_uniform(gen, shape, fan_in, fan_out, dtype):
+  lim = math.sqrt(6.0 / (fan_in + fan_out))
+  return (torch.rand(shape, generator=gen, dtype=dtype) * 2 - 1) * lim
+
+
+def _lecun_normal(gen, shape, fan_in, dtype):
+  # variance_scaling(1.0, "fan_in", "truncated_normal"); plain normal is used
+  # here (same variance) — initial values never enter a parity comparison.
+  return torch.randn(shape, generator=gen, dtype=dtype) * math.sqrt(1.0 / fan_in)
+
+
+def _init_mha(gen, d, h, dtype):
+  dh = d // h
+  p = {}
+  for name in ("query", "key", "value"):
+    p[name] = {"kernel": _xavier_uniform(gen, (d, h, dh), d, d, dtype),
+               "bias": torch.zeros(h, dh, dtype=dtype)}
+  p["out"] = {"kernel": _xavier_uniform(gen, (h, dh, d), d, d, dtype),
+              "bias": torch.zeros(d, dtype=dtype)}
+  return p
+
+
+def _init_mlp(gen, d, m, dtype):
+  return {
+      "Dense_0": {"kernel": _xavier_uniform(gen, (d, m), d, m, dtype),
+                  "bias": torch.randn(m, generator=gen, dtype=dtype) * 1e-6},
+      "Dense_1": {"kernel": _xavier_uniform(gen, (m, d), m, d, dtype),
+                  "bias": torch.randn(d, generator=gen, dtype=dtype) * 1e-6},
+  }
+
+
+def _init_ln(d, dtype):
+  return {"scale": torch.ones(d, dtype=dtype), "bias": torch.zeros(d, dtype=dtype)}
+
+
+def _init_encoder(gen, depth, d, m, h, dtype):
+  p = {}
+  for i in range(depth):
+    p[f"encoderblock_{i}"] = {
+        "LayerNorm_0": _init_ln(d, dtype),
+        "MultiHeadDotProductAttention_0": _init_mha(gen, d, h, dtype),
+        "LayerNorm_1": _init_ln(d, dtype),
+        "MlpBlock_0": _init_mlp(gen, d, m, dtype),
+    }
+  p["encoder_norm"] = _init_ln(d, dtype)
+  return p
+
+
+def _init_map(gen, d, m, h, dtype):
+  return {"probe": _xavier_uniform(gen, (1, 1, d), d, d, dtype),
+          "MultiHeadDotProductAttention_0": _init_mha(gen, d, h, dtype),
+          "LayerNorm_0": _init_ln(d, dtype),
+          "MlpBlock_0": _init_mlp(gen, d, m, dtype)}
+
+
+def init_vit(gen, image_hw, *, num_classes=None, patch_size=(16, 16), width=768,
+             depth=12, mlp_dim=None, num_heads=12, posemb="learn", rep_size=False,
+             pool_type="gap", head_zeroinit=True, dtype=torch.float32, **_):
+  mlp_dim = mlp_dim or 4 * width
+  ph, pw = patch_size
+  h, w = image_hw[0] // ph, image_hw[1] // pw
+  p = {"embedding": {
+      "kernel": _lecun_normal(gen, (ph, pw, 3, width), ph * pw * 3, dtype),
+      "bias": torch.zeros(width, dtype=dtype)}}
+  if posemb == "learn":
+    p["pos_embedding"] = torch.randn((1, h * w, width), generator=gen, dtype=dtype) / math.sqrt(width)
+  if pool_type == "tok":
+    p["cls"] = torch.zeros(1, 1, width, dtype=dtype)
+  p["Transformer"] = _init_encoder(gen, depth, width, mlp_dim, num_heads, dtype)
+  if pool_type == "map":
+    p["MAPHead_0"] = _init_map(gen, width, mlp_dim, num_heads, dtype)
+  feat = width
+  if rep_size:
+    rs = width if rep_size is True else rep_size
+    p["pre_logits"] = {"kernel": _lecun_normal(gen, (width, rs), width, dtype),
+                       "bias": torch.zeros(rs, dtype=dtype)}
+    feat = rs
+  if num_classes:
+    k = (torch.zeros(feat, num_classes, dtype=dtype) if head_zeroinit
+         else _lecun_normal(gen, (feat, num_classes), feat, dtype))
+    p["head"] = {"kernel": k, "bias": torch.zeros(num_classes, dtype=dtype)}
+  return p
+
+
+def init_text(gen, seq_len, *, num_classes, width=512, depth=12, mlp_dim=2048,
+              num_heads=8, vocab_size=32_000, pool_type="last",
+              dtype=torch.float32, **_):
+  p = {"Embed_0": {"embedding": torch.randn((vocab_size, width), generator=gen, dtype=dtype) / math.sqrt(width)},
+       "pos_embedding": torch.randn((1, seq_len, width), generator=gen, dtype=dtype) / math.sqrt(width),
+       "Encoder_0": _init_encoder(gen, depth, width, mlp_dim, num_heads, dtype)}
+  if pool_type == "map":
+    p["MAPHead_0"] = _init_map(gen, width, mlp_dim, num_heads, dtype)
+  if num_classes:
+    p["head"] = {"kernel": _lecun_normal(gen, (width, num_classes), width, dtype),
+                 "bias": torch.zeros(num_classes, dtype=dtype)}
+  return p
+
+
+def init_two_towers(seed, image_hw, seq_len, *, image_cfg, text_cfg, out_dim,
+                    temperature_init=1.0, bias_init=None, dtype=torch.float32):
+  gen = torch.Generator().manual_seed(seed)
+  out_dims = (out_dim, out_dim) if isinstance(out_dim, int) else tuple(out_dim)
+  ikw = {**decode_variant(image_cfg.get("variant")), **{k: v for k, v in image_cfg.items() if k != "variant"}}
+  tkw = {**decode_variant(text_cfg.get("variant")), **{k: v for k, v in text_cfg.items() if k != "variant"}}
+  p = {"img": init_vit(gen, image_hw, num_classes=out_dims[0], dtype=dtype, **ikw),
+       "txt": init_text(gen, seq_len, num_classes=out_dims[1], dtype=dtype, **tkw),
+       "t": torch.full((1,), math.log(temperature_init), dtype=dtype)}
+  if bias_init is not None:
+    p["b"] = torch.full((1,), float(bias_init), dtype=dtype)
+  return p
+
+
+def synthetic_batch(seed, n, res, seq_len, vocab_size=32_000, dtype=torch.float32):
+  """U(-1,1) NHWC images; sticky-EOS tokens (pp/ops_text.py:143-155)."""
+  gen = torch.Generator().manual_seed(seed)
+  image = torch.rand((n, res, res, 3), generator=gen, dtype=torch.float32) * 2 - 1
+  text = torch.randint(2, vocab_size, (n, seq_len), generator=gen, dtype=torch.int64)
+  lens = torch.randint(min(4, seq_len - 1), seq_len, (n,), generator=gen)
+  pos = torch.arange(seq_len)[None, :]
+  text = torch.where(pos >= lens[:, None], torch.ones_like(text), text)
+  return image.to(dtype), text.to(torch.int32)
+
+
+def siglip_step_loss(params, image, text, *, image_cfg, text_cfg, out_dim):
+  """siglip.py:287-308 loss_fn: model.apply -> global sigmoid loss."""
+  zimg, ztxt, out = two_towers_forward(
+      params, image, text.long(), image_cfg=image_cfg, text_cfg=text_cfg, out_dim=out_dim)
+  loss, logits = siglip_loss_global(zimg, ztxt, out["t"], out["b"])
+  return loss, (zimg, ztxt, logits, out)
