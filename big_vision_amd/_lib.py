@@ -1,0 +1,79 @@
+"""ctypes binding of libbvhip.so (the C ABI declared in include/bvhip.h).
+
+The product path has NO fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  Build it with `python big_vision_amd/build.py`
+(or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+from ctypes import c_int, c_long, c_float, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbvhip.so")
+
+P = c_void_p
+
+# name -> argtypes (return type is always int, except bv_last_error)
+PROTOTYPES = {
+    "bv_version": [],
+    "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
+                     c_int, P, P, c_long, c_int, P, c_float, c_int, P],
+    "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
+                         c_float, c_float, P],
+    "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
+    "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
+    "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
+    "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_patchify": [P, P, c_int, c_int, c_int, c_int, P],
+    "bv_embed_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_embed_bwd": [P, P, P, c_int, c_int, c_int, P],
+    "bv_colsum": [P, c_int, c_long, P, c_int, c_int, P],
+    "bv_batchsum": [P, P, c_int, c_int, c_int, P],
+    "bv_cast_bf16": [P, P, c_long, P],
+    "bv_concat_cls": [P, P, P, c_int, c_int, c_int, P],
+    "bv_pool_gap_fwd": [P, P, c_int, c_int, c_int, P],
+    "bv_pool_gap_bwd": [P, P, c_int, c_int, c_int, P],
+    "bv_l2norm_fwd": [P, P, P, c_int, c_int, c_float, P],
+    "bv_l2norm_bwd": [P, P, P, P, c_int, c_int, c_float, P],
+    "bv_siglip_loss": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_softmax_xent": [P, P, P, P, c_int, c_int, P],
+    "bv_sqnorm": [P, c_long, P, P],
+    "bv_adam_step": [P, P, P, c_int, P, P, P, P, c_long, P, c_float, c_float, c_float, c_float,
+                     c_float, c_float, P, P],
+}
+
+EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC = range(6)
+
+_lib = None
+
+
+def load():
+  """Loads libbvhip.so (once).  Raises if it is not built — no fallback."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+        "`python big_vision_amd/build.py`. There is no CPU/eager fallback.")
+  lib = ctypes.CDLL(LIB_PATH)
+  lib.bv_last_error.restype = ctypes.c_char_p
+  lib.bv_last_error.argtypes = []
+  for name, argtypes in PROTOTYPES.items():
+    fn = getattr(lib, name)  # AttributeError if the ABI drifted
+    fn.restype = c_int
+    fn.argtypes = argtypes
+  if lib.bv_version() != 1:
+    raise RuntimeError("libbvhip.so ABI version mismatch")
+  _lib = lib
+  return lib
+
+
+def call(name, *args):
+  lib = load()
+  rc = getattr(lib, name)(*args)
+  if rc != 0:
+    raise RuntimeError(f"{name} failed (rc={rc}): {lib.bv_last_error().decode()}")

@@ -1,0 +1,368 @@
+// HBM-bound helper kernels of the SigLIP/ViT step for gfx950: patchify, token
+// embedding gather / scatter-add, column / batch reductions, casts, pooling,
+// L2 normalisation.  All accesses are 16-byte vectors, coalesced along the
+// fastest axis; reductions pre-reduce per workgroup before fp32 atomics.
+// Reference call sites are cited at each entry point (paths relative to
+// big_vision/ in the reference tree).
+#include "bv_common.h"
+#include "bvhip_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------- patchify --
+// out[(i*h*w + py*w + px)][r*P*3 + c*3 + ch] = image[i][py*P + r][px*P + c][ch]
+// One thread converts 8 consecutive output elements (they are contiguous in
+// the input as well because P*3 % 8 == 0).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
+                                                       bf16* __restrict__ out, int n, int Hi,
+                                                       int Wi, int P, int h, int w) {
+  const int K = P * P * 3;
+  const int P3 = P * 3;
+  const long total8 = (long)n * h * w * K / 8;
+  for (long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x; i8 < total8;
+       i8 += (long)gridDim.x * blockDim.x) {
+    const long o = i8 * 8;
+    const long row = o / K;
+    const int within = (int)(o - row * K);
+    const int r = within / P3, cc = within - r * P3;
+    const int px = (int)(row % w);
+    const long t = row / w;
+    const int py = (int)(t % h);
+    const long i = t / h;
+    const float* src = img + ((i * Hi + (long)py * P + r) * Wi + (long)px * P) * 3 + cc;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    uint4 p;
+    p.x = pack_bf2(a.x, a.y);
+    p.y = pack_bf2(a.z, a.w);
+    p.z = pack_bf2(b.x, b.y);
+    p.w = pack_bf2(b.z, b.w);
+    *reinterpret_cast<uint4*>(out + o) = p;
+  }
+}
+
+// generic (any P): one thread per output element
+__global__ __launch_bounds__(256) void patchify_scalar_kernel(const float* __restrict__ img,
+                                                              bf16* __restrict__ out, int n, int Hi,
+                                                              int Wi, int P, int h, int w) {
+  const int K = P * P * 3;
+  const int P3 = P * 3;
+  const long total = (long)n * h * w * K;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (long)gridDim.x * blockDim.x) {
+    const long row = o / K;
+    const int within = (int)(o - row * K);
+    const int r = within / P3, cc = within - r * P3;
+    const int px = (int)(row % w);
+    const long t = row / w;
+    const int py = (int)(t % h);
+    const long i = t / h;
+    out[o] = f2bf(img[((i * Hi + (long)py * P + r) * Wi + (long)px * P) * 3 + cc]);
+  }
+}
+
+// ---------------------------------------------------------------- embedding --
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ ids,
+                                                        const float* __restrict__ table,
+                                                        const float* __restrict__ pos,
+                                                        float* __restrict__ x, long rows, int L,
+                                                        int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nw) {
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* src = table + (long)id * D;
+    const float* ps = pos + (long)(r % L) * D;
+    float* dst = x + r * D;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(src + c);
+      const float4 b = *reinterpret_cast<const float4*>(ps + c);
+      *reinterpret_cast<float4*>(dst + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ ids,
+                                                        const float* __restrict__ dx,
+                                                        float* __restrict__ dtable, long rows,
+                                                        int D, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nw = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nw) {
+    int id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float* dst = dtable + (long)id * D;
+    const float* src = dx + r * D;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(src + c);
+      unsafeAtomicAdd(dst + c + 0, a.x);
+      unsafeAtomicAdd(dst + c + 1, a.y);
+      unsafeAtomicAdd(dst + c + 2, a.z);
+      unsafeAtomicAdd(dst + c + 3, a.w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ colsum --
+// out[c] += sum_r x[r][c].  Workgroup = 64 columns x ROWS_PER_BLOCK rows;
+// thread (tx = t&7 -> 8 columns, ty = t>>3 -> row lane).
+constexpr int CS_ROWS = 1024;
+template <bool F32>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x_, long ldx,
+                                                     float* __restrict__ out, int rows, int cols) {
+  __shared__ float red[32][65];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int c0 = blockIdx.x * 64 + tx * 8;
+  const int r0 = blockIdx.y * CS_ROWS;
+  const int r1 = min(rows, r0 + CS_ROWS);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < cols) {
+    for (int r = r0 + ty; r < r1; r += 32) {
+      if constexpr (F32) {
+        const float* p = reinterpret_cast<const float*>(x_) + (long)r * ldx + c0;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(x_) + (long)r * ldx + c0);
+        acc[0] += bflo(u.x); acc[1] += bfhi(u.x); acc[2] += bflo(u.y); acc[3] += bfhi(u.y);
+        acc[4] += bflo(u.z); acc[5] += bfhi(u.z); acc[6] += bflo(u.w); acc[7] += bfhi(u.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += red[j][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < cols) unsafeAtomicAdd(out + c, s);
+  }
+}
+
+// ---------------------------------------------------------------- batchsum --
+// out[j] += sum_i x[i][j], j over L*D (fp32), i over n split across blockIdx.y
+__global__ __launch_bounds__(256) void batchsum_kernel(const float* __restrict__ x,
+                                                       float* __restrict__ out, int n, long LD,
+                                                       int n_per) {
+  const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j >= LD) return;
+  const int i0 = blockIdx.y * n_per, i1 = min(n, i0 + n_per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = i0; i < i1; ++i) {
+    const float4 a = *reinterpret_cast<const float4*>(x + (long)i * LD + j);
+    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+  }
+  unsafeAtomicAdd(out + j + 0, s.x);
+  unsafeAtomicAdd(out + j + 1, s.y);
+  unsafeAtomicAdd(out + j + 2, s.z);
+  unsafeAtomicAdd(out + j + 3, s.w);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x,
+                                                        bf16* __restrict__ y, long count) {
+  const long n8 = count / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 8);
+    const float4 b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    uint4 p;
+    p.x = pack_bf2(a.x, a.y); p.y = pack_bf2(a.z, a.w);
+    p.z = pack_bf2(b.x, b.y); p.w = pack_bf2(b.z, b.w);
+    *reinterpret_cast<uint4*>(y + i * 8) = p;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = n8 * 8 + threadIdx.x; i < count; i += 256) y[i] = f2bf(x[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void concat_cls_kernel(const float* __restrict__ cls,
+                                                         const float* __restrict__ x,
+                                                         float* __restrict__ y, int n, int L, int D) {
+  const long total4 = (long)n * (L + 1) * D / 4;
+  const int D4 = D / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long row = i / D4;
+    const int c = (int)(i - row * D4) * 4;
+    const long b = row / (L + 1);
+    const int l = (int)(row - b * (L + 1));
+    float4 v;
+    if (l == 0) v = *reinterpret_cast<const float4*>(cls + c);
+    else v = *reinterpret_cast<const float4*>(x + (b * L + (l - 1)) * D + c);
+    *reinterpret_cast<float4*>(y + row * D + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_gap_fwd_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int n, int L, int D) {
+  const int D4 = D / 4;
+  const long total = (long)n * D4;
+  const float inv = 1.0f / (float)L;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / D4;
+    const int c = (int)(i - b * D4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < L; ++l) {
+      const float4 a = *reinterpret_cast<const float4*>(x + (b * L + l) * D + c);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    *reinterpret_cast<float4*>(y + b * D + c) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+__global__ __launch_bounds__(256) void pool_gap_bwd_kernel(const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int n, int L, int D) {
+  const int D4 = D / 4;
+  const long total = (long)n * L * D4;
+  const float inv = 1.0f / (float)L;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / D4;
+    const int c = (int)(i - row * D4) * 4;
+    const long b = row / L;
+    const float4 a = *reinterpret_cast<const float4*>(dy + b * D + c);
+    *reinterpret_cast<float4*>(dx + row * D + c) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  }
+}
+
+// ------------------------------------------------------------------ l2norm --
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ z,
+                                                         float* __restrict__ zn,
+                                                         float* __restrict__ norm, int rows, int D,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* zr = z + (long)r * D;
+  float ss = 0.f;
+  for (int c = lane; c < D; c += 64) ss += zr[c] * zr[c];
+  ss = wave_sum(ss);
+  const float s = sqrtf(ss);
+  if (lane == 0) norm[r] = s;
+  const float inv = 1.0f / (s + eps);
+  for (int c = lane; c < D; c += 64) zn[(long)r * D + c] = zr[c] * inv;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ z,
+                                                         const float* __restrict__ norm,
+                                                         const float* __restrict__ dzn,
+                                                         float* __restrict__ dz, int rows, int D,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* zr = z + (long)r * D;
+  const float* gr = dzn + (long)r * D;
+  const float s = norm[r];
+  const float inv = 1.0f / (s + eps);
+  float dot = 0.f;  // zn . dzn
+  for (int c = lane; c < D; c += 64) dot += zr[c] * inv * gr[c];
+  dot = wave_sum(dot);
+  const float k = s > 0.f ? dot / (s * (s + eps)) : 0.f;
+  for (int c = lane; c < D; c += 64) dz[(long)r * D + c] = gr[c] * inv - zr[c] * k;
+}
+
+inline int grid_for(long work_items, int per_block, int cap) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// models/vit.py:212-217 — im2col of the stride-P VALID patch conv.
+extern "C" int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream) {
+  BV_REQUIRE(n > 0 && Hi >= P && Wi >= P && P > 0, "bv_patchify: bad shape n=%d Hi=%d Wi=%d P=%d", n, Hi, Wi, P);
+  const int h = Hi / P, w = Wi / P;
+  const long total = (long)n * h * w * P * P * 3;
+  if ((P * 3) % 8 == 0 && (Wi * 3) % 4 == 0 && ((uintptr_t)image % 16 == 0)) {
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total / 8, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, image, (bf16*)patches, n, Hi, Wi, P, h, w);
+  } else {
+    hipLaunchKernelGGL(patchify_scalar_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, image, (bf16*)patches, n, Hi, Wi, P, h, w);
+  }
+  return bv_check_launch("bv_patchify");
+}
+
+// models/proj/image_text/text_transformer.py:63-70
+extern "C" int bv_embed_fwd(const int* ids, const float* table, const float* pos, float* x, int n,
+                            int L, int D, int vocab, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0 && vocab > 0, "bv_embed_fwd: bad shape n=%d L=%d D=%d", n, L, D);
+  const long rows = (long)n * L;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     ids, table, pos, x, rows, L, D, vocab);
+  return bv_check_launch("bv_embed_fwd");
+}
+extern "C" int bv_embed_bwd(const int* ids, const float* dx, float* dtable, int rows, int D, int vocab,
+                            void* stream) {
+  BV_REQUIRE(rows > 0 && D % 4 == 0 && vocab > 0, "bv_embed_bwd: bad shape rows=%d D=%d", rows, D);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     ids, dx, dtable, (long)rows, D, vocab);
+  return bv_check_launch("bv_embed_bwd");
+}
+
+extern "C" int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int cols,
+                         void* stream) {
+  BV_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0, "bv_colsum: rows=%d cols=%d ldx=%ld (cols, ldx %% 8)", rows, cols, ldx);
+  dim3 grid((cols + 63) / 64, (rows + CS_ROWS - 1) / CS_ROWS);
+  if (x_is_f32) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows, cols);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, out, rows, cols);
+  return bv_check_launch("bv_colsum");
+}
+
+extern "C" int bv_batchsum(const float* x, float* out, int n, int L, int D, void* stream) {
+  const long LD = (long)L * D;
+  BV_REQUIRE(n > 0 && LD > 0 && LD % 4 == 0, "bv_batchsum: bad shape n=%d L=%d D=%d", n, L, D);
+  const int ny = n >= 64 ? 8 : 1;
+  const int n_per = (n + ny - 1) / ny;
+  dim3 grid((unsigned)((LD / 4 + 255) / 256), ny);
+  hipLaunchKernelGGL(batchsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, n, LD, n_per);
+  return bv_check_launch("bv_batchsum");
+}
+
+extern "C" int bv_cast_bf16(const float* x, void* y, long count, void* stream) {
+  BV_REQUIRE(count > 0, "bv_cast_bf16: empty");
+  BV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "bv_cast_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(count / 8 + 1, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, x, (bf16*)y, count);
+  return bv_check_launch("bv_cast_bf16");
+}
+
+// models/vit.py:223-225
+extern "C" int bv_concat_cls(const float* cls, const float* x, float* y, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0, "bv_concat_cls: bad shape");
+  hipLaunchKernelGGL(concat_cls_kernel, dim3(grid_for((long)n * (L + 1) * D / 4, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, cls, x, y, n, L, D);
+  return bv_check_launch("bv_concat_cls");
+}
+
+// models/vit.py:246
+extern "C" int bv_pool_gap_fwd(const float* x, float* y, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0, "bv_pool_gap_fwd: bad shape");
+  hipLaunchKernelGGL(pool_gap_fwd_kernel, dim3(grid_for((long)n * D / 4, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, n, L, D);
+  return bv_check_launch("bv_pool_gap_fwd");
+}
+extern "C" int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0, "bv_pool_gap_bwd: bad shape");
+  hipLaunchKernelGGL(pool_gap_bwd_kernel, dim3(grid_for((long)n * L * D / 4, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, n, L, D);
+  return bv_check_launch("bv_pool_gap_bwd");
+}
+
+// models/proj/image_text/two_towers.py:60-61,73-74
+extern "C" int bv_l2norm_fwd(const float* z, float* zn, float* norm, int rows, int D, float eps, void* stream) {
+  BV_REQUIRE(rows > 0 && D > 0, "bv_l2norm_fwd: bad shape");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, zn, norm, rows, D, eps);
+  return bv_check_launch("bv_l2norm_fwd");
+}
+extern "C" int bv_l2norm_bwd(const float* z, const float* norm, const float* dzn, float* dz, int rows,
+                             int D, float eps, void* stream) {
+  BV_REQUIRE(rows > 0 && D > 0, "bv_l2norm_bwd: bad shape");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, norm, dzn, dz, rows, D, eps);
+  return bv_check_launch("bv_l2norm_bwd");
+}

@@ -1,0 +1,302 @@
+// bf16 MFMA GEMM for gfx950 (MI355X): C[M,N] = A(M x K) * B(K x N), fp32 accumulate.
+//
+// Replaces the XLA-lowered lax.dot_general calls behind flax nn.Dense /
+// nn.DenseGeneral / nn.Conv(stem) on the hot path
+// (reference big_vision/models/vit.py:72,77,93-98,212-214,261,272;
+//  models/proj/image_text/text_transformer.py:98) and their transposes in the
+// backward pass (jax.value_and_grad, trainers/proj/image_text/siglip.py:311).
+//
+// Tile: 128x128x64 per 256-thread workgroup (4 waves as 2x2, each 64x64 =
+// 4x4 fragments of v_mfma_f32_16x16x32_bf16), LDS double-buffered (64 KiB, two
+// workgroups per CU), register-staged global->LDS so that either operand may
+// be "K-major" (reduction dim contiguous: 16-byte loads along K) or
+// "K-minor" (reduction dim is the slow axis: 4x8 blocks transposed in
+// registers and written as 8-byte K-runs).  One LDS image for all variants:
+//   tile[row][64 k] bf16, 128 B per row, 16-byte chunk c stored at
+//   c ^ swz(row), swz(row) = (row ^ (row >> 3)) & 7.
+// The MFMA is issued "swapped" (first operand = B rows, second = A rows) so a
+// lane ends up with 4 consecutive output columns of one output row, giving 8/16
+// byte epilogue accesses.
+#include "bv_common.h"
+#include "bvhip_internal.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const void* aux;
+  long lda, ldb, ldc, ldaux;
+  int M, N, K;
+  int aux_rows;
+  int k_chunk;
+  int epi;
+  int out_f32;
+  float alpha;
+};
+
+__device__ __forceinline__ int swz(int row) { return (row ^ (row >> 3)) & 7; }
+
+// ---- global -> registers ---------------------------------------------------
+// K-major operand: memory P[row][k], k contiguous.  Thread t owns chunk (t&7)
+// of rows (t>>3) + 32*i.
+__device__ __forceinline__ void gload_kmajor(uint4 (&r)[4], const bf16* P, long ld, int R,
+                                             int row0, int k0, int kend, int tid) {
+  const int c = tid & 7;
+  const int gk = k0 + c * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int grow = row0 + (tid >> 3) + 32 * i;
+    if (grow < R && gk < kend) {
+      r[i] = *reinterpret_cast<const uint4*>(P + (long)grow * ld + gk);
+    } else {
+      r[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+// K-minor operand: memory P[k][row], row contiguous.  Thread t owns the 4(k) x
+// 8(row) block at k = 4*(t>>4), row = 8*(t&15).
+__device__ __forceinline__ void gload_kminor(uint4 (&r)[4], const bf16* P, long ld, int R,
+                                             int row0, int k0, int kend, int tid) {
+  const int grow = row0 + (tid & 15) * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gk = k0 + (tid >> 4) * 4 + j;
+    if (grow < R && gk < kend) {
+      r[j] = *reinterpret_cast<const uint4*>(P + (long)gk * ld + grow);
+    } else {
+      r[j] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+// ---- registers -> LDS -------------------------------------------------------
+__device__ __forceinline__ void sstore_kmajor(const uint4 (&r)[4], char* tile, int tid) {
+  const int c = tid & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ swz(row)) << 4)) = r[i];
+  }
+}
+__device__ __forceinline__ void sstore_kminor(const uint4 (&r)[4], char* tile, int tid) {
+  const int r0 = (tid & 15) * 8;
+  const int kg = tid >> 4;  // k = 4*kg .. 4*kg+3
+  const int chunk = kg >> 1, half = kg & 1;
+  const uint32_t w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w},
+                            {r[1].x, r[1].y, r[1].z, r[1].w},
+                            {r[2].x, r[2].y, r[2].z, r[2].w},
+                            {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int d = e >> 1;
+    uint2 o;
+    if ((e & 1) == 0) {
+      o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+      o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+    } else {
+      o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+      o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+    }
+    const int row = r0 + e;
+    *reinterpret_cast<uint2*>(tile + row * 128 + ((chunk ^ swz(row)) << 4) + half * 8) = o;
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ void gload(uint4 (&r)[4], const bf16* P, long ld, int R, int row0,
+                                      int k0, int kend, int tid) {
+  if constexpr (KM) gload_kmajor(r, P, ld, R, row0, k0, kend, tid);
+  else gload_kminor(r, P, ld, R, row0, k0, kend, tid);
+}
+template <bool KM>
+__device__ __forceinline__ void sstore(const uint4 (&r)[4], char* tile, int tid) {
+  if constexpr (KM) sstore_kmajor(r, tile, tid);
+  else sstore_kminor(r, tile, tid);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk) {
+  const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 128 + ((chunk ^ swz(row)) << 4));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool A_KM, bool B_KM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  gload<A_KM>(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
+  gload<B_KM>(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+  sstore<A_KM>(ra, smem, tid);
+  sstore<B_KM>(rb, smem + TILE_BYTES, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sA = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* sB = sA + TILE_BYTES;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      gload<A_KM>(ra, p.A, p.lda, p.M, m0, k0, kend, tid);
+      gload<B_KM>(rb, p.B, p.ldb, p.N, n0, k0, kend, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = lds_frag(sA, wm * 64 + i * 16 + lr, ks * 4 + lg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = lds_frag(sB, wn * 64 + j * 16 + lr, ks * 4 + lg);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* dA = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      sstore<A_KM>(ra, dA, tid);
+      sstore<B_KM>(rb, dA + TILE_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m][n..n+3], m = m_base + lr, n = n_base + 4*lg
+  const int epi = p.epi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + lr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
+      if (epi == BV_EPI_ATOMIC) {
+        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, v[r]);
+        continue;
+      }
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (epi == BV_EPI_RESIDUAL) {
+        const float4 x = *reinterpret_cast<const float4*>(
+            reinterpret_cast<const float*>(p.aux) + (long)m * p.ldaux + n);
+        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+      } else if (epi == BV_EPI_POS) {
+        const float4 x = *reinterpret_cast<const float4*>(
+            reinterpret_cast<const float*>(p.aux) + (long)(m % p.aux_rows) * p.ldaux + n);
+        v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+      } else if (epi == BV_EPI_GELU_BWD) {
+        const uint2 h = *reinterpret_cast<const uint2*>(
+            reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + n);
+        v[0] *= gelu_tanh_grad_f(bflo(h.x));
+        v[1] *= gelu_tanh_grad_f(bfhi(h.x));
+        v[2] *= gelu_tanh_grad_f(bflo(h.y));
+        v[3] *= gelu_tanh_grad_f(bfhi(h.y));
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
+        if (epi == BV_EPI_GELU) {
+          uint2 g;
+          g.x = pack_bf2(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]));
+          g.y = pack_bf2(gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + n) = g;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// See include/bvhip.h for the contract.
+extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
+                            long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
+                            int epilogue, const float* bias, const void* aux, long ldaux,
+                            int aux_rows, void* C2, float alpha, int split_k, void* stream) {
+  BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
+  BV_REQUIRE(N % 8 == 0, "bv_gemm_bf16: N=%d must be a multiple of 8", N);
+  BV_REQUIRE(a_kmajor ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0),
+             "bv_gemm_bf16: A contiguous dim / lda must be multiples of 8 (M=%d K=%d lda=%ld)", M, K, lda);
+  BV_REQUIRE(b_kmajor ? (K % 8 == 0 && ldb % 8 == 0) : (ldb % 8 == 0),
+             "bv_gemm_bf16: B contiguous dim / ldb must be multiples of 8 (N=%d K=%d ldb=%ld)", N, K, ldb);
+  BV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0),
+             "bv_gemm_bf16: operand pointers must be 16-byte aligned");
+  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_ATOMIC, "bv_gemm_bf16: bad epilogue %d", epilogue);
+  BV_REQUIRE(ldc % 4 == 0, "bv_gemm_bf16: ldc=%ld must be a multiple of 4", ldc);
+  if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_GELU_BWD)
+    BV_REQUIRE(aux != nullptr && ldaux % 4 == 0, "bv_gemm_bf16: epilogue %d needs aux (ldaux %% 4 == 0)", epilogue);
+  if (epilogue == BV_EPI_POS) BV_REQUIRE(aux_rows > 0, "bv_gemm_bf16: POS epilogue needs aux_rows > 0");
+  if (epilogue == BV_EPI_GELU) BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: GELU epilogue needs bf16 C and C2");
+  if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
+    BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
+  if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
+
+  GemmParams p;
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.C2 = C2;
+  p.bias = bias; p.aux = aux;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+  p.M = M; p.N = N; p.K = K; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
+  p.epi = epilogue; p.out_f32 = out_f32; p.alpha = alpha;
+
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  int splits = 1;
+  if (epilogue == BV_EPI_ATOMIC) {
+    const int ksteps = (K + BK - 1) / BK;
+    if (split_k > 0) {
+      splits = split_k;
+    } else {
+      // aim for >= 1024 workgroups (256 CUs x 2 resident x 2 waves of work)
+      // while keeping >= 8 K-steps per split.
+      splits = (1024 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n);
+      const int max_splits = ksteps / 8 > 0 ? ksteps / 8 : 1;
+      if (splits > max_splits) splits = max_splits;
+    }
+    if (splits < 1) splits = 1;
+    if (splits > ksteps) splits = ksteps;
+    const int steps_per = (ksteps + splits - 1) / splits;
+    p.k_chunk = steps_per * BK;
+    splits = (K + p.k_chunk - 1) / p.k_chunk;
+  } else {
+    p.k_chunk = ((K + BK - 1) / BK) * BK;
+  }
+  BV_REQUIRE(tiles_m <= 65535 && splits <= 65535, "bv_gemm_bf16: grid too large");
+  dim3 grid(tiles_n, tiles_m, splits), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
+  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+  else if (!a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
+  return bv_check_launch("bv_gemm_bf16");
+}

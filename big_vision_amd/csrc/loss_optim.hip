@@ -1,0 +1,302 @@
+// Sigmoid loss, softmax cross-entropy, fp32 strided GEMM, grad-norm and the
+// fused optimizer chain for gfx950.  fp32 arithmetic throughout (the logits are
+// scaled by t = exp(t') ~ 10..100, so bf16 would be visible in the loss).
+#include "bv_common.h"
+#include "bvhip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------- siglip loss --
+// trainers/proj/image_text/siglip.py:291-306.  raw[n][B] -> G in place.
+__global__ __launch_bounds__(256) void siglip_loss_kernel(float* __restrict__ raw,
+                                                          const float* __restrict__ t_param,
+                                                          const float* __restrict__ b_param,
+                                                          double* __restrict__ stats, int n, int B,
+                                                          int row_offset, float inv_bg) {
+  __shared__ float sh[4];
+  const float t = __expf(t_param[0]);
+  const float b = b_param ? b_param[0] : 0.f;
+  const long total = (long)n * B;
+  float l_acc = 0.f, dt_acc = 0.f, db_acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / B);
+    const int col = (int)(i - (long)row * B);
+    const float r = raw[i];
+    const float s = t * r + b;
+    const float m = (col == row_offset + row) ? 1.f : -1.f;
+    const float x = m * s;
+    const float e = __expf(-fabsf(x));
+    // -log_sigmoid(x) = max(-x, 0) + log1p(exp(-|x|))
+    l_acc += fmaxf(-x, 0.f) + log1pf(e);
+    // sigmoid(-x)
+    const float sig = x >= 0.f ? e / (1.f + e) : 1.f / (1.f + e);
+    const float g = -inv_bg * m * sig;
+    raw[i] = g;
+    dt_acc += g * (s - b);
+    db_acc += g;
+  }
+  const float l = block_sum_256(l_acc, sh);
+  const float dt = block_sum_256(dt_acc, sh);
+  const float db = block_sum_256(db_acc, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + 0, (double)l * (double)inv_bg);
+    atomicAdd(stats + 1, (double)dt);
+    atomicAdd(stats + 2, (double)db);
+  }
+}
+
+// ------------------------------------------------------------ softmax xent --
+// utils.py:276-281; one workgroup per row.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
+                                                           const float* __restrict__ labels,
+                                                           double* __restrict__ loss_sum,
+                                                           float* __restrict__ dlogits, int n, int C) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  const float* lr = logits + (long)r * C;
+  const float* yr = labels + (long)r * C;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, lr[c]);
+  mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  float se = 0.f, sy = 0.f, syl = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    se += __expf(lr[c] - mx);
+    sy += yr[c];
+    syl += yr[c] * (lr[c] - mx);
+  }
+  se = block_sum_256(se, sh);
+  sy = block_sum_256(sy, sh);
+  syl = block_sum_256(syl, sh);
+  const float lse = logf(se);
+  // -sum_c y (l - mx - lse) = -(syl - sy*lse)
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (double)(-(syl - sy * lse)) / (double)n);
+  if (dlogits) {
+    const float inv_n = 1.0f / (float)n;
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float p = __expf(lr[c] - mx - lse);
+      dlogits[(long)r * C + c] = (p * sy - yr[c]) * inv_n;
+    }
+  }
+}
+
+// ----------------------------------------------------------- strided sgemm --
+// 64x64 tile, 16x16 threads, 4x4 micro-tile, BK = 16.
+__global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restrict__ A, long sam,
+                                                            long sak, const float* __restrict__ B,
+                                                            long sbk, long sbn, float* __restrict__ C,
+                                                            long ldc, int M, int N, int K, float alpha,
+                                                            float beta) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // each thread loads 4 elements of A (64 m x 16 k) and 4 of B (16 k x 64 n)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + e * 256;
+      int mm, kk;
+      if (sak == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+      const int gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < K) ? A[(long)gm * sam + (long)gk * sak] : 0.f;
+      int nn, kb;
+      if (sbk == 1) { kb = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kb = idx >> 6; }
+      const int gn = n0 + nn, gkb = k0 + kb;
+      Bs[kb][nn] = (gn < N && gkb < K) ? B[(long)gkb * sbk + (long)gn * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float* c = C + (long)m * ldc + n;
+      *c = alpha * acc[i][j] + (beta != 0.f ? beta * (*c) : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ sqnorm --
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, long count,
+                                                     double* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const long n4 = count / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
+    acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = n4 * 4 + threadIdx.x; i < count; i += 256) acc += x[i] * x[i];
+  }
+  const float s = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, (double)s);
+}
+
+// -------------------------------------------------------------- adam chain --
+// optax.py:143-149.  One workgroup per 1024-element chunk; chunk_seg maps the
+// chunk to its hyper-parameter segment.
+struct AdamArgs {
+  float* p;
+  const float* g;
+  void* mu;
+  float* nu;
+  bf16* shadow;
+  const bv_adam_seg* segs;
+  const int* chunk_seg;
+  const double* gsq;
+  double* stats;
+  float clip_norm, b1, b2, eps, bc1, bc2;
+  int mu_bf16;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  __shared__ float sh[4];
+  const bv_adam_seg hp = a.segs[a.chunk_seg[blockIdx.x]];
+  float clip = 1.f;
+  if (a.clip_norm > 0.f) {
+    const float gn = (float)sqrt(*a.gsq);
+    clip = gn > a.clip_norm ? a.clip_norm / gn : 1.f;
+  }
+  const long i = (long)blockIdx.x * 1024 + threadIdx.x * 4;
+  const float4 p4 = *reinterpret_cast<const float4*>(a.p + i);
+  const float4 g4 = *reinterpret_cast<const float4*>(a.g + i);
+  const float4 v4 = *reinterpret_cast<const float4*>(a.nu + i);
+  float m[4];
+  if (a.mu_bf16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(a.mu) + i);
+    m[0] = bflo(u.x); m[1] = bfhi(u.x); m[2] = bflo(u.y); m[3] = bfhi(u.y);
+  } else {
+    const float4 m4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mu) + i);
+    m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
+  }
+  float p[4] = {p4.x, p4.y, p4.z, p4.w};
+  const float g[4] = {g4.x * clip, g4.y * clip, g4.z * clip, g4.w * clip};
+  float v[4] = {v4.x, v4.y, v4.z, v4.w};
+  float sp = 0.f, su = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m[e] = a.b1 * m[e] + (1.f - a.b1) * g[e];
+    v[e] = a.b2 * v[e] + (1.f - a.b2) * g[e] * g[e];
+    float u = (m[e] / a.bc1) / (sqrtf(v[e] / a.bc2) + a.eps);
+    u = hp.lr_eff * u + hp.wd_eff * p[e];
+    u *= hp.sched;
+    p[e] -= u;
+    sp += p[e] * p[e];
+    su += u * u;
+  }
+  *reinterpret_cast<float4*>(a.p + i) = make_float4(p[0], p[1], p[2], p[3]);
+  *reinterpret_cast<float4*>(a.nu + i) = make_float4(v[0], v[1], v[2], v[3]);
+  if (a.mu_bf16) {
+    uint2 u;
+    u.x = pack_bf2(m[0], m[1]);
+    u.y = pack_bf2(m[2], m[3]);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(a.mu) + i) = u;
+  } else {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.mu) + i) = make_float4(m[0], m[1], m[2], m[3]);
+  }
+  if (a.shadow) {
+    uint2 u;
+    u.x = pack_bf2(p[0], p[1]);
+    u.y = pack_bf2(p[2], p[3]);
+    *reinterpret_cast<uint2*>(a.shadow + i) = u;
+  }
+  if (a.stats) {
+    const float tp = block_sum_256(sp, sh);
+    const float tu = block_sum_256(su, sh);
+    if (threadIdx.x == 0) {
+      atomicAdd(a.stats + 0, (double)tp);
+      atomicAdd(a.stats + 1, (double)tu);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int bv_siglip_loss(float* raw, const float* t_param, const float* b_param, double* stats,
+                              int n, int B, int row_offset, int B_global, void* stream) {
+  BV_REQUIRE(n > 0 && B > 0 && B_global > 0, "bv_siglip_loss: bad shape n=%d B=%d B_global=%d", n, B, B_global);
+  BV_REQUIRE(row_offset >= 0 && row_offset + n <= B, "bv_siglip_loss: positive diagonal [%d,%d) outside B=%d", row_offset, row_offset + n, B);
+  long g = ((long)n * B + 1023) / 1024;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(siglip_loss_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, raw, t_param,
+                     b_param, stats, n, B, row_offset, 1.0f / (float)B_global);
+  return bv_check_launch("bv_siglip_loss");
+}
+
+extern "C" int bv_softmax_xent(const float* logits, const float* labels, double* loss_sum,
+                               float* dlogits, int n, int C, void* stream) {
+  BV_REQUIRE(n > 0 && C > 0, "bv_softmax_xent: bad shape");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     loss_sum, dlogits, n, C);
+  return bv_check_launch("bv_softmax_xent");
+}
+
+extern "C" int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                                float* C, long ldc, int M, int N, int K, float alpha, float beta,
+                                void* stream) {
+  BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_sgemm_strided: empty problem");
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(sgemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
+                     sbn, C, ldc, M, N, K, alpha, beta);
+  return bv_check_launch("bv_sgemm_strided");
+}
+
+extern "C" int bv_sqnorm(const float* x, long count, double* sqnorm_out, void* stream) {
+  BV_REQUIRE(count > 0 && (uintptr_t)x % 16 == 0, "bv_sqnorm: empty or unaligned input");
+  long g = (count / 4 + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, count, sqnorm_out);
+  return bv_check_launch("bv_sqnorm");
+}
+
+extern "C" int bv_adam_step(float* params, const float* grads, void* mu, int mu_bf16, float* nu,
+                            void* shadow_bf16, const bv_adam_seg* segs, const int* chunk_seg,
+                            long count, const double* gsq, float clip_norm, float b1, float b2,
+                            float eps, float bc1, float bc2, double* stats, void* stream) {
+  BV_REQUIRE(count > 0 && count % 1024 == 0, "bv_adam_step: count=%ld must be a positive multiple of 1024", count);
+  BV_REQUIRE(clip_norm <= 0.f || gsq != nullptr, "bv_adam_step: clipping needs gsq");
+  AdamArgs a;
+  a.p = params; a.g = grads; a.mu = mu; a.nu = nu; a.shadow = (bf16*)shadow_bf16;
+  a.segs = segs; a.chunk_seg = chunk_seg; a.gsq = gsq; a.stats = stats;
+  a.clip_norm = clip_norm; a.b1 = b1; a.b2 = b2; a.eps = eps; a.bc1 = bc1; a.bc2 = bc2;
+  a.mu_bf16 = mu_bf16;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(count / 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  return bv_check_launch("bv_adam_step");
+}

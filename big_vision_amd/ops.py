@@ -1,0 +1,255 @@
+"""Tensor-level wrappers over the libbvhip C ABI (include/bvhip.h).
+
+PyTorch is used only for device memory and the HIP stream; every function here
+enqueues hand-written HIP kernels on torch's current stream.  There is no
+eager/PyTorch fallback: non-GPU tensors raise.
+"""
+import torch
+
+from big_vision_amd import _lib
+from big_vision_amd._lib import (EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD,
+                                 EPI_ATOMIC)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+  return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+  if not t.is_cuda:
+    raise RuntimeError(f"{name}: expected a GPU tensor (libbvhip has no CPU path)")
+  if t.dtype != dtype:
+    raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+  return t
+
+
+def _rowmajor2d(t, name):
+  if t.dim() != 2 or t.stride(1) != 1:
+    raise ValueError(f"{name}: expected a 2-D tensor with contiguous rows, got {tuple(t.shape)} strides {t.stride()}")
+  return t.stride(0)
+
+
+# ------------------------------------------------------------------- GEMMs --
+def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=None, N=None, K=None,
+         epilogue=EPI_NONE, bias=None, aux=None, aux_rows=0, out2=None, alpha=1.0, split_k=0):
+  """C[M,N] = A(MxK) B(KxN) with bf16 inputs; see bv_gemm_bf16 in include/bvhip.h.
+
+  a: [M,K] if a_kmajor else [K,M];  b: [N,K] if b_kmajor else [K,N].
+  """
+  _chk(a, BF16, "gemm.a"); _chk(b, BF16, "gemm.b")
+  lda = _rowmajor2d(a, "gemm.a"); ldb = _rowmajor2d(b, "gemm.b")
+  m, k = (a.shape if a_kmajor else (a.shape[1], a.shape[0]))
+  n, k2 = (b.shape if b_kmajor else (b.shape[1], b.shape[0]))
+  if k != k2:
+    raise ValueError(f"gemm: reduction dims differ: {k} vs {k2}")
+  M = m if M is None else M; N = n if N is None else N; K = k if K is None else K
+  if out is None:
+    out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+  ldc = _rowmajor2d(out, "gemm.out")
+  if out.dtype not in (BF16, F32):
+    raise TypeError("gemm.out must be bf16 or fp32")
+  ldaux = 0
+  if aux is not None:
+    ldaux = _rowmajor2d(aux, "gemm.aux")
+  if bias is not None:
+    _chk(bias, F32, "gemm.bias")
+  _lib.call("bv_gemm_bf16", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
+            int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
+            float(alpha), split_k, _stream())
+  return out
+
+
+def sgemm(a, sam, sak, b, sbk, sbn, out, M, N, K, alpha=1.0, beta=0.0):
+  """fp32 strided GEMM (bv_sgemm_strided)."""
+  _chk(a, F32, "sgemm.a"); _chk(b, F32, "sgemm.b"); _chk(out, F32, "sgemm.out")
+  _lib.call("bv_sgemm_strided", _p(a), sam, sak, _p(b), sbk, sbn, _p(out), out.stride(0), M, N, K,
+            float(alpha), float(beta), _stream())
+  return out
+
+
+# --------------------------------------------------------------- LayerNorm --
+def layernorm_fwd(x, scale, bias, *, rows, D, row_stride=1, row_offset=0, want_bf16=True,
+                  want_f32=False, eps=1e-6):
+  _chk(x, F32, "layernorm.x"); _chk(scale, F32, "layernorm.scale"); _chk(bias, F32, "layernorm.bias")
+  dev = x.device
+  y_bf = torch.empty((rows, D), device=dev, dtype=BF16) if want_bf16 else None
+  y_f = torch.empty((rows, D), device=dev, dtype=F32) if want_f32 else None
+  mean = torch.empty((rows,), device=dev, dtype=F32)
+  rstd = torch.empty((rows,), device=dev, dtype=F32)
+  _lib.call("bv_layernorm_fwd", _p(x), _p(scale), _p(bias), _p(y_bf), _p(y_f), _p(mean), _p(rstd),
+            rows, D, row_stride, row_offset, float(eps), _stream())
+  return y_bf, y_f, mean, rstd
+
+
+def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_bf16=None,
+                  dscale=None, dbias=None, row_stride=1, row_offset=0):
+  """dx = dres + LN_bwd(dy); dscale/dbias accumulated in place."""
+  if dy.dtype not in (BF16, F32):
+    raise TypeError("layernorm_bwd.dy must be bf16 or fp32")
+  _chk(x, F32, "layernorm_bwd.x")
+  if dx is None:
+    dx = torch.empty_like(x) if row_stride == 1 else torch.zeros_like(x)
+  _lib.call("bv_layernorm_bwd", _p(dy), int(dy.dtype == F32), _p(x), _p(scale), _p(mean), _p(rstd),
+            _p(dres), _p(dx), _p(dx_bf16), _p(dscale), _p(dbias), rows, D, row_stride, row_offset,
+            _stream())
+  return dx
+
+
+# --------------------------------------------------------------- Attention --
+def attn_fwd(qkv, n, L, H):
+  _chk(qkv, BF16, "attn.qkv")
+  assert qkv.is_contiguous() and qkv.numel() == n * L * 3 * H * 64, qkv.shape
+  o = torch.empty((n * L, H * 64), device=qkv.device, dtype=BF16)
+  lse = torch.empty((n, H, L), device=qkv.device, dtype=F32)
+  _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream())
+  return o, lse
+
+
+def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None):
+  _chk(qkv, BF16, "attn.qkv"); _chk(o, BF16, "attn.o"); _chk(d_o, BF16, "attn.do")
+  assert d_o.is_contiguous() and o.is_contiguous()
+  if dqkv is None:
+    dqkv = torch.empty_like(qkv)
+  delta = torch.empty((n, H, L), device=qkv.device, dtype=F32)
+  _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), n, L, H, _stream())
+  return dqkv
+
+
+def map_attn_fwd(q, kv, n, L, H):
+  _chk(q, BF16, "map_attn.q"); _chk(kv, BF16, "map_attn.kv")
+  assert q.is_contiguous() and kv.is_contiguous()
+  o = torch.empty((n, H * 64), device=q.device, dtype=BF16)
+  p = torch.empty((n, H, L), device=q.device, dtype=F32)
+  _lib.call("bv_map_attn_fwd", _p(q), _p(kv), _p(o), _p(p), n, L, H, _stream())
+  return o, p
+
+
+def map_attn_bwd(q, kv, p, d_o, n, L, H):
+  _chk(d_o, BF16, "map_attn.do")
+  assert d_o.is_contiguous()
+  dq = torch.empty_like(q)
+  dkv = torch.empty_like(kv)
+  _lib.call("bv_map_attn_bwd", _p(q), _p(kv), _p(p), _p(d_o), _p(dq), _p(dkv), n, L, H, _stream())
+  return dq, dkv
+
+
+# ------------------------------------------------------------ data movers ---
+def patchify(image, P):
+  _chk(image, F32, "patchify.image")
+  assert image.is_contiguous() and image.dim() == 4 and image.shape[3] == 3, image.shape
+  n, Hi, Wi, _ = image.shape
+  h, w = Hi // P, Wi // P
+  out = torch.empty((n * h * w, P * P * 3), device=image.device, dtype=BF16)
+  _lib.call("bv_patchify", _p(image), _p(out), n, Hi, Wi, P, _stream())
+  return out, (h, w)
+
+
+def embed_fwd(ids, table, pos, n, L):
+  _chk(ids, torch.int32, "embed.ids"); _chk(table, F32, "embed.table"); _chk(pos, F32, "embed.pos")
+  vocab, D = table.shape
+  x = torch.empty((n * L, D), device=table.device, dtype=F32)
+  _lib.call("bv_embed_fwd", _p(ids), _p(table), _p(pos), _p(x), n, L, D, vocab, _stream())
+  return x
+
+
+def embed_bwd(ids, dx, dtable):
+  _chk(ids, torch.int32, "embed.ids"); _chk(dx, F32, "embed.dx"); _chk(dtable, F32, "embed.dtable")
+  vocab, D = dtable.shape
+  _lib.call("bv_embed_bwd", _p(ids), _p(dx), _p(dtable), dx.shape[0], D, vocab, _stream())
+
+
+def colsum(x, out, rows=None, cols=None):
+  """out[c] += sum_r x[r][c]."""
+  ldx = _rowmajor2d(x, "colsum.x")
+  _chk(out, F32, "colsum.out")
+  rows = x.shape[0] if rows is None else rows
+  cols = x.shape[1] if cols is None else cols
+  _lib.call("bv_colsum", _p(x), int(x.dtype == F32), ldx, _p(out), rows, cols, _stream())
+
+
+def batchsum(x, out, n, L, D):
+  _chk(x, F32, "batchsum.x"); _chk(out, F32, "batchsum.out")
+  _lib.call("bv_batchsum", _p(x), _p(out), n, L, D, _stream())
+
+
+def cast_bf16(x, out=None):
+  _chk(x, F32, "cast_bf16.x")
+  assert x.is_contiguous()
+  if out is None:
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+  _lib.call("bv_cast_bf16", _p(x), _p(out), x.numel(), _stream())
+  return out
+
+
+def concat_cls(cls, x, n, L, D):
+  y = torch.empty((n * (L + 1), D), device=x.device, dtype=F32)
+  _lib.call("bv_concat_cls", _p(cls), _p(x), _p(y), n, L, D, _stream())
+  return y
+
+
+def pool_gap_fwd(x, n, L, D):
+  y = torch.empty((n, D), device=x.device, dtype=F32)
+  _lib.call("bv_pool_gap_fwd", _p(x), _p(y), n, L, D, _stream())
+  return y
+
+
+def pool_gap_bwd(dy, n, L, D):
+  dx = torch.empty((n * L, D), device=dy.device, dtype=F32)
+  _lib.call("bv_pool_gap_bwd", _p(dy), _p(dx), n, L, D, _stream())
+  return dx
+
+
+def l2norm_fwd(z, eps=1e-8):
+  _chk(z, F32, "l2norm.z")
+  assert z.is_contiguous()
+  zn = torch.empty_like(z)
+  norm = torch.empty((z.shape[0],), device=z.device, dtype=F32)
+  _lib.call("bv_l2norm_fwd", _p(z), _p(zn), _p(norm), z.shape[0], z.shape[1], float(eps), _stream())
+  return zn, norm
+
+
+def l2norm_bwd(z, norm, dzn, eps=1e-8):
+  _chk(dzn, F32, "l2norm.dzn")
+  assert dzn.is_contiguous()
+  dz = torch.empty_like(z)
+  _lib.call("bv_l2norm_bwd", _p(z), _p(norm), _p(dzn), _p(dz), z.shape[0], z.shape[1], float(eps), _stream())
+  return dz
+
+
+# -------------------------------------------------------------- loss / opt --
+def siglip_loss_(raw, t_param, b_param, stats, row_offset, B_global):
+  """In place: raw [n,B] (zimg.ztxt_all^T) -> G = dL/dS; stats (f64[3]) accumulated."""
+  _chk(raw, F32, "siglip_loss.raw")
+  assert raw.is_contiguous() and stats.dtype == torch.float64
+  n, B = raw.shape
+  _lib.call("bv_siglip_loss", _p(raw), _p(t_param), _p(b_param), _p(stats), n, B, row_offset,
+            B_global, _stream())
+
+
+def softmax_xent(logits, labels, loss_sum, want_grad=True):
+  _chk(logits, F32, "softmax_xent.logits"); _chk(labels, F32, "softmax_xent.labels")
+  n, C = logits.shape
+  dl = torch.empty_like(logits) if want_grad else None
+  _lib.call("bv_softmax_xent", _p(logits), _p(labels), _p(loss_sum), _p(dl), n, C, _stream())
+  return dl
+
+
+def sqnorm_(x, out):
+  """out (f64[1]) += sum(x^2)."""
+  _chk(x, F32, "sqnorm.x")
+  assert x.is_contiguous() and out.dtype == torch.float64
+  _lib.call("bv_sqnorm", _p(x), x.numel(), _p(out), _stream())
+
+
+def adam_step_(params, grads, mu, nu, shadow, segs, chunk_seg, count, gsq, clip_norm, b1, b2, eps,
+               bc1, bc2, stats):
+  _lib.call("bv_adam_step", _p(params), _p(grads), _p(mu), int(mu.dtype == BF16), _p(nu), _p(shadow),
+            _p(segs), _p(chunk_seg), count, _p(gsq), float(clip_norm or 0.0), float(b1), float(b2),
+            float(eps), float(bc1), float(bc2), _p(stats), _stream())

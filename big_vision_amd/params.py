@@ -1,0 +1,208 @@
+"""Flat parameter storage with Flax-compatible named views.
+
+The reference keeps parameters as an immutable pytree of arrays whose leaf
+names ('/'-joined, utils.py:616-641) are the checkpoint / regex-addressing
+contract.  Here all parameters of a model live in ONE flat fp32
+device buffer (plus a same-shaped grad buffer, a bf16 shadow for the MFMA
+GEMMs and the Adam moments), laid out for the kernels:
+
+  * q/k/v projection kernels are stored fused as [D, 3, H, Dh] so the QKV
+    projection is a single [D, 3D] GEMM; the Flax leaves `query/kernel`,
+    `key/kernel`, `value/kernel` (D,H,Dh) are strided VIEWS of that tensor
+    (same for the MAP head's key/value).
+  * every tensor starts at a multiple of 1024 elements so the fused optimizer
+    kernel can address hyper-parameters per 1024-element chunk.
+
+`ParamStore.tree()` returns the nested dict with exactly the reference's leaf
+names and shapes; `load_tree()` accepts such a tree (e.g. from an .npz).
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+ALIGN = 1024
+
+
+class Entry:
+  """One storage tensor; `views` maps Flax leaf names to (dim, index) slices."""
+
+  def __init__(self, name: str, shape: Sequence[int], init, views: Optional[Dict[str, Tuple[int, int]]] = None):
+    self.name = name
+    self.shape = tuple(int(s) for s in shape)
+    self.init = init          # callable(gen, flax_shape) -> cpu tensor, applied per Flax leaf
+    self.views = views        # None: the Flax leaf IS the storage tensor (same name)
+    self.offset = -1
+    self.numel = int(np.prod(self.shape))
+
+  def flax_leaves(self):
+    if self.views is None:
+      return [(self.name, None)]
+    return list(self.views.items())
+
+
+class ParamTree(dict):
+  """Nested dict of parameter views that remembers the store it came from."""
+  store = None
+  buf = "master"
+
+
+def _nest(flat: Dict[str, torch.Tensor], store, buf) -> ParamTree:
+  root = ParamTree()
+  root.store, root.buf = store, buf
+  for name, v in flat.items():
+    node = root
+    parts = name.split("/")
+    for p in parts[:-1]:
+      if p not in node:
+        child = ParamTree()
+        child.store, child.buf = store, buf
+        dict.__setitem__(node, p, child)
+      node = node[p]
+    dict.__setitem__(node, parts[-1], v)
+  return root
+
+
+def flatten_tree(tree, prefix="") -> Dict[str, object]:
+  """'/'-joined leaf names, sorted traversal (utils.py:616-641)."""
+  out = {}
+  if isinstance(tree, dict):
+    for k in sorted(tree.keys()):
+      out.update(flatten_tree(tree[k], f"{prefix}{k}/"))
+    return out
+  out[prefix.rstrip("/")] = tree
+  return out
+
+
+class ParamStore:
+  def __init__(self, entries: List[Entry], device, frozen: Optional[Sequence[str]] = None):
+    """`frozen`: storage-entry names placed at the END of the flat buffers so
+    the optimizer state / kernels only cover the trainable prefix."""
+    self.device = torch.device(device)
+    frozen = set(frozen or ())
+    self.entries: Dict[str, Entry] = {}
+    order = [e for e in entries if e.name not in frozen] + [e for e in entries if e.name in frozen]
+    off = 0
+    self.trainable_count = 0
+    for e in order:
+      if e.name in self.entries:
+        raise ValueError(f"duplicate parameter {e.name}")
+      e.offset = off
+      off += (e.numel + ALIGN - 1) // ALIGN * ALIGN
+      if e.name not in frozen:
+        self.trainable_count = off
+      self.entries[e.name] = e
+    self.frozen = frozen
+    self.count = off
+    self.master = torch.zeros(off, device=self.device, dtype=torch.float32)
+    self.shadow = torch.zeros(off, device=self.device, dtype=torch.bfloat16)
+    self.grad = None  # allocated by ensure_grad()
+    self.leaf_index: Dict[str, Tuple[str, Optional[Tuple[int, int]]]] = {}
+    for e in order:
+      for leaf, sl in e.flax_leaves():
+        self.leaf_index[leaf] = (e.name, sl)
+    self._shadow_dirty = True
+
+  # ------------------------------------------------------------ accessors --
+  def _buf(self, buf):
+    if buf == "grad":
+      self.ensure_grad()
+    return getattr(self, buf)
+
+  def ensure_grad(self):
+    if self.grad is None:
+      self.grad = torch.zeros(self.trainable_count, device=self.device, dtype=torch.float32)
+    return self.grad
+
+  def t(self, name: str, buf: str = "master") -> torch.Tensor:
+    """Storage tensor `name` (kernel layout) from one of the flat buffers."""
+    e = self.entries[name]
+    b = self._buf(buf)
+    if e.offset + e.numel > b.numel():
+      raise KeyError(f"{name} is frozen: it has no entry in buffer '{buf}'")
+    return b[e.offset:e.offset + e.numel].view(e.shape)
+
+  def has_grad(self, name: str) -> bool:
+    return name not in self.frozen
+
+  def g(self, name: str) -> Optional[torch.Tensor]:
+    """Grad view of a storage tensor, or None if it is frozen."""
+    return self.t(name, "grad") if name not in self.frozen else None
+
+  def leaf(self, leaf_name: str, buf: str = "master") -> torch.Tensor:
+    sname, sl = self.leaf_index[leaf_name]
+    t = self.t(sname, buf)
+    return t if sl is None else t.select(sl[0], sl[1])
+
+  def leaf_names(self) -> List[str]:
+    return sorted(self.leaf_index.keys())
+
+  def tree(self, buf: str = "master") -> ParamTree:
+    flat = {}
+    for n in self.leaf_names():
+      sname, _ = self.leaf_index[n]
+      if buf == "grad" and sname in self.frozen:
+        continue
+      flat[n] = self.leaf(n, buf)
+    return _nest(flat, self, buf)
+
+  # ---------------------------------------------------------------- I / O --
+  def init_random(self, seed: int):
+    """Fills the master buffer from each entry's initialiser (CPU RNG -> device)."""
+    gen = torch.Generator().manual_seed(int(seed))
+    for e in self.entries.values():
+      for leaf, sl in e.flax_leaves():
+        dst = self.leaf(leaf)
+        val = e.init(gen, tuple(dst.shape))
+        dst.copy_(val.to(torch.float32).to(self.device))
+    self._shadow_dirty = True
+
+  def load_tree(self, tree, strict: bool = True):
+    flat = flatten_tree(tree)
+    missing = [n for n in self.leaf_index if n not in flat]
+    extra = [n for n in flat if n not in self.leaf_index]
+    if strict and (missing or extra):
+      raise ValueError(f"Parameter tree mismatch. Missing: {missing[:8]} Unexpected: {extra[:8]}")
+    for n, v in flat.items():
+      if n not in self.leaf_index:
+        continue
+      dst = self.leaf(n)
+      v = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v)
+      if tuple(v.shape) != tuple(dst.shape):
+        raise ValueError(f"Shape mismatch for {n}: got {tuple(v.shape)}, expected {tuple(dst.shape)}")
+      dst.copy_(v.to(torch.float32).to(self.device))
+    self._shadow_dirty = True
+
+  def refresh_shadow(self, force: bool = False):
+    """bf16 shadow <- master (HIP cast kernel).  The optimizer kernel keeps the
+    trainable prefix in sync itself; this is for init / load / frozen tensors."""
+    if self._shadow_dirty or force:
+      from big_vision_amd import ops
+      ops.cast_bf16(self.master, self.shadow)
+      self._shadow_dirty = False
+
+  def mark_dirty(self):
+    self._shadow_dirty = True
+
+  def zero_grad(self):
+    self.ensure_grad().zero_()
+
+
+# ------------------------------------------------------------ regex masks ----
+def make_masks(names: Sequence[str], patterns: Sequence[str]) -> List[Dict[str, bool]]:
+  """First-match-wins masks with fullmatch (reference utils.py:1169-1212)."""
+  comp = []
+  for p in patterns:
+    assert not p.startswith("/"), f"Big vision parameter names never start with '/': '{p}"
+    comp.append(re.compile(p))
+  masks = [dict() for _ in patterns]
+  for n in names:
+    hit = False
+    for i, c in enumerate(comp):
+      m = (not hit) and bool(c.fullmatch(n))
+      masks[i][n] = m
+      hit = hit or m
+  return masks

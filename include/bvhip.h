@@ -1,0 +1,195 @@
+/* libbvhip — C ABI of the MI355X (gfx950) SigLIP/ViT training-step kernels.
+ *
+ * The reference (google-research/big_vision) has NO native boundary: every op
+ * on the hot path is a jax.numpy / flax.linen call lowered by XLA
+ * (SURVEY.md §1, §8b).  This header is therefore the boundary a maintainer
+ * would bind (ctypes / jax.ffi custom-call) to replace those lowered ops; each
+ * entry point cites the reference call site(s) it replaces, paths relative to
+ * big_vision/ in the reference tree.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (no hidden
+ *     allocation); tensors are row-major, densely packed unless an ld* argument
+ *     says otherwise; `bf16` tensors are raw 16-bit bfloat16.
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately: 0 = ok, <0 = error (BV_ERR_*); the message is
+ *     available from bv_last_error().  No call synchronises.
+ *   - thread-safe per stream; no global state besides the last-error string.
+ */
+#ifndef BVHIP_H_
+#define BVHIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVHIP_VERSION 1
+
+/* error codes */
+#define BV_OK 0
+#define BV_ERR_INVALID_ARG (-1)
+#define BV_ERR_UNSUPPORTED (-2)
+#define BV_ERR_HIP (-3)
+
+const char* bv_last_error(void);
+int bv_version(void);
+
+/* ---------------------------------------------------------------- GEMM ----
+ * C[M,N] = alpha * A(MxK) * B(KxN) (+ epilogue), bf16 inputs, fp32 MFMA
+ * accumulate.  Replaces nn.Dense / nn.DenseGeneral / nn.Conv(stem) matmuls:
+ * models/vit.py:72,77 (MlpBlock), :93-98 (q/k/v/out projections), :212-214
+ * (patch embedding as a matmul over patchified pixels), :261,:272 (heads),
+ * models/proj/image_text/text_transformer.py:98, and their dX / dW transposes
+ * produced by jax.value_and_grad (trainers/proj/image_text/siglip.py:311).
+ *
+ * a_kmajor: 1 = A stored [M][K] (K contiguous, row stride lda);
+ *           0 = A stored [K][M] (M contiguous, row stride lda).
+ * b_kmajor: 1 = B stored [N][K] (K contiguous, row stride ldb)  ("B^T");
+ *           0 = B stored [K][N] (N contiguous, row stride ldb).
+ *   forward  Y = X W      : a_kmajor=1, b_kmajor=0 (W is Flax (in,out))
+ *   dX = dY W^T           : a_kmajor=1, b_kmajor=1
+ *   dW = X^T dY           : a_kmajor=0, b_kmajor=0, epilogue ATOMIC (split-K)
+ * out_f32: C is float (1) or bf16 (0).
+ * epilogue (applied after alpha, then + bias[N] if bias != NULL):
+ */
+#define BV_EPI_NONE 0
+#define BV_EPI_RESIDUAL 1 /* C(f32) += aux(f32)[m,n]           (x + f(x), vit.py:101,110)   */
+#define BV_EPI_POS 2      /* C(f32) += aux(f32)[m % aux_rows,n] (posemb add, vit.py:220-221) */
+#define BV_EPI_GELU 3     /* C(bf16)=pre-activation, C2(bf16)=gelu_tanh(pre) (vit.py:75)    */
+#define BV_EPI_GELU_BWD 4 /* C *= gelu_tanh'(aux(bf16)[m,n])   (backward of vit.py:75)      */
+#define BV_EPI_ATOMIC 5   /* C(f32) += result via fp32 atomics; split-K over K              */
+int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
+                 void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
+                 const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
+                 float alpha, int split_k /*0 = auto*/, void* stream);
+
+/* fp32 GEMM with arbitrary element strides (small, numerically sensitive
+ * products: the B x B logits of the sigmoid loss and its gradients,
+ * trainers/proj/image_text/siglip.py:291).  C[m,n] = alpha * sum_k A(m,k) B(k,n)
+ * + beta * C[m,n]; element (m,k) of A is A[m*sam + k*sak] etc. */
+int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
+                     float* C, long ldc, int M, int N, int K, float alpha, float beta,
+                     void* stream);
+
+/* ------------------------------------------------------------ LayerNorm ----
+ * flax nn.LayerNorm(): eps=1e-6, fp32 statistics (models/vit.py:92,103,160,181).
+ * Input row r is read at x + (r*row_stride + row_offset)*D (row_stride>=1 lets
+ * the final encoder_norm run only on the pooled token, text_transformer.py:82-84).
+ * Outputs: y_bf16 and/or y_f32 (either may be NULL), mean[rows], rstd[rows]. */
+int bv_layernorm_fwd(const float* x, const float* scale, const float* bias, void* y_bf16,
+                     float* y_f32, float* mean, float* rstd, int rows, int D, long row_stride,
+                     long row_offset, float eps, void* stream);
+/* dx_out[row] = (dres ? dres[row] : 0) + LN_bwd(dy[row]); optional bf16 copy of
+ * dx_out; dscale/dbias are ACCUMULATED (+=) with fp32 atomics.  dy is bf16 or
+ * fp32 (dy_is_f32).  With row_stride>1 only the selected rows of dx are
+ * written (caller zero-fills the rest). */
+int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* scale,
+                     const float* mean, const float* rstd, const float* dres, float* dx,
+                     void* dx_bf16, float* dscale, float* dbias, int rows, int D,
+                     long row_stride, long row_offset, void* stream);
+
+/* ------------------------------------------------------------ Attention ----
+ * Self-attention core of nn.MultiHeadDotProductAttention (models/vit.py:93-98):
+ * S = (q/sqrt(Dh)) k^T, P = softmax(S), O = P v per (sample, head); no mask, no
+ * dropout.  qkv is the packed projection output [n*L][3][H][64] bf16 (row
+ * stride 3*H*64); o is [n*L][H][64] bf16; lse is [n][H][L] fp32 (row
+ * log-sum-exp, saved for the backward).  Dh must be 64; L <= 576. */
+int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
+/* dqkv (same layout as qkv) from do ([n*L][H][64] bf16); delta is fp32 scratch
+ * [n][H][L] (rowsum(dO*O), computed here). */
+int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                void* dqkv, int n, int L, int H, void* stream);
+
+/* Single-query attention of the MAP head (models/vit.py:176-178): q [n][H][64]
+ * bf16, kv packed [n*L][2][H][64] bf16 -> o [n][H][64] bf16, probabilities p
+ * [n][H][L] fp32 (saved for the backward). */
+int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int L, int H,
+                    void* stream);
+int bv_map_attn_bwd(const void* q, const void* kv, const float* p, const void* d_o, void* dq,
+                    void* dkv, int n, int L, int H, void* stream);
+
+/* ---------------------------------------------------------- Patch / embed --
+ * NHWC fp32 image [n][Hi][Wi][3] -> bf16 patch matrix [n*h*w][P*P*3] in HWIO
+ * flattening order (row, col, channel), the im2col of the stride-P VALID conv
+ * of models/vit.py:212-217. */
+int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream);
+/* x[(i*L+l)] = table[ids[i*L+l]] + pos[l]  (nn.Embed + pos_embedding,
+ * models/proj/image_text/text_transformer.py:63-70).  fp32 in/out. */
+int bv_embed_fwd(const int* ids, const float* table, const float* pos, float* x, int n, int L,
+                 int D, int vocab, void* stream);
+/* dtable[ids[r]] += dx[r] (fp32 atomics). */
+int bv_embed_bwd(const int* ids, const float* dx, float* dtable, int rows, int D, int vocab,
+                 void* stream);
+
+/* ------------------------------------------------------------- Reductions --
+ * out[c] += sum_r x[r][c] (bias gradients db = sum_rows dY).  x bf16 or fp32. */
+int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int cols, void* stream);
+/* out[l][c] += sum_i x[i][l][c]  (dpos = sum over the batch, fp32). */
+int bv_batchsum(const float* x, float* out, int n, int L, int D, void* stream);
+/* fp32 -> bf16 cast of a flat buffer (bf16 weight shadows). */
+int bv_cast_bf16(const float* x, void* y, long count, void* stream);
+/* y[i][0] = cls, y[i][1+l] = x[i][l] (cls-token concat, models/vit.py:223-225), fp32. */
+int bv_concat_cls(const float* cls, const float* x, float* y, int n, int L, int D, void* stream);
+
+/* pooled[i][c] = mean_l x[i][l][c] (pool_type="gap", models/vit.py:246); fp32. */
+int bv_pool_gap_fwd(const float* x, float* y, int n, int L, int D, void* stream);
+int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, void* stream);
+
+/* ------------------------------------------------------------ L2 normalise --
+ * zn = z / (||z||_2 + eps), eps = 1e-8 (models/proj/image_text/two_towers.py:60-61,
+ * :73-74).  fp32. */
+int bv_l2norm_fwd(const float* z, float* zn, float* norm, int rows, int D, float eps, void* stream);
+int bv_l2norm_bwd(const float* z, const float* norm, const float* dzn, float* dz, int rows, int D,
+                  float eps, void* stream);
+
+/* ---------------------------------------------------------- Sigmoid loss ----
+ * Pairwise sigmoid loss of trainers/proj/image_text/siglip.py:291-306 (==
+ * _deprecated_contrastive.py:117-141 summed over devices).  `raw` holds
+ * zimg_local . ztxt_all^T [n][B] fp32 on entry; on exit it holds
+ * G = dL/dS = -(1/B_global) * m * sigmoid(-m*S), S = t*raw + b, m = +1 on the
+ * positive diagonal (column row_offset + i) else -1.
+ * stats is double[3] (device), ACCUMULATED:
+ * stats[0] += sum_ij -log_sigmoid(m*S) / B_global   (this rank's loss share)
+ * stats[1] += sum_ij G*(S-b)   (= dL/dt', t = exp(t'))
+ * stats[2] += sum_ij G         (= dL/db)
+ * t and b are read from device memory (t_param holds t' = log t). */
+int bv_siglip_loss(float* raw, const float* t_param, const float* b_param, double* stats, int n,
+                   int B, int row_offset, int B_global, void* stream);
+
+/* softmax cross-entropy with soft labels, utils.py:276-281 (config 1):
+ * loss_sum[0] += sum_i -sum_c y*log_softmax(logits) / n ; dlogits = (softmax*sum(y) - y)/n */
+int bv_softmax_xent(const float* logits, const float* labels, double* loss_sum, float* dlogits,
+                    int n, int C, void* stream);
+
+/* -------------------------------------------------------------- Optimizer --
+ * sqnorm_out[0] += sum x^2 (double accumulator) — global grad norm for
+ * optax.clip_by_global_norm (optax.py:100-105) and the l2_* measurements
+ * (trainers/proj/image_text/siglip.py:315-321). */
+int bv_sqnorm(const float* x, long count, double* sqnorm_out, void* stream);
+
+/* Fused bv_optax chain (optax.py:143-149): clip -> scale_by_adam -> scale(lr)
+ * -> lr_mult -> add_decayed_weights -> scale_by_schedule -> scale(-1) ->
+ * apply_updates (trainers/proj/image_text/siglip.py:312-313), over a flat fp32
+ * parameter buffer of `count` elements (multiple of 1024).  Chunk c (1024
+ * elements) uses hyper-parameters segs[chunk_seg[c]] (both device arrays):
+ * lr_eff = lr*lr_mult, wd_eff = wd*wd_mult, sched = schedule value at this
+ * step.  mu may be bf16 (mu_bf16=1, optax mu_dtype) or fp32.  gsq points at
+ * sum(g^2) over the not-frozen grads (device double); clip_norm <= 0 disables
+ * clipping.  bc1 = 1-b1^k, bc2 = 1-b2^k.  Also refreshes the bf16 shadow of the
+ * params (may be NULL) and accumulates stats[0] += sum p_new^2,
+ * stats[1] += sum update^2 (device doubles; stats may be NULL). */
+typedef struct {
+  float lr_eff;
+  float wd_eff;
+  float sched;
+  float pad_;
+} bv_adam_seg;
+int bv_adam_step(float* params, const float* grads, void* mu, int mu_bf16, float* nu,
+                 void* shadow_bf16, const bv_adam_seg* segs, const int* chunk_seg, long count,
+                 const double* gsq, float clip_norm, float b1, float b2, float eps, float bc1,
+                 float bc2, double* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVHIP_H_ */

@@ -1,0 +1,391 @@
+"""Per-kernel parity tests: every libbvhip entry point (through the C ABI) vs a
+plain fp32/fp64 PyTorch statement of the same op on identical inputs.
+
+Tolerances: bf16-input MFMA kernels are compared against fp32 math on the SAME
+bf16-rounded inputs, so the only differences are accumulation order and the
+final rounding of the output dtype (bf16: 2^-8 relative).  fp32 HBM-bound
+kernels: rtol 1e-5 / atol 1e-6.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=F32):
+  g = torch.Generator(device="cpu").manual_seed(seed)
+  return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dev).to(dtype)
+
+
+def assert_close(a, b, rtol, atol, name=""):
+  a = a.double(); b = b.double()
+  err = (a - b).abs()
+  tol = atol + rtol * b.abs()
+  bad = err > tol
+  assert not bad.any(), (f"{name}: {int(bad.sum())}/{bad.numel()} mismatches, max abs err "
+                         f"{err.max().item():.3e} (ref max {b.abs().max().item():.3e})")
+
+
+# ----------------------------------------------------------------- GEMM ------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1568, 768, 768), (130, 136, 72), (5, 8, 8)])
+def test_gemm_forward_layout(dev, M, N, K):
+  """Y = X W (+bias): A k-major, B k-minor (Flax (in,out) kernel)."""
+  from big_vision_amd import ops
+  x = rnd((M, K), dev, 0, dtype=BF16)
+  w = rnd((K, N), dev, 1, 0.05, dtype=BF16)   # asymmetric: catches transposes
+  b = rnd((N,), dev, 2)
+  ref = x.float() @ w.float() + b
+  y = ops.gemm(x, w, a_kmajor=True, b_kmajor=False, bias=b, out_dtype=F32)
+  assert_close(y, ref, 1e-4, 1e-3, "gemm f32")
+  y16 = ops.gemm(x, w, a_kmajor=True, b_kmajor=False, bias=b, out_dtype=BF16)
+  assert_close(y16, ref, 1e-2, 1e-2, "gemm bf16")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 256), (1568, 768, 3072), (77, 64, 128)])
+def test_gemm_dx_layout(dev, M, N, K):
+  """dX = dY W^T: A k-major, B k-major (W stored [N=in][K=out])."""
+  from big_vision_amd import ops
+  dy = rnd((M, K), dev, 3, dtype=BF16)
+  w = rnd((N, K), dev, 4, 0.05, dtype=BF16)
+  ref = dy.float() @ w.float().T
+  dx = ops.gemm(dy, w, a_kmajor=True, b_kmajor=True, out_dtype=BF16)
+  assert_close(dx, ref, 1e-2, 1e-2, "gemm dx")
+
+
+@pytest.mark.parametrize("T,Din,Dout,split", [(512, 128, 256, 0), (1568, 768, 2304, 0), (333, 64, 72, 3), (64, 8, 8, 1)])
+def test_gemm_dw_layout(dev, T, Din, Dout, split):
+  """dW = X^T dY: both operands k-minor, split-K with fp32 atomics, accumulating."""
+  from big_vision_amd import ops
+  x = rnd((T, Din), dev, 5, dtype=BF16)
+  dy = rnd((T, Dout), dev, 6, dtype=BF16)
+  base = rnd((Din, Dout), dev, 7)
+  ref = base + x.float().T @ dy.float()
+  out = base.clone()
+  ops.gemm(x, dy, a_kmajor=False, b_kmajor=False, out=out, epilogue=ops.EPI_ATOMIC, split_k=split)
+  assert_close(out, ref, 1e-4, 1e-4 * math.sqrt(T) * 4, "gemm dw")
+
+
+def test_gemm_epilogues(dev):
+  from big_vision_amd import ops
+  M, N, K, L = 392, 256, 128, 196
+  x = rnd((M, K), dev, 8, dtype=BF16)
+  w = rnd((K, N), dev, 9, 0.1, dtype=BF16)
+  b = rnd((N,), dev, 10)
+  pre = x.float() @ w.float() + b
+  res = rnd((M, N), dev, 11)
+  y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res)
+  assert_close(y, pre + res, 1e-4, 1e-3, "residual")
+  pos = rnd((L, N), dev, 12)
+  y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L)
+  assert_close(y, pre + pos.repeat(M // L, 1), 1e-4, 1e-3, "pos")
+  g = torch.empty((M, N), device=dev, dtype=BF16)
+  h = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
+  assert_close(h, pre, 1e-2, 1e-2, "gelu pre")
+  assert_close(g, torch.nn.functional.gelu(pre, approximate="tanh"), 1e-2, 1e-2, "gelu out")
+  # gelu backward epilogue: dH = (dG W2^T) * gelu'(h)
+  dg_in = rnd((M, K), dev, 13, dtype=BF16)
+  w2 = rnd((N, K), dev, 14, 0.1, dtype=BF16)
+  hh = rnd((M, N), dev, 15, dtype=BF16)
+  hf = hh.float().requires_grad_(True)
+  torch.nn.functional.gelu(hf, approximate="tanh").sum().backward()
+  ref = (dg_in.float() @ w2.float().T) * hf.grad
+  out = ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16,
+                 epilogue=ops.EPI_GELU_BWD, aux=hh)
+  assert_close(out, ref, 1e-2, 2e-2, "gelu bwd")
+
+
+def test_gemm_rejects_bad_args(dev):
+  from big_vision_amd import ops
+  x = rnd((16, 12), dev, 0, dtype=BF16)   # K=12 not a multiple of 8
+  w = rnd((12, 16), dev, 1, dtype=BF16)
+  with pytest.raises(RuntimeError):
+    ops.gemm(x, w)
+  with pytest.raises(RuntimeError):
+    ops.gemm(x.cpu(), w.cpu())
+
+
+def test_sgemm_strided(dev):
+  from big_vision_amd import ops
+  M, N, K = 70, 133, 96
+  a = rnd((M, K), dev, 1); b = rnd((N, K), dev, 2)
+  out = torch.zeros((M, N), device=dev)
+  ops.sgemm(a, K, 1, b, 1, K, out, M, N, K, alpha=2.0)       # A B^T
+  assert_close(out, 2.0 * a @ b.T, 1e-5, 1e-4, "sgemm NT")
+  g = rnd((M, N), dev, 3)
+  out2 = torch.zeros((N, K), device=dev)
+  ops.sgemm(g, 1, N, a, K, 1, out2, N, K, M)                 # G^T A
+  assert_close(out2, g.T @ a, 1e-5, 1e-4, "sgemm TN")
+
+
+# ------------------------------------------------------------- LayerNorm -----
+@pytest.mark.parametrize("rows,D", [(1568, 768), (37, 128), (64, 1024), (9, 384)])
+def test_layernorm(dev, rows, D):
+  from big_vision_amd import ops
+  x = rnd((rows, D), dev, 1, 2.0) + 0.5
+  scale = 1 + 0.1 * rnd((D,), dev, 2); bias = 0.1 * rnd((D,), dev, 3)
+  xr = x.double().requires_grad_(True); sr = scale.double().requires_grad_(True)
+  br = bias.double().requires_grad_(True)
+  ref = torch.nn.functional.layer_norm(xr, (D,), sr, br, eps=1e-6)
+  y_bf, y_f, mean, rstd = ops.layernorm_fwd(x, scale, bias, rows=rows, D=D, want_f32=True)
+  assert_close(y_f, ref, 1e-5, 1e-5, "ln fwd f32")
+  assert_close(y_bf, ref, 1e-2, 1e-2, "ln fwd bf16")
+  dy = rnd((rows, D), dev, 4)
+  dres = rnd((rows, D), dev, 5)
+  ref.backward(dy.double())
+  dscale = torch.zeros(D, device=dev); dbias = torch.zeros(D, device=dev)
+  dx_bf = torch.empty((rows, D), device=dev, dtype=BF16)
+  dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=rows, D=D, dres=dres, dx_bf16=dx_bf,
+                         dscale=dscale, dbias=dbias)
+  assert_close(dx, xr.grad + dres.double(), 1e-4, 1e-4, "ln dx")
+  assert_close(dx_bf, xr.grad + dres.double(), 1e-2, 1e-2, "ln dx bf16")
+  assert_close(dscale, sr.grad, 1e-4, 1e-3, "ln dscale")
+  assert_close(dbias, br.grad, 1e-4, 1e-3, "ln dbias")
+  # bf16 upstream gradient variant
+  dyb = dy.to(BF16)
+  dx2 = ops.layernorm_bwd(dyb, x, scale, mean, rstd, rows=rows, D=D)
+  xr.grad = None
+  torch.nn.functional.layer_norm(xr, (D,), sr, br, eps=1e-6).backward(dyb.double())
+  assert_close(dx2, xr.grad, 1e-4, 1e-4, "ln dx (bf16 dy)")
+
+
+def test_layernorm_strided_rows(dev):
+  """encoder_norm applied to the pooled (last) token only."""
+  from big_vision_amd import ops
+  n, L, D = 6, 16, 128
+  x = rnd((n * L, D), dev, 1)
+  scale = 1 + 0.1 * rnd((D,), dev, 2); bias = 0.1 * rnd((D,), dev, 3)
+  _, y, mean, rstd = ops.layernorm_fwd(x, scale, bias, rows=n, D=D, row_stride=L, row_offset=L - 1,
+                                       want_bf16=False, want_f32=True)
+  sel = x.view(n, L, D)[:, -1]
+  assert_close(y, torch.nn.functional.layer_norm(sel, (D,), scale, bias, eps=1e-6), 1e-5, 1e-5, "strided ln")
+  dy = rnd((n, D), dev, 4)
+  dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=n, D=D, row_stride=L, row_offset=L - 1)
+  xr = x.clone().requires_grad_(True)
+  torch.nn.functional.layer_norm(xr.view(n, L, D)[:, -1], (D,), scale, bias, eps=1e-6).backward(dy)
+  assert_close(dx, xr.grad, 1e-4, 1e-5, "strided ln bwd")
+
+
+# ------------------------------------------------------------- Attention -----
+def _attn_ref(qkv, n, L, H):
+  q, k, v = qkv.double().view(n, L, 3, H, 64).unbind(2)
+  s = torch.einsum("nqhd,nkhd->nhqk", q / 8.0, k)
+  p = torch.softmax(s, -1)
+  o = torch.einsum("nhqk,nkhd->nqhd", p, v)
+  return o.reshape(n * L, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("n,L,H", [(3, 196, 2), (2, 64, 3), (2, 5, 1), (1, 197, 2), (1, 441, 1), (1, 576, 1)])
+def test_attention(dev, n, L, H):
+  from big_vision_amd import ops
+  qkv = rnd((n * L, 3 * H * 64), dev, 1, 1.5, dtype=BF16)
+  qr = qkv.double().requires_grad_(True)
+  o_ref, lse_ref = _attn_ref(qr, n, L, H)
+  o, lse = ops.attn_fwd(qkv, n, L, H)
+  assert_close(lse, lse_ref, 1e-4, 1e-3, "lse")
+  assert_close(o, o_ref, 2e-2, 2e-2, "attn out")
+  d_o = rnd((n * L, H * 64), dev, 2, dtype=BF16)
+  o_ref.backward(d_o.double())
+  dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+  g = qr.grad
+  err = (dqkv.double() - g).abs().max().item()
+  assert_close(dqkv, g, 3e-2, 3e-2 * g.abs().max().item(), f"dqkv (max err {err:.3e})")
+
+
+def test_attention_peaked_softmax(dev):
+  """One key dominates each row (large logits): exercises the max-subtraction."""
+  from big_vision_amd import ops
+  n, L, H = 1, 196, 1
+  qkv = rnd((n * L, 3 * 64), dev, 3, 1.0, dtype=BF16).float()
+  qkv[:, :64] *= 8.0
+  qkv[7, 64:128] *= 10.0
+  qkv = qkv.to(BF16)
+  o_ref, lse_ref = _attn_ref(qkv, n, L, H)
+  o, lse = ops.attn_fwd(qkv, n, L, H)
+  assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+  assert_close(lse, lse_ref, 1e-3, 1e-2, "lse peaked")
+  assert_close(o, o_ref, 3e-2, 3e-2, "attn out peaked")
+
+
+@pytest.mark.parametrize("n,L,H", [(4, 196, 2), (3, 16, 1), (5, 70, 3)])
+def test_map_attention(dev, n, L, H):
+  from big_vision_amd import ops
+  q = rnd((n, H * 64), dev, 1, dtype=BF16)
+  kv = rnd((n * L, 2 * H * 64), dev, 2, dtype=BF16)
+  qr = q.double().requires_grad_(True); kvr = kv.double().requires_grad_(True)
+  k, v = kvr.view(n, L, 2, H, 64).unbind(2)
+  s = torch.einsum("nhd,nkhd->nhk", qr.view(n, H, 64) / 8.0, k)
+  p = torch.softmax(s, -1)
+  o_ref = torch.einsum("nhk,nkhd->nhd", p, v).reshape(n, H * 64)
+  o, pp = ops.map_attn_fwd(q, kv, n, L, H)
+  assert_close(pp, p, 1e-3, 1e-5, "map p")
+  assert_close(o, o_ref, 1e-2, 1e-2, "map o")
+  d_o = rnd((n, H * 64), dev, 3, dtype=BF16)
+  o_ref.backward(d_o.double())
+  dq, dkv = ops.map_attn_bwd(q, kv, pp, d_o, n, L, H)
+  assert_close(dq, qr.grad, 2e-2, 2e-2 * qr.grad.abs().max().item(), "map dq")
+  assert_close(dkv, kvr.grad, 2e-2, 2e-2 * kvr.grad.abs().max().item(), "map dkv")
+
+
+# ----------------------------------------------------------- data movers -----
+@pytest.mark.parametrize("P,res", [(16, 64), (8, 32), (14, 28)])
+def test_patchify(dev, P, res):
+  import bv_oracle as O
+  from big_vision_amd import ops
+  img = torch.rand((3, res, res, 3), device=dev) * 2 - 1
+  ref, (h, w) = O.extract_patches(img.cpu(), (P, P))
+  out, hw = ops.patchify(img, P)
+  assert hw == (h, w)
+  assert torch.equal(out.cpu(), ref.reshape(-1, P * P * 3).to(BF16))
+
+
+def test_embed(dev):
+  from big_vision_amd import ops
+  n, L, D, V = 5, 16, 128, 50
+  g = torch.Generator().manual_seed(0)
+  ids = torch.randint(0, V, (n, L), generator=g, dtype=torch.int32)
+  ids[:, 10:] = 1  # heavy duplicates (sticky EOS)
+  ids = ids.to(dev)
+  table = rnd((V, D), dev, 1); pos = rnd((L, D), dev, 2)
+  x = ops.embed_fwd(ids, table, pos, n, L)
+  ref = table[ids.long().view(-1)] + pos.repeat(n, 1)
+  assert torch.equal(x, ref)
+  dx = rnd((n * L, D), dev, 3)
+  dt = torch.zeros((V, D), device=dev)
+  ops.embed_bwd(ids.view(-1), dx, dt)
+  ref_dt = torch.zeros((V, D), device=dev, dtype=torch.float64).index_add_(0, ids.long().view(-1), dx.double())
+  assert_close(dt, ref_dt, 1e-5, 1e-5, "embed bwd")
+
+
+def test_reductions_and_casts(dev):
+  from big_vision_amd import ops
+  rows, cols = 3000, 200
+  x = rnd((rows, cols), dev, 1)
+  out = torch.ones(cols, device=dev)
+  ops.colsum(x, out)
+  assert_close(out, 1 + x.double().sum(0), 1e-5, 1e-3, "colsum f32")
+  xb = x.to(BF16)
+  out = torch.zeros(cols, device=dev)
+  ops.colsum(xb, out)
+  assert_close(out, xb.double().sum(0), 1e-5, 1e-3, "colsum bf16")
+  # strided view (columns of a wider matrix)
+  wide = rnd((rows, 3 * cols), dev, 2).to(BF16)
+  out = torch.zeros(cols, device=dev)
+  ops.colsum(wide[:, cols:2 * cols], out)
+  assert_close(out, wide[:, cols:2 * cols].double().sum(0), 1e-5, 1e-3, "colsum view")
+  n, L, D = 70, 9, 32
+  y = rnd((n, L, D), dev, 3)
+  acc = torch.zeros((L, D), device=dev)
+  ops.batchsum(y, acc, n, L, D)
+  assert_close(acc, y.double().sum(0), 1e-5, 1e-4, "batchsum")
+  z = rnd((1000003,), dev, 4)
+  assert torch.equal(ops.cast_bf16(z), z.to(BF16))
+  cls = rnd((D,), dev, 5)
+  cat = ops.concat_cls(cls, y.view(n * L, D), n, L, D).view(n, L + 1, D)
+  assert torch.equal(cat[:, 0], cls.expand(n, D)) and torch.equal(cat[:, 1:], y)
+  gp = ops.pool_gap_fwd(y.view(n * L, D), n, L, D)
+  assert_close(gp, y.mean(1), 1e-5, 1e-6, "gap")
+  gb = ops.pool_gap_bwd(gp, n, L, D).view(n, L, D)
+  assert_close(gb, (gp / L)[:, None, :].expand(n, L, D), 1e-6, 1e-7, "gap bwd")
+
+
+def test_l2norm(dev):
+  from big_vision_amd import ops
+  z = rnd((33, 768), dev, 1, 3.0)
+  zr = z.double().requires_grad_(True)
+  nr = torch.linalg.norm(zr, dim=1, keepdim=True)
+  ref = zr / (nr + 1e-8)
+  zn, norm = ops.l2norm_fwd(z)
+  assert_close(zn, ref, 1e-5, 1e-6, "l2norm")
+  assert_close(norm, nr[:, 0], 1e-5, 1e-6, "norm")
+  g = rnd((33, 768), dev, 2)
+  ref.backward(g.double())
+  dz = ops.l2norm_bwd(z, norm, g)
+  assert_close(dz, zr.grad, 1e-4, 1e-6, "l2norm bwd")
+
+
+# ------------------------------------------------------------------ loss -----
+@pytest.mark.parametrize("n,B,off,t0,b0", [(64, 64, 0, 10.0, -10.0), (48, 192, 96, 10.0, -2.71), (7, 21, 14, 3.0, 0.5)])
+def test_siglip_loss_kernel_vs_oracle(dev, n, B, off, t0, b0):
+  import bv_oracle as O
+  from big_vision_amd import ops
+  zi = torch.nn.functional.normalize(rnd((n, 32), dev, 1), dim=1)
+  zt = torch.nn.functional.normalize(rnd((B, 32), dev, 2), dim=1)
+  zt[off:off + n] = 0.7 * zt[off:off + n] + 0.3 * zi  # make positives informative
+  tp = torch.tensor([math.log(t0)], device=dev); bp = torch.tensor([b0], device=dev)
+  # oracle: rows [off, off+n) of the global loss (siglip.py:291-306), fp64
+  zi_all = torch.zeros((B, 32), dtype=torch.float64); zi_all[off:off + n] = zi.double().cpu()
+  zid = zi.double().cpu().requires_grad_(True); ztd = zt.double().cpu().requires_grad_(True)
+  tpd = tp.double().cpu().requires_grad_(True); bpd = bp.double().cpu().requires_grad_(True)
+  logits = zid @ ztd.T * torch.exp(tpd) + bpd
+  m = -torch.ones_like(logits); m[torch.arange(n), off + torch.arange(n)] = 1.0
+  loss_ref = (-O.log_sigmoid(m * logits).sum(-1)).sum() / B
+  loss_ref.backward()
+  raw = torch.zeros((n, B), device=dev)
+  ops.sgemm(zi, 32, 1, zt, 1, 32, raw, n, B, 32)
+  stats = torch.zeros(3, device=dev, dtype=torch.float64)
+  ops.siglip_loss_(raw, tp, bp, stats, off, B)
+  t = math.exp(tp.item())
+  assert_close(stats[0].cpu(), loss_ref.detach(), 1e-5, 1e-6, "loss")
+  assert_close(stats[1].cpu(), tpd.grad[0], 1e-4, 1e-6, "dt'")
+  assert_close(stats[2].cpu(), bpd.grad[0], 1e-4, 1e-6, "db")
+  dzi = t * raw.double().cpu() @ ztd.detach()
+  dzt = t * raw.double().cpu().T @ zid.detach()
+  assert_close(dzi, zid.grad, 1e-4, 1e-7, "dzimg")
+  assert_close(dzt, ztd.grad, 1e-4, 1e-7, "dztxt")
+
+
+def test_softmax_xent(dev):
+  import bv_oracle as O
+  from big_vision_amd import ops
+  n, C = 8, 1000
+  logits = rnd((n, C), dev, 1, 3.0)
+  labels = torch.softmax(rnd((n, C), dev, 2, 2.0), -1)  # soft labels (mixup)
+  lr = logits.double().cpu().requires_grad_(True)
+  ref = O.softmax_xent(lr, labels.double().cpu())
+  ref.backward()
+  acc = torch.zeros(1, device=dev, dtype=torch.float64)
+  dl = ops.softmax_xent(logits, labels, acc)
+  assert_close(acc.cpu()[0], ref.detach(), 1e-5, 1e-6, "xent")
+  assert_close(dl.cpu(), lr.grad, 1e-4, 1e-7, "dlogits")
+
+
+# ------------------------------------------------------------- optimizer -----
+def test_sqnorm_and_adam_vs_oracle(dev):
+  import bv_oracle as O
+  from big_vision_amd import ops
+  import ctypes, struct
+  count = 4096
+  g = torch.Generator().manual_seed(0)
+  p0 = torch.randn(count, generator=g); steps = 3
+  grads = [torch.randn(count, generator=g) * 3 for _ in range(steps)]
+  # oracle: two tensors, "a/kernel" (wd) = first 3072 elements, "a/bias" = rest
+  params = {"a": {"kernel": p0[:3072].clone().double(), "bias": p0[3072:].clone().double()}}
+  cfg = dict(lr=1e-2, wd=1e-2, schedule=dict(decay_type="cosine", warmup_steps=2),
+             optax_name="scale_by_adam", grad_clip_norm=1.0)
+  orc = O.OptaxOracle(cfg, params, sched_kw=dict(total_steps=10, batch_size=8))
+  p = p0.clone().to(dev); mu = torch.zeros(count, device=dev); nu = torch.zeros(count, device=dev)
+  shadow = torch.empty(count, device=dev, dtype=BF16)
+  chunk_seg = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=dev)
+  for k in range(steps):
+    gk = grads[k]
+    upd = orc.update({"a": {"kernel": gk[:3072].double(), "bias": gk[3072:].double()}}, params)
+    params = O.tree_map(lambda a, u: a + u, params, upd)
+    sched = orc.schedule_fns[0](k)
+    segs = torch.tensor([cfg["lr"], cfg["wd"], sched, 0.0, cfg["lr"], 0.0, sched, 0.0], device=dev)
+    gd = gk.to(dev)
+    gsq = torch.zeros(1, device=dev, dtype=torch.float64)
+    ops.sqnorm_(gd, gsq)
+    assert_close(gsq.cpu()[0], (gk.double() ** 2).sum(), 1e-6, 0, "sqnorm")
+    stats = torch.zeros(2, device=dev, dtype=torch.float64)
+    ops.adam_step_(p, gd, mu, nu, shadow, segs, chunk_seg, count, gsq, 1.0, 0.9, 0.999, 1e-8,
+                   1 - 0.9 ** (k + 1), 1 - 0.999 ** (k + 1), stats)
+    ref = torch.cat([params["a"]["kernel"], params["a"]["bias"]])
+    assert_close(p.cpu(), ref, 1e-5, 1e-6, f"adam params step {k}")
+    assert torch.equal(shadow, p.to(BF16))
+    assert_close(stats.cpu()[0], (ref ** 2).sum(), 1e-5, 0, "l2_params^2")
+    u = torch.cat([upd["a"]["kernel"], upd["a"]["bias"]])
+    assert_close(stats.cpu()[1], (u ** 2).sum(), 1e-4, 1e-12, "l2_updates^2")
