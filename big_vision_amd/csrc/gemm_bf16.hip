@@ -10,8 +10,9 @@
 // 4x4 fragments of v_mfma_f32_16x16x32_bf16), LDS double-buffered (64 KiB, two
 // workgroups per CU), register-staged global->LDS so that either operand may
 // be "K-major" (reduction dim contiguous: 16-byte loads along K) or
-// "K-minor" (reduction dim is the slow axis: 4x8 blocks transposed in
-// registers and written as 8-byte K-runs).  One LDS image for all variants:
+// "K-minor" (reduction dim is the slow axis: the tile is staged in its natural
+// [k][row] layout and MFMA fragments are gathered with the LDS transpose read
+// ds_read_b64_tr_b16 — no register transposes).  K-major LDS image:
 //   tile[row][64 k] bf16, 128 B per row, 16-byte chunk c stored at
 //   c ^ swz(row), swz(row) = (row ^ (row >> 3)) & 7.
 // The MFMA is issued "swapped" (first operand = B rows, second = A rows) so a
@@ -60,18 +61,19 @@ __device__ __forceinline__ void gload_kmajor(uint4 (&r)[4], const bf16* P, long 
     }
   }
 }
-// K-minor operand: memory P[k][row], row contiguous.  Thread t owns the 4(k) x
-// 8(row) block at k = 4*(t>>4), row = 8*(t&15).
+// K-minor operand: memory P[k][row], row contiguous.  The tile is kept in its
+// natural [64 k][128 rows] layout (256 B per k-row); thread t owns the 16-byte
+// chunk (t&15) of k-rows (t>>4) + 16*i.
 __device__ __forceinline__ void gload_kminor(uint4 (&r)[4], const bf16* P, long ld, int R,
                                              int row0, int k0, int kend, int tid) {
   const int grow = row0 + (tid & 15) * 8;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gk = k0 + (tid >> 4) * 4 + j;
+  for (int i = 0; i < 4; ++i) {
+    const int gk = k0 + (tid >> 4) + 16 * i;
     if (grow < R && gk < kend) {
-      r[j] = *reinterpret_cast<const uint4*>(P + (long)gk * ld + grow);
+      r[i] = *reinterpret_cast<const uint4*>(P + (long)gk * ld + grow);
     } else {
-      r[j] = make_uint4(0, 0, 0, 0);
+      r[i] = make_uint4(0, 0, 0, 0);
     }
   }
 }
@@ -85,27 +87,18 @@ __device__ __forceinline__ void sstore_kmajor(const uint4 (&r)[4], char* tile, i
     *reinterpret_cast<uint4*>(tile + row * 128 + ((c ^ swz(row)) << 4)) = r[i];
   }
 }
+// K-minor LDS image: tile[k][128 rows], 32-byte slot q (16 rows) of k-row k is
+// stored at slot q ^ swzk(k), swzk(k) = (k & 3) | (((k >> 3) & 1) << 2): the 8
+// k-rows {8g..8g+3, 8g+8..8g+11} one half-wave touches in a transpose read land
+// on 8 distinct 32-byte bank groups.
+__device__ __forceinline__ int swzk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
 __device__ __forceinline__ void sstore_kminor(const uint4 (&r)[4], char* tile, int tid) {
-  const int r0 = (tid & 15) * 8;
-  const int kg = tid >> 4;  // k = 4*kg .. 4*kg+3
-  const int chunk = kg >> 1, half = kg & 1;
-  const uint32_t w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w},
-                            {r[1].x, r[1].y, r[1].z, r[1].w},
-                            {r[2].x, r[2].y, r[2].z, r[2].w},
-                            {r[3].x, r[3].y, r[3].z, r[3].w}};
+  const int c = tid & 15;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int d = e >> 1;
-    uint2 o;
-    if ((e & 1) == 0) {
-      o.x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
-      o.y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
-    } else {
-      o.x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
-      o.y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
-    }
-    const int row = r0 + e;
-    *reinterpret_cast<uint2*>(tile + row * 128 + ((chunk ^ swz(row)) << 4) + half * 8) = o;
+  for (int i = 0; i < 4; ++i) {
+    const int k = (tid >> 4) + 16 * i;
+    *reinterpret_cast<uint4*>(tile + k * 256 + ((((c >> 1) ^ swzk(k)) << 5) | ((c & 1) << 4))) = r[i];
   }
 }
 
@@ -123,6 +116,24 @@ __device__ __forceinline__ void sstore(const uint4 (&r)[4], char* tile, int tid)
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int chunk) {
   const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 128 + ((chunk ^ swz(row)) << 4));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// Fragment of a K-minor tile through the LDS transpose read
+// (ds_read_b64_tr_b16): within a 16-lane group, lane i supplies the address of
+// the 4-element chunk [k = i>>2][rows 4*(i&3)..+3] of a 4(k) x 16(row) block and
+// receives the 4 k-values of row i (measured on gfx950, tools/probes/tr_probe.hip).
+// rb = 16-row block index (0..7), ks = 32-wide k-step, lg = lane>>4, lr = lane&15.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 lds_frag_tr(const char* tile, int rb, int ks, int lg, int lr) {
+  const int ka = ks * 32 + lg * 8 + (lr >> 2);
+  const int kb = ka + 4;
+  const char* pa = tile + ka * 256 + ((rb ^ swzk(ka)) << 5) + ((lr & 3) << 3);
+  const char* pb = tile + kb * 256 + ((rb ^ swzk(kb)) << 5) + ((lr & 3) << 3);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pa);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)pb);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
 
@@ -163,9 +174,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = lds_frag(sA, wm * 64 + i * 16 + lr, ks * 4 + lg);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (A_KM) af[i] = lds_frag(sA, wm * 64 + i * 16 + lr, ks * 4 + lg);
+        else af[i] = lds_frag_tr(sA, wm * 4 + i, ks, lg, lr);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = lds_frag(sB, wn * 64 + j * 16 + lr, ks * 4 + lg);
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (B_KM) bfr[j] = lds_frag(sB, wn * 64 + j * 16 + lr, ks * 4 + lg);
+        else bfr[j] = lds_frag_tr(sB, wn * 4 + j, ks, lg, lr);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -1,0 +1,304 @@
+"""Explicit forward/backward executors for the transformer pieces of the hot path.
+
+The reference builds these with flax.linen modules and lets jax.value_and_grad
+derive the backward (big_vision/models/vit.py:57-183,
+trainers/proj/image_text/siglip.py:311).  Here forward and backward are spelled
+out as sequences of libbvhip kernels so that every fusion is explicit:
+
+  forward block  (vit.py:88-112):   LN -> QKV GEMM -> attention -> out-proj GEMM
+     (+bias +residual epilogue) -> LN -> fc1 GEMM (+bias, GELU epilogue) ->
+     fc2 GEMM (+bias +residual epilogue)
+  backward block: dW GEMMs (split-K fp32 atomics straight into the flat grad
+     buffer), dX GEMMs (GELU' fused into the fc2 dX epilogue), attention
+     backward, LayerNorm backward fused with the residual-gradient add and the
+     bf16 copy the next GEMM needs.
+
+The residual stream and all reductions are fp32; GEMM / attention operands are
+bf16 (fp32 MFMA accumulate).  No autograd graph is built.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from big_vision_amd import ops
+from big_vision_amd.params import Entry, ParamStore
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ----------------------------------------------------------------- inits -----
+def init_zeros(gen, shape):
+  return torch.zeros(shape)
+
+
+def init_ones(gen, shape):
+  return torch.ones(shape)
+
+
+def init_normal(std):
+  return lambda gen, shape: torch.randn(shape, generator=gen) * std
+
+
+def init_const(val):
+  return lambda gen, shape: torch.full(shape, float(val))
+
+
+def init_xavier_uniform(fan_in, fan_out):
+  lim = math.sqrt(6.0 / (fan_in + fan_out))
+  return lambda gen, shape: (torch.rand(shape, generator=gen) * 2 - 1) * lim
+
+
+def init_lecun_normal(fan_in):
+  # flax default kernel_init = variance_scaling(1.0, "fan_in", "truncated_normal")
+  std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+
+  def f(gen, shape):
+    t = torch.empty(shape)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=gen)
+    return t * std
+  return f
+
+
+# --------------------------------------------------------------- entries -----
+def ln_entries(prefix):
+  return lambda d: [Entry(f"{prefix}/scale", (d,), init_ones), Entry(f"{prefix}/bias", (d,), init_zeros)]
+
+
+def mha_entries(prefix, D, H, fused="qkv"):
+  """Flax MultiHeadDotProductAttention params; q/k/v stored fused.
+
+  fused="qkv": self-attention, one [D,3,H,Dh] tensor.  fused="kv": MAP head,
+  query separate and key/value fused as [D,2,H,Dh].
+  """
+  Dh = D // H
+  xav = init_xavier_uniform(D, D)
+  ents = []
+  if fused == "qkv":
+    names = ("query", "key", "value")
+    ents.append(Entry(f"{prefix}/qkv/kernel", (D, 3, H, Dh), xav,
+                      {f"{prefix}/{n}/kernel": (1, i) for i, n in enumerate(names)}))
+    ents.append(Entry(f"{prefix}/qkv/bias", (3, H, Dh), init_zeros,
+                      {f"{prefix}/{n}/bias": (0, i) for i, n in enumerate(names)}))
+  else:
+    ents.append(Entry(f"{prefix}/query/kernel", (D, H, Dh), xav))
+    ents.append(Entry(f"{prefix}/query/bias", (H, Dh), init_zeros))
+    names = ("key", "value")
+    ents.append(Entry(f"{prefix}/kv/kernel", (D, 2, H, Dh), xav,
+                      {f"{prefix}/{n}/kernel": (1, i) for i, n in enumerate(names)}))
+    ents.append(Entry(f"{prefix}/kv/bias", (2, H, Dh), init_zeros,
+                      {f"{prefix}/{n}/bias": (0, i) for i, n in enumerate(names)}))
+  ents.append(Entry(f"{prefix}/out/kernel", (H, Dh, D), xav))
+  ents.append(Entry(f"{prefix}/out/bias", (D,), init_zeros))
+  return ents
+
+
+def mlp_entries(prefix, D, M):
+  """MlpBlock params (vit.py:63-78): xavier_uniform kernels, normal(1e-6) biases."""
+  return [Entry(f"{prefix}/Dense_0/kernel", (D, M), init_xavier_uniform(D, M)),
+          Entry(f"{prefix}/Dense_0/bias", (M,), init_normal(1e-6)),
+          Entry(f"{prefix}/Dense_1/kernel", (M, D), init_xavier_uniform(M, D)),
+          Entry(f"{prefix}/Dense_1/bias", (D,), init_normal(1e-6))]
+
+
+def encoder_entries(prefix, depth, D, H, M):
+  """vit.Encoder params, python-loop layout (vit.py:149-160)."""
+  ents = []
+  for i in range(depth):
+    P = f"{prefix}/encoderblock_{i}"
+    ents += ln_entries(f"{P}/LayerNorm_0")(D)
+    ents += mha_entries(f"{P}/MultiHeadDotProductAttention_0", D, H, "qkv")
+    ents += ln_entries(f"{P}/LayerNorm_1")(D)
+    ents += mlp_entries(f"{P}/MlpBlock_0", D, M)
+  ents += ln_entries(f"{prefix}/encoder_norm")(D)
+  return ents
+
+
+def map_entries(prefix, D, H, M):
+  """MAPHead params (vit.py:163-183)."""
+  ents = [Entry(f"{prefix}/probe", (1, 1, D), init_xavier_uniform(D, D))]
+  ents += mha_entries(f"{prefix}/MultiHeadDotProductAttention_0", D, H, "kv")
+  ents += ln_entries(f"{prefix}/LayerNorm_0")(D)
+  ents += mlp_entries(f"{prefix}/MlpBlock_0", D, M)
+  return ents
+
+
+# ------------------------------------------------------------- helpers -------
+class _W:
+  """A weight tensor resolved against a store: bf16 shadow (2-D), fp32 master,
+  and the fp32 grad view (None if frozen)."""
+
+  def __init__(self, store: ParamStore, name: str, shape2d=None):
+    self.name = name
+    sh = store.t(name, "shadow")
+    ma = store.t(name, "master")
+    g = store.g(name)
+    if shape2d is not None:
+      sh, ma = sh.view(shape2d), ma.view(shape2d)
+      g = g.view(shape2d) if g is not None else None
+    self.bf, self.f32, self.grad = sh, ma, g
+
+
+def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
+  return ops.gemm(x_bf, w.bf, a_kmajor=True, b_kmajor=False, bias=None if b is None else b.f32, **kw)
+
+
+def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
+  """dW += x^T dy (split-K atomics into the grad buffer), db += colsum(dy)."""
+  if w.grad is not None:
+    ops.gemm(x_bf, dy_bf, a_kmajor=False, b_kmajor=False, out=w.grad, epilogue=ops.EPI_ATOMIC)
+  if b is not None and b.grad is not None:
+    ops.colsum(dy_bf if dy_for_bias is None else dy_for_bias, b.grad)
+
+
+def linear_bwd_x(dy_bf, w: _W, **kw):
+  return ops.gemm(dy_bf, w.bf, a_kmajor=True, b_kmajor=True, out_dtype=BF16, **kw)
+
+
+class LN:
+  def __init__(self, store, prefix):
+    self.scale = _W(store, f"{prefix}/scale")
+    self.bias = _W(store, f"{prefix}/bias")
+
+  def fwd(self, x, rows, D, **kw):
+    return ops.layernorm_fwd(x, self.scale.f32, self.bias.f32, rows=rows, D=D, **kw)
+
+  def bwd(self, dy, x, mean, rstd, rows, D, **kw):
+    return ops.layernorm_bwd(dy, x, self.scale.f32, mean, rstd, rows=rows, D=D,
+                             dscale=self.scale.grad, dbias=self.bias.grad, **kw)
+
+
+class MLP:
+  def __init__(self, store, prefix, D, M):
+    self.w1 = _W(store, f"{prefix}/Dense_0/kernel"); self.b1 = _W(store, f"{prefix}/Dense_0/bias")
+    self.w2 = _W(store, f"{prefix}/Dense_1/kernel"); self.b2 = _W(store, f"{prefix}/Dense_1/bias")
+    self.M = M
+
+  def fwd(self, y_bf, resid):
+    """resid + fc2(gelu(fc1(y))) ; returns (out f32, h_pre bf16, g bf16)."""
+    g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
+    h = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
+    out = linear_fwd(g, self.w2, self.b2, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=resid)
+    return out, h, g
+
+  def bwd(self, dout_f32, dout_bf, y_bf, h, g):
+    """Returns dy (bf16) = gradient w.r.t. the MLP input y."""
+    linear_bwd_w(g, dout_bf, self.w2, self.b2, dy_for_bias=dout_f32)
+    dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h)
+    linear_bwd_w(y_bf, dh, self.w1, self.b1)
+    return linear_bwd_x(dh, self.w1)
+
+
+# ------------------------------------------------------------- encoder -------
+class Block:
+  """Encoder1DBlock (vit.py:81-112)."""
+
+  def __init__(self, store, P, D, H, M):
+    A = f"{P}/MultiHeadDotProductAttention_0"
+    self.D, self.H, self.M = D, H, M
+    self.ln0 = LN(store, f"{P}/LayerNorm_0")
+    self.ln1 = LN(store, f"{P}/LayerNorm_1")
+    self.wqkv = _W(store, f"{A}/qkv/kernel", (D, 3 * D))
+    self.bqkv = _W(store, f"{A}/qkv/bias", (3 * D,))
+    self.wo = _W(store, f"{A}/out/kernel", (D, D))
+    self.bo = _W(store, f"{A}/out/bias")
+    self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
+
+  def fwd(self, x, n, L):
+    T, D, H = n * L, self.D, self.H
+    y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
+    qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
+    o, lse = ops.attn_fwd(qkv, n, L, H)
+    x1 = linear_fwd(o, self.wo, self.bo, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=x)
+    y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
+    x2, h, g = self.mlp.fwd(y1, x1)
+    return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
+
+  def bwd(self, saved, dx2, dx2_bf, n, L):
+    x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g = saved
+    T, D, H = n * L, self.D, self.H
+    dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g)
+    dx1_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
+    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf)
+    linear_bwd_w(o, dx1_bf, self.wo, self.bo, dy_for_bias=dx1)
+    d_o = linear_bwd_x(dx1_bf, self.wo)
+    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+    linear_bwd_w(y0, dqkv, self.wqkv, self.bqkv)
+    dy0 = linear_bwd_x(dqkv, self.wqkv)
+    dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
+    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf)
+    return dx, dx_bf
+
+
+class Encoder:
+  """vit.Encoder without the final encoder_norm (the caller applies it, because
+  which rows it must cover depends on the pooling)."""
+
+  def __init__(self, store, prefix, depth, D, H, M):
+    self.blocks = [Block(store, f"{prefix}/encoderblock_{i}", D, H, M) for i in range(depth)]
+    self.norm = LN(store, f"{prefix}/encoder_norm")
+    self.D = D
+
+  def fwd(self, x, n, L, save, out=None):
+    saved = []
+    for i, blk in enumerate(self.blocks):
+      x_in = x
+      x, s = blk.fwd(x, n, L)
+      if save:
+        saved.append(s)
+      if out is not None:
+        x1 = s[7]
+        out[f"block{i:02d}"] = {"sa": x1 - x_in, "+sa": x1, "mlp": x - x1, "+mlp": x}
+    if out is not None:
+      out["pre_ln"] = x
+    return x, saved
+
+  def bwd(self, saved, dx, dx_bf, n, L):
+    for blk, s in zip(reversed(self.blocks), reversed(saved)):
+      dx, dx_bf = blk.bwd(s, dx, dx_bf, n, L)
+    return dx, dx_bf
+
+
+# ------------------------------------------------------------- MAP head ------
+class MAPHead:
+  """MAPHead (vit.py:163-183) on top of the encoder_norm output."""
+
+  def __init__(self, store, prefix, D, H, M):
+    A = f"{prefix}/MultiHeadDotProductAttention_0"
+    self.D, self.H = D, H
+    self.probe = _W(store, f"{prefix}/probe", (1, D))
+    self.wq = _W(store, f"{A}/query/kernel", (D, D)); self.bq = _W(store, f"{A}/query/bias", (D,))
+    self.wkv = _W(store, f"{A}/kv/kernel", (D, 2 * D)); self.bkv = _W(store, f"{A}/kv/bias", (2 * D,))
+    self.wo = _W(store, f"{A}/out/kernel", (D, D)); self.bo = _W(store, f"{A}/out/bias")
+    self.ln = LN(store, f"{prefix}/LayerNorm_0")
+    self.mlp = MLP(store, f"{prefix}/MlpBlock_0", D, M)
+
+  def fwd(self, y_bf, n, L):
+    D, H = self.D, self.H
+    probe_t = self.probe.bf.expand(n, D).contiguous()
+    q = linear_fwd(probe_t, self.wq, self.bq, out_dtype=BF16)
+    kv = linear_fwd(y_bf, self.wkv, self.bkv, out_dtype=BF16)
+    o, p = ops.map_attn_fwd(q, kv, n, L, H)
+    a = linear_fwd(o, self.wo, self.bo, out_dtype=F32)
+    yl, _, mean, rstd = self.ln.fwd(a, n, D)
+    z, h, g = self.mlp.fwd(yl, a)
+    return z, (y_bf, probe_t, q, kv, o, p, a, mean, rstd, yl, h, g)
+
+  def bwd(self, saved, dz, n, L):
+    y_bf, probe_t, q, kv, o, p, a, mean, rstd, yl, h, g = saved
+    D, H = self.D, self.H
+    dz_bf = ops.cast_bf16(dz)
+    dyl = self.mlp.bwd(dz, dz_bf, yl, h, g)
+    da_bf = torch.empty((n, D), device=dz.device, dtype=BF16)
+    da = self.ln.bwd(dyl, a, mean, rstd, n, D, dres=dz, dx_bf16=da_bf)
+    linear_bwd_w(o, da_bf, self.wo, self.bo, dy_for_bias=da)
+    d_o = linear_bwd_x(da_bf, self.wo)
+    dq, dkv = ops.map_attn_bwd(q, kv, p, d_o, n, L, H)
+    linear_bwd_w(probe_t, dq, self.wq, self.bq)
+    if self.probe.grad is not None:
+      dprobe_t = linear_bwd_x(dq, self.wq)
+      ops.colsum(dprobe_t, self.probe.grad.view(-1))
+    linear_bwd_w(y_bf, dkv, self.wkv, self.bkv)
+    return linear_bwd_x(dkv, self.wkv)   # dy (bf16 [T, D])
