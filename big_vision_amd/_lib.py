@@ -20,7 +20,7 @@ PROTOTYPES = {
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
                      c_int, P, P, c_long, c_int, P, c_float, c_int, P],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
-                         c_float, c_float, P],
+                         c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
@@ -41,8 +41,8 @@ PROTOTYPES = {
     "bv_siglip_loss": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bv_softmax_xent": [P, P, P, P, c_int, c_int, P],
     "bv_sqnorm": [P, c_long, P, P],
-    "bv_adam_step": [P, P, P, c_int, P, P, P, P, c_long, P, c_float, c_float, c_float, c_float,
-                     c_float, c_float, P, P],
+    "bv_adam_step": [P, P, P, c_int, P, P, P, P, c_long, P, c_int, P, c_float, c_float, c_float,
+                     c_float, c_float, c_float, P, P],
 }
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC = range(6)

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(const float* __restr
                                                             long sak, const float* __restrict__ B,
                                                             long sbk, long sbn, float* __restrict__ C,
                                                             long ldc, int M, int N, int K, float alpha,
-                                                            float beta) {
+                                                            float beta, const float* __restrict__ log_alpha) {
+  if (log_alpha) alpha *= __expf(log_alpha[0]);
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -183,11 +184,13 @@ struct AdamArgs {
   double* stats;
   float clip_norm, b1, b2, eps, bc1, bc2;
   int mu_bf16;
+  float sched[BV_MAX_SCHED];
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   __shared__ float sh[4];
   const bv_adam_seg hp = a.segs[a.chunk_seg[blockIdx.x]];
+  const float sched = a.sched[hp.sched_idx & (BV_MAX_SCHED - 1)];
   float clip = 1.f;
   if (a.clip_norm > 0.f) {
     const float gn = (float)sqrt(*a.gsq);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     v[e] = a.b2 * v[e] + (1.f - a.b2) * g[e] * g[e];
     float u = (m[e] / a.bc1) / (sqrtf(v[e] / a.bc2) + a.eps);
     u = hp.lr_eff * u + hp.wd_eff * p[e];
-    u *= hp.sched;
+    u *= sched;
     p[e] -= u;
     sp += p[e] * p[e];
     su += u * u;
@@ -269,11 +272,11 @@ extern "C" int bv_softmax_xent(const float* logits, const float* labels, double*
 
 extern "C" int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                                 float* C, long ldc, int M, int N, int K, float alpha, float beta,
-                                void* stream) {
+                                const float* log_alpha, void* stream) {
   BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_sgemm_strided: empty problem");
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   hipLaunchKernelGGL(sgemm_strided_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, sam, sak, B, sbk,
-                     sbn, C, ldc, M, N, K, alpha, beta);
+                     sbn, C, ldc, M, N, K, alpha, beta, log_alpha);
   return bv_check_launch("bv_sgemm_strided");
 }
 
@@ -288,11 +291,14 @@ extern "C" int bv_sqnorm(const float* x, long count, double* sqnorm_out, void* s
 
 extern "C" int bv_adam_step(float* params, const float* grads, void* mu, int mu_bf16, float* nu,
                             void* shadow_bf16, const bv_adam_seg* segs, const int* chunk_seg,
-                            long count, const double* gsq, float clip_norm, float b1, float b2,
-                            float eps, float bc1, float bc2, double* stats, void* stream) {
+                            long count, const float* sched, int nsched, const double* gsq,
+                            float clip_norm, float b1, float b2, float eps, float bc1, float bc2,
+                            double* stats, void* stream) {
   BV_REQUIRE(count > 0 && count % 1024 == 0, "bv_adam_step: count=%ld must be a positive multiple of 1024", count);
   BV_REQUIRE(clip_norm <= 0.f || gsq != nullptr, "bv_adam_step: clipping needs gsq");
+  BV_REQUIRE(sched != nullptr && nsched >= 1 && nsched <= BV_MAX_SCHED, "bv_adam_step: 1..%d schedule values required", BV_MAX_SCHED);
   AdamArgs a;
+  for (int i = 0; i < BV_MAX_SCHED; ++i) a.sched[i] = i < nsched ? sched[i] : 0.f;
   a.p = params; a.g = grads; a.mu = mu; a.nu = nu; a.shadow = (bf16*)shadow_bf16;
   a.segs = segs; a.chunk_seg = chunk_seg; a.gsq = gsq; a.stats = stats;
   a.clip_norm = clip_norm; a.b1 = b1; a.b2 = b2; a.eps = eps; a.bc1 = bc1; a.bc2 = bc2;

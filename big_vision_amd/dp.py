@@ -1,0 +1,89 @@
+"""Data-parallel communication layer: one process per GPU over RCCL (xGMI).
+
+Re-expresses the reference's replicated-parameter data parallelism
+(big_vision/sharding.py:83-101 `replicate`, batch split on dim 0 by
+utils.py:1388-1409) and the explicit collectives of the pmap trainer
+(trainers/proj/image_text/_deprecated_contrastive.py):
+
+  all_gather(ztxt)                    :67-77,122   -> all_gather_rows
+  transpose of that gather (psum_scatter inserted by JAX AD) -> reduce_scatter_rows
+  pmean(grads) / pmean(loss)          :343-344     -> all_reduce_sum_ on the flat
+                                                      grad buffer (sum: every rank
+                                                      already uses the GLOBAL 1/B)
+
+`torch.distributed` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU
+tests (world_size 2).  With world_size 1 every method is the identity.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+  def __init__(self, group=None):
+    self.enabled = dist.is_available() and dist.is_initialized()
+    self.group = group
+    self.rank = dist.get_rank(group) if self.enabled else 0
+    self.size = dist.get_world_size(group) if self.enabled else 1
+
+  # ------------------------------------------------------------ embeddings --
+  def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+    """[n, E] on every rank -> [size*n, E], rank r's rows at [r*n, (r+1)*n)."""
+    if self.size == 1:
+      return x
+    out = torch.empty((self.size * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+    return out
+
+  def reduce_scatter_rows(self, x: torch.Tensor) -> torch.Tensor:
+    """[size*n, E] partial sums -> this rank's [n, E] block of the total."""
+    if self.size == 1:
+      return x
+    n = x.shape[0] // self.size
+    out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+    if dist.get_backend(self.group) == "gloo":  # gloo has no reduce_scatter_tensor
+      tmp = x.contiguous().clone()
+      dist.all_reduce(tmp, group=self.group)
+      out.copy_(tmp[self.rank * n:(self.rank + 1) * n])
+    else:
+      dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
+    return out
+
+  # ----------------------------------------------------------------- grads --
+  def all_reduce_sum_(self, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
+    """In-place sum over ranks of a flat buffer, in large buckets.
+
+    xGMI is point-to-point (7 links/GPU); RCCL picks its own ring/tree/direct
+    algorithm per message, large messages amortise launch latency.
+    """
+    if self.size == 1:
+      return
+    step = max(1, bucket_bytes // flat.element_size())
+    for off in range(0, flat.numel(), step):
+      dist.all_reduce(flat[off:off + step], group=self.group)
+
+  def all_reduce_scalars_(self, t: torch.Tensor):
+    if self.size > 1:
+      dist.all_reduce(t, group=self.group)
+
+  def barrier(self):
+    if self.size > 1:
+      dist.barrier(group=self.group)
+
+
+def init_from_env(backend: str | None = None) -> Comm:
+  """Initialises torch.distributed from torchrun-style env vars (if present)."""
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  if world > 1 and not dist.is_initialized():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+      torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+  return Comm()

@@ -134,7 +134,7 @@ class _W:
     self.name = name
     sh = store.t(name, "shadow")
     ma = store.t(name, "master")
-    g = store.g(name)
+    g = store.g(name) if getattr(store, "want_grads", False) else None
     if shape2d is not None:
       sh, ma = sh.view(shape2d), ma.view(shape2d)
       g = g.view(shape2d) if g is not None else None
@@ -153,8 +153,8 @@ def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
     ops.colsum(dy_bf if dy_for_bias is None else dy_for_bias, b.grad)
 
 
-def linear_bwd_x(dy_bf, w: _W, **kw):
-  return ops.gemm(dy_bf, w.bf, a_kmajor=True, b_kmajor=True, out_dtype=BF16, **kw)
+def linear_bwd_x(dy_bf, w: _W, out_dtype=BF16, **kw):
+  return ops.gemm(dy_bf, w.bf, a_kmajor=True, b_kmajor=True, out_dtype=out_dtype, **kw)
 
 
 class LN:

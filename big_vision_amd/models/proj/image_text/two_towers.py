@@ -1,0 +1,189 @@
+"""Two-tower image/text model behind `models.proj.image_text.two_towers`.
+
+Mirrors big_vision/models/proj/image_text/two_towers.py: `Model(**config.model)`
+with fields image/text/image_model/text_model/out_dim/temperature_init/bias_init
+(:28-37); towers are resolved by module path below `big_vision_amd.models`
+(:51-53, :64-66); embeddings are L2-normalised with eps 1e-8 (:60-61, :73-74);
+`t` (log-temperature) and `b` are (1,)-shaped params (:76-85).  `apply` returns
+`(zimg, ztxt, out)` and accepts `image=None` or `text=None` (:43).
+"""
+from __future__ import annotations
+
+import importlib
+import math
+
+import torch
+
+from big_vision_amd import engine as E
+from big_vision_amd import ops
+from big_vision_amd import utils
+from big_vision_amd.params import Entry, ParamStore, ParamTree
+
+F32 = torch.float32
+MODELS_PKG = "big_vision_amd.models"
+
+
+class TwoTowersExec:
+  def __init__(self, m: "Model", store: ParamStore, prefix: str, hw, seq_len):
+    self.m, self.store = m, store
+    self.img = m.image_tower.executor(store, f"{prefix}img/", hw) if hw is not None else None
+    self.txt = m.text_tower.executor(store, f"{prefix}txt/", seq_len) if seq_len is not None else None
+    self.t = E._W(store, f"{prefix}t")
+    self.b = E._W(store, f"{prefix}b") if m.bias_init is not None else None
+
+  def fwd(self, image, text, save=False, collect=False):
+    out, ctx = {}, {}
+    zimg = ztxt = None
+    if text is not None:
+      z, o, c = self.txt.fwd(text, save, collect)
+      out.update({f"txt/{k}": v for k, v in o.items()})
+      ztxt, norm = ops.l2norm_fwd(z)
+      out["txt/norm"] = norm.view(-1, 1)
+      out["txt/normalized"] = ztxt
+      ctx["txt"] = (c, z, norm)
+    if image is not None:
+      z, o, c = self.img.fwd(image, save, collect)
+      out.update({f"img/{k}": v for k, v in o.items()})
+      zimg, norm = ops.l2norm_fwd(z)
+      out["img/norm"] = norm.view(-1, 1)
+      out["img/normalized"] = zimg
+      ctx["img"] = (c, z, norm)
+    out["t"] = torch.exp(self.t.f32)
+    out["t/parameter"] = self.t.f32
+    if self.b is not None:
+      out["b"] = self.b.f32
+    return zimg, ztxt, out, (ctx if save else None)
+
+  def bwd(self, ctx, dzimg, dztxt):
+    """dzimg / dztxt: gradients w.r.t. the NORMALISED embeddings (None = tower skipped)."""
+    if dztxt is not None and "txt" in ctx:
+      c, z, norm = ctx["txt"]
+      self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt))
+    if dzimg is not None and "img" in ctx:
+      c, z, norm = ctx["img"]
+      self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg))
+
+
+class Model:
+  """Two towers transformer."""
+
+  def __init__(self, image=None, text=None, text_model="proj.image_text.text_transformer",
+               image_model="vit", out_dim=128, temperature_init=1.0, bias_init=None, name=None):
+    self.image, self.text = dict(image or {}), dict(text or {})
+    self.text_model, self.image_model = text_model, image_model
+    self.out_dim, self.temperature_init, self.bias_init = out_dim, temperature_init, bias_init
+    out_dims = (out_dim, out_dim) if isinstance(out_dim, int) else tuple(out_dim)
+    self.text_tower = importlib.import_module(f"{MODELS_PKG}.{text_model}").Model(
+        **{"num_classes": out_dims[1], **self.text}, name="txt")
+    self.image_tower = importlib.import_module(f"{MODELS_PKG}.{image_model}").Model(
+        **{"num_classes": out_dims[0], **self.image}, name="img")
+    self._execs = {}
+
+  def entries(self, prefix, hw, seq_len):
+    ents = self.image_tower.entries(f"{prefix}img/", hw) + self.text_tower.entries(f"{prefix}txt/", seq_len)
+    ents.append(Entry(f"{prefix}t", (1,), E.init_const(math.log(self.temperature_init))))
+    if self.bias_init is not None:
+      ents.append(Entry(f"{prefix}b", (1,), E.init_const(self.bias_init)))
+    return ents
+
+  def leaf_names(self, image_shape, text_shape):
+    hw = self.image_tower.grid(tuple(image_shape))
+    return sorted(l for e in self.entries("", hw, text_shape[1]) for l, _ in e.flax_leaves())
+
+  def make_store(self, image_shape, text_shape, device=None, frozen_leaves=()):
+    """Allocates the flat parameter store for both towers (+ t, b).
+
+    `frozen_leaves`: exact Flax leaf names that get no gradient / optimizer
+    state (config.schedule None entries); they are laid out last."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    hw = self.image_tower.grid(tuple(image_shape))
+    ents = self.entries("", hw, text_shape[1])
+    frozen_leaves = set(frozen_leaves)
+    frozen = set()
+    for e in ents:
+      hits = [leaf in frozen_leaves for leaf, _ in e.flax_leaves()]
+      if any(hits) and not all(hits):
+        raise NotImplementedError(f"fused tensor {e.name} is only partially frozen")
+      if all(hits):
+        frozen.add(e.name)
+    return ParamStore(ents, device, frozen=frozen)
+
+  def init(self, rng, image, text=None, **kw):
+    del kw
+    from big_vision_amd.models.vit import _seed_of
+    store = self.make_store(tuple(image.shape), tuple(text.shape))
+    store.init_random(_seed_of(rng))
+    store.refresh_shadow()
+    return {"params": store.tree()}
+
+  def executor(self, store, prefix, image_shape, text_shape):
+    hw = self.image_tower.grid(tuple(image_shape)) if image_shape is not None else None
+    sl = text_shape[1] if text_shape is not None else None
+    key = (id(store), prefix, hw, sl, getattr(store, "want_grads", False))
+    if key not in self._execs:
+      self._execs[key] = TwoTowersExec(self, store, prefix, hw, sl)
+    return self._execs[key]
+
+  def apply(self, variables, image, text=None, *, train=False, rngs=None, collect=True, **kw):
+    del rngs, train, kw
+    params = variables["params"]
+    if isinstance(params, ParamTree) and params.store is not None:
+      store, prefix = params.store, params.prefix
+    else:
+      key = ("adhoc", id(params))
+      if key not in self._execs:
+        if image is None or text is None:
+          raise ValueError("ad-hoc parameter trees need both inputs to size the store")
+        store = self.make_store(tuple(image.shape), tuple(text.shape))
+        store.load_tree(params)
+        self._execs[key] = store
+      store, prefix = self._execs[key], ""
+    store.refresh_shadow()
+    ex = self.executor(store, prefix, None if image is None else tuple(image.shape),
+                       None if text is None else tuple(text.shape))
+    zimg, ztxt, out, _ = ex.fwd(image, text, save=False, collect=collect)
+    return zimg, ztxt, out
+
+
+def load(init_params, init_files, model_cfg, img_load_kw={}, txt_load_kw={}):  # pylint: disable=dangerous-default-value
+  """Loads both towers, `init_files` is a dict with `img` and `txt` keys (two_towers.py:93-137)."""
+  if isinstance(init_files, str):
+    init_files = VANITY_NAMES.get(init_files, init_files)
+  if isinstance(init_files, str):
+    keys = ("img", "txt", "t", "b") if "bias_init" in model_cfg.keys() else ("img", "txt", "t")
+    init_files = {k: f"{init_files}:{k}" for k in keys}
+  else:
+    init_files = {**init_files}
+  if not init_params:
+    init_params = {"img": None, "txt": None}
+  restored_params = {**init_params}
+
+  img_init = init_files.pop("image", init_files.pop("img", None))
+  if img_init:
+    restored_params["img"] = importlib.import_module(
+        f"{MODELS_PKG}.{model_cfg.get('image_model', 'vit')}"
+    ).load(init_params["img"], img_init, model_cfg.get("image"), **img_load_kw)
+  txt_init = init_files.pop("text", init_files.pop("txt", None))
+  if txt_init:
+    restored_params["txt"] = importlib.import_module(
+        f"{MODELS_PKG}.{model_cfg.get('text_model', 'proj.image_text.text_transformer')}"
+    ).load(init_params["txt"], txt_init, model_cfg.get("text"), **txt_load_kw)
+  t_init = init_files.pop("temperature", init_files.pop("t", None))
+  if t_init:
+    restored_params["t"] = utils.load_params(t_init)
+  b_init = init_files.pop("bias", init_files.pop("b", None))
+  if b_init:
+    restored_params["b"] = utils.load_params(b_init)
+  assert not init_files, (
+      f"There's something unused left in `config.model_init`. You probably got "
+      f"a typo. Here it is: {init_files}")
+  return restored_params
+
+
+# Shortcut names for some canonical paper checkpoints (gs:// paths; kept for
+# config compatibility — unreachable offline).
+VANITY_NAMES = {
+    "SigLIP B/16 224": "gs://big_vision/siglip/webli_en_b16_224_63724782.npz",
+    "SigLIP B/16 256": "gs://big_vision/siglip/webli_en_b16_256_60500360.npz",
+    "SigLIP L/16 256": "gs://big_vision/siglip/webli_en_l16_256_60552751.npz",
+}

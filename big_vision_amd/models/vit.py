@@ -1,0 +1,356 @@
+"""ViT on hand-written gfx950 kernels, behind big_vision's `models.vit` surface.
+
+Mirrors the module-level API of the reference big_vision/models/vit.py:
+`Model(num_classes=None, *, variant=None, **kw)` (:279-281), `.init` /
+`.apply` with Flax-named parameter trees, `decode_variant` (:284-303),
+`load` (:408-433), `VANITY_NAMES`.  The forward math follows
+`_Model.__call__` (:206-276); every tensor op is a libbvhip kernel
+(see big_vision_amd/engine.py), nothing runs in eager PyTorch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from big_vision_amd import engine as E
+from big_vision_amd import ops
+from big_vision_amd import utils
+from big_vision_amd.models import common
+from big_vision_amd.params import Entry, ParamStore, ParamTree
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def posemb_sincos_2d(h, w, width, temperature=10_000.0):
+  """Constant sin-cos table [1, h*w, width] (reference vit.py:34-44), float32."""
+  y, x = np.mgrid[:h, :w]
+  assert width % 4 == 0, "Width must be mult of 4 for sincos posemb"
+  omega = np.arange(width // 4) / (width // 4 - 1)
+  omega = 1.0 / (temperature ** omega)
+  y = np.einsum("m,d->md", y.flatten(), omega)
+  x = np.einsum("m,d->md", x.flatten(), omega)
+  pe = np.concatenate([np.sin(x), np.cos(x), np.sin(y), np.cos(y)], axis=1)
+  return np.asarray(pe, np.float32)[None, :, :]
+
+
+def decode_variant(variant):
+  """Converts a string like "B" or "B/32" into a params dict (vit.py:284-303)."""
+  if variant is None:
+    return {}
+  v, patch = variant, {}
+  if "/" in variant:
+    v, patch = variant.split("/")
+    patch = {"patch_size": (int(patch), int(patch))}
+  return {
+      "width": {"mu": 32, "Ti": 192, "S": 384, "M": 512, "B": 768, "L": 1024, "So400m": 1152, "H": 1280, "g": 1408, "g-opt": 1536, "G": 1664, "G-opt": 1536, "e": 1792}[v],
+      "depth": {"mu": 1, "Ti": 12, "S": 12, "M": 12, "B": 12, "L": 24, "So400m": 27, "H": 32, "g": 40, "g-opt": 40, "G": 48, "G-opt": 48, "e": 56}[v],
+      "mlp_dim": {"mu": 128, "Ti": 768, "S": 1536, "M": 2048, "B": 3072, "L": 4096, "So400m": 4304, "H": 5120, "g": 6144, "g-opt": 6144, "G": 8192, "G-opt": 8192, "e": 15360}[v],
+      "num_heads": {"mu": 2, "Ti": 3, "S": 6, "M": 8, "B": 12, "L": 16, "So400m": 16, "H": 16, "g": 16, "g-opt": 16, "G": 16, "G-opt": 16, "e": 16}[v],
+      **patch
+  }
+
+
+def _seed_of(rng) -> int:
+  if isinstance(rng, torch.Generator):
+    return int(rng.initial_seed())
+  a = np.asarray(rng).astype(np.uint64).ravel()
+  s = 0
+  for v in a:
+    s = (s * 1000003 + int(v)) % (2 ** 63)
+  return int(s)
+
+
+class VitExec:
+  """Forward / backward of one image tower bound to a ParamStore at `prefix`."""
+
+  def __init__(self, m: "_Model", store: ParamStore, prefix: str, hw):
+    self.m, self.store = m, store
+    D, H, M = m.width, m.num_heads, m.mlp_dim
+    self.hw = hw
+    self.wemb = E._W(store, f"{prefix}embedding/kernel", (m.patch_size[0] * m.patch_size[1] * 3, D))
+    self.bemb = E._W(store, f"{prefix}embedding/bias")
+    if m.posemb == "learn":
+      self.pos = E._W(store, f"{prefix}pos_embedding", (hw[0] * hw[1], D))
+      self.pos_const = None
+    else:
+      self.pos = None
+      self.pos_const = torch.from_numpy(posemb_sincos_2d(hw[0], hw[1], D)[0]).to(store.device)
+    self.cls = E._W(store, f"{prefix}cls", (1, D)) if m.pool_type == "tok" else None
+    self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M)
+    self.map = E.MAPHead(store, f"{prefix}MAPHead_0", D, H, M) if m.pool_type == "map" else None
+    self.pre = None
+    if m.rep_size:
+      raise NotImplementedError("rep_size (pre_logits tanh) is served by big_vision_amd.train only")
+    self.head = None
+    if m.num_classes:
+      self.head = (E._W(store, f"{prefix}head/kernel"), E._W(store, f"{prefix}head/bias"))
+
+  # -------------------------------------------------------------- forward --
+  def fwd(self, image, save=False, collect=False):
+    m = self.m
+    D = m.width
+    out = {}
+    image = image.to(F32).contiguous()
+    n = image.shape[0]
+    patches, (h, w) = ops.patchify(image, m.patch_size[0])
+    assert (h, w) == tuple(self.hw), f"image grid {(h, w)} != initialised grid {self.hw}"
+    L0 = h * w
+    pos = self.pos.f32 if self.pos is not None else self.pos_const
+    x = E.linear_fwd(patches, self.wemb, self.bemb, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L0)
+    if collect:
+      out["with_posemb"] = x.view(n, L0, D)
+    L = L0
+    if m.pool_type == "tok":
+      x = ops.concat_cls(self.cls.f32, x, n, L0, D)
+      L = L0 + 1
+    enc_out = {} if collect else None
+    xL, saved = self.enc.fwd(x, n, L, save, enc_out)
+    if collect:
+      out["encoder"] = enc_out
+    ctx = dict(n=n, L=L, L0=L0, patches=patches, enc=saved, xL=xL)
+    T = n * L
+    if m.pool_type == "map":
+      y, _, mean, rstd = self.enc.norm.fwd(xL, T, D)
+      z, msaved = self.map.fwd(y, n, L)
+      ctx.update(norm=(mean, rstd), map=msaved)
+      if collect:
+        out["encoded"] = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)[1].view(n, L, D)
+    elif m.pool_type == "gap":
+      _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
+      z = ops.pool_gap_fwd(yf, n, L, D)
+      ctx.update(norm=(mean, rstd))
+      if collect:
+        out["encoded"] = yf.view(n, L, D)
+    elif m.pool_type in ("0", "tok"):
+      if collect:
+        _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
+        enc = yf.view(n, L, D)
+        out["encoded"] = enc[:, 1:] if m.pool_type == "tok" else enc
+        z = enc[:, 0].contiguous()
+        mean, rstd = mean.view(n, L)[:, 0].contiguous(), rstd.view(n, L)[:, 0].contiguous()
+      else:
+        _, z, mean, rstd = self.enc.norm.fwd(xL, n, D, row_stride=L, row_offset=0, want_bf16=False, want_f32=True)
+      ctx.update(norm=(mean, rstd))
+    else:
+      raise ValueError(f"Unknown pool type: '{m.pool_type}'")
+    out["head_input"] = z
+    out["pre_logits"] = z
+    x = z
+    if self.head is not None:
+      zb = ops.cast_bf16(z)
+      x = E.linear_fwd(zb, self.head[0], self.head[1], out_dtype=F32)
+      out["logits"] = x
+      ctx["head_in"] = zb
+    return x, out, (ctx if save else None)
+
+  # ------------------------------------------------------------- backward --
+  def bwd(self, ctx, dx):
+    m = self.m
+    D = m.width
+    n, L, L0 = ctx["n"], ctx["L"], ctx["L0"]
+    T = n * L
+    dz = dx.contiguous()
+    if self.head is not None:
+      dzb = ops.cast_bf16(dz)
+      E.linear_bwd_w(ctx["head_in"], dzb, self.head[0], self.head[1], dy_for_bias=dz)
+      dz = E.linear_bwd_x(dzb, self.head[0], out_dtype=F32)
+    mean, rstd = ctx["norm"]
+    xL = ctx["xL"]
+    dxL_bf = torch.empty((T, D), device=xL.device, dtype=BF16)
+    if m.pool_type == "map":
+      dy = self.map.bwd(ctx["map"], dz, n, L)
+      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
+    elif m.pool_type == "gap":
+      dyf = ops.pool_gap_bwd(dz, n, L, D)
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
+    else:
+      dxL = torch.zeros((T, D), device=xL.device, dtype=F32)
+      dxL_bf.zero_()
+      self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=0)
+    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L)
+    if m.pool_type == "tok":
+      if self.cls.grad is not None:
+        ops.colsum(dx0.view(n, L * D)[:, :D], self.cls.grad.view(-1))
+      dx0 = dx0.view(n, L, D)[:, 1:].contiguous().view(n * L0, D)
+      dx0_bf = ops.cast_bf16(dx0)
+    E.linear_bwd_w(ctx["patches"], dx0_bf, self.wemb, self.bemb, dy_for_bias=dx0)
+    if self.pos is not None and self.pos.grad is not None:
+      ops.batchsum(dx0, self.pos.grad, n, L0, D)
+
+
+class _Model:
+  """ViT model (configuration holder + Flax-like init/apply)."""
+
+  def __init__(self, num_classes: Optional[int] = None, patch_size: Sequence[int] = (16, 16),
+               width: int = 768, depth: int = 12, mlp_dim: Optional[int] = None, num_heads: int = 12,
+               posemb: str = "learn", rep_size: Union[int, bool] = False, dropout: float = 0.0,
+               pool_type: str = "gap", head_zeroinit: bool = True, scan: bool = False,
+               remat_policy: str = "nothing_saveable", dtype_mm: str = "float32", name=None):
+    if posemb not in ("learn", "sincos2d"):
+      raise ValueError(f"Unknown posemb type: {posemb}")
+    if pool_type not in ("map", "gap", "0", "tok", "none"):
+      raise ValueError(f"Unknown pool type: '{pool_type}'")
+    if dropout:
+      raise NotImplementedError("dropout > 0 is not on the accelerated path (all in-scope configs use 0)")
+    if width % num_heads or width // num_heads != 64:
+      raise NotImplementedError(f"attention kernels need head_dim 64, got {width}/{num_heads}")
+    self.num_classes, self.patch_size = num_classes, tuple(patch_size)
+    self.width, self.depth, self.mlp_dim = width, depth, mlp_dim or 4 * width
+    self.num_heads, self.posemb, self.rep_size = num_heads, posemb, rep_size
+    self.pool_type, self.head_zeroinit, self.scan = pool_type, head_zeroinit, scan
+    self.name = name
+    self._execs = {}
+
+  # -------------------------------------------------------------- params ---
+  def entries(self, prefix, hw):
+    D, H, M = self.width, self.num_heads, self.mlp_dim
+    ph, pw = self.patch_size
+    ents = [Entry(f"{prefix}embedding/kernel", (ph, pw, 3, D), E.init_lecun_normal(ph * pw * 3)),
+            Entry(f"{prefix}embedding/bias", (D,), E.init_zeros)]
+    if self.posemb == "learn":
+      ents.append(Entry(f"{prefix}pos_embedding", (1, hw[0] * hw[1], D), E.init_normal(1 / math.sqrt(D))))
+    if self.pool_type == "tok":
+      ents.append(Entry(f"{prefix}cls", (1, 1, D), E.init_zeros))
+    ents += E.encoder_entries(f"{prefix}Transformer", self.depth, D, H, M)
+    if self.pool_type == "map":
+      ents += E.map_entries(f"{prefix}MAPHead_0", D, H, M)
+    feat = D
+    if self.rep_size:
+      rs = D if self.rep_size is True else self.rep_size
+      ents += [Entry(f"{prefix}pre_logits/kernel", (D, rs), E.init_lecun_normal(D)),
+               Entry(f"{prefix}pre_logits/bias", (rs,), E.init_zeros)]
+      feat = rs
+    if self.num_classes:
+      kinit = E.init_zeros if self.head_zeroinit else E.init_lecun_normal(feat)
+      ents += [Entry(f"{prefix}head/kernel", (feat, self.num_classes), kinit),
+               Entry(f"{prefix}head/bias", (self.num_classes,), E.init_zeros)]
+    return ents
+
+  def grid(self, image_shape):
+    return (image_shape[1] // self.patch_size[0], image_shape[2] // self.patch_size[1])
+
+  def init(self, rng, image, **kw):
+    del kw
+    shape = tuple(image.shape)
+    dev = image.device if torch.is_tensor(image) and image.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    store = ParamStore(self.entries("", self.grid(shape)), dev)
+    store.init_random(_seed_of(rng))
+    store.refresh_shadow()
+    return {"params": store.tree()}
+
+  def executor(self, store, prefix, hw):
+    key = (id(store), prefix, tuple(hw), getattr(store, "want_grads", False))
+    if key not in self._execs:
+      self._execs[key] = VitExec(self, store, prefix, hw)
+    return self._execs[key]
+
+  def _store_for(self, params, hw):
+    if isinstance(params, ParamTree) and params.store is not None:
+      return params.store, params.prefix
+    key = ("adhoc", id(params))
+    if key not in self._execs:
+      dev = torch.device("cuda", torch.cuda.current_device())
+      store = ParamStore(self.entries("", hw), dev)
+      store.load_tree(params)
+      self._execs[key] = store
+    return self._execs[key], ""
+
+  def apply(self, variables, image, *, train=False, rngs=None, collect=True, **kw):
+    del rngs, train, kw
+    hw = self.grid(tuple(image.shape))
+    store, prefix = self._store_for(variables["params"], hw)
+    store.refresh_shadow()
+    x, out, _ = self.executor(store, prefix, hw).fwd(image, save=False, collect=collect)
+    return x, out
+
+  __call__ = None  # Flax-style direct calls are not supported; use .apply
+
+
+def Model(num_classes=None, *, variant=None, **kw):  # pylint: disable=invalid-name
+  """Factory function (reference vit.py:279-281)."""
+  return _Model(num_classes, **{**decode_variant(variant), **kw})
+
+
+# ----------------------------------------------------------- checkpoint I/O --
+def resample_posemb(old, new):
+  """"High-res finetuning": bilinear resize of the posemb grid (vit.py:306-321)."""
+  import scipy.ndimage
+  old, new_shape = np.asarray(old), tuple(np.asarray(new).shape)
+  if old.shape == new_shape:
+    return old
+  gs_old = int(np.sqrt(old.shape[1]))
+  gs_new = int(np.sqrt(new_shape[1]))
+  grid = old.reshape(gs_old, gs_old, -1)
+  zoom = (gs_new / gs_old, gs_new / gs_old, 1)
+  grid = scipy.ndimage.zoom(grid, zoom, order=1)
+  return grid.reshape(1, gs_new * gs_new, -1)
+
+
+def fix_old_checkpoints(params):
+  """Small backward-compat fix-ups that names alone cannot express (vit.py:324-360)."""
+  params = utils.tree_map(lambda x: x, params)  # structural copy
+  t = params["Transformer"]
+  if "posembed_input" in t:
+    params["pos_embedding"] = t.pop("posembed_input")["pos_embedding"]
+  if "pos_embedding" in t:
+    params["pos_embedding"] = t.pop("pos_embedding")
+  if "pos_embedding" in params:
+    pe = np.asarray(params["pos_embedding"])
+    if int(np.sqrt(pe.shape[1])) ** 2 + 1 == int(pe.shape[1]):
+      pe_cls, params["pos_embedding"] = pe[:, :1], pe[:, 1:]
+      if "cls" in params:
+        params["cls"] = np.asarray(params["cls"]) + pe_cls
+  if "probe" in params:
+    params["MAPHead_0"] = {k: params.pop(k) for k in
+                           ["probe", "MlpBlock_0", "MultiHeadDotProductAttention_0", "LayerNorm_0"]}
+  return params
+
+
+def pyloop_to_scan(params_pyloop):
+  """encoderblock_{i} -> stacked `encoderblock` (vit.py:363-386)."""
+  p = utils.tree_map(lambda x: x, params_pyloop)
+  t = p["Transformer"]
+  depth = 1 + max(int(k.split("_")[-1]) for k in t if k.startswith("encoderblock_"))
+  blocks = [t.pop(f"encoderblock_{i}") for i in range(depth)]
+  t["encoderblock"] = utils.tree_map(lambda *v: np.stack([np.asarray(a) for a in v]), *blocks)
+  return p
+
+
+def scan_to_pyloop(params_scan):
+  """Stacked `encoderblock` -> encoderblock_{i} (vit.py:389-405)."""
+  p = utils.tree_map(lambda x: x, params_scan)
+  t = p["Transformer"]
+  stacked = t.pop("encoderblock")
+  depth = len(stacked["LayerNorm_0"]["bias"])
+  for i in range(depth):
+    t[f"encoderblock_{i}"] = utils.tree_map(lambda x, i=i: np.asarray(x)[i], stacked)
+  return p
+
+
+def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=invalid-name
+  """Load init from checkpoint, both old model and this one. +Hi-res posemb (vit.py:408-433)."""
+  init_file = VANITY_NAMES.get(init_file, init_file)
+  restored_params = utils.load_params(init_file)
+  restored_params = fix_old_checkpoints(restored_params)
+  # The accelerated encoder always uses the python-loop layout.
+  if "encoderblock" in restored_params["Transformer"]:
+    restored_params = scan_to_pyloop(restored_params)
+  del model_cfg
+  restored_params = common.merge_params(restored_params, init_params, dont_load)
+  if init_params and "pos_embedding" in init_params:
+    restored_params["pos_embedding"] = resample_posemb(
+        old=restored_params["pos_embedding"], new=init_params["pos_embedding"])
+  return restored_params
+
+
+# Shortcut names for some canonical paper checkpoints (paths are gs:// buckets,
+# unreachable offline; kept so configs referring to them resolve the same way).
+VANITY_NAMES = {
+    "howto-i21k-Ti/16": "gs://vit_models/augreg/Ti_16-i21k-300ep-lr_0.001-aug_none-wd_0.03-do_0.0-sd_0.0.npz",
+    "howto-i21k-S/16": "gs://vit_models/augreg/S_16-i21k-300ep-lr_0.001-aug_light1-wd_0.03-do_0.0-sd_0.0.npz",
+    "howto-i21k-B/16": "gs://vit_models/augreg/B_16-i21k-300ep-lr_0.001-aug_medium1-wd_0.1-do_0.0-sd_0.0.npz",
+    "howto-i21k-L/16": "gs://vit_models/augreg/L_16-i21k-300ep-lr_0.001-aug_strong1-wd_0.1-do_0.0-sd_0.0.npz",
+}

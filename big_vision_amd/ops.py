@@ -66,11 +66,11 @@ def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=Non
   return out
 
 
-def sgemm(a, sam, sak, b, sbk, sbn, out, M, N, K, alpha=1.0, beta=0.0):
-  """fp32 strided GEMM (bv_sgemm_strided)."""
+def sgemm(a, sam, sak, b, sbk, sbn, out, M, N, K, alpha=1.0, beta=0.0, log_alpha=None):
+  """fp32 strided GEMM (bv_sgemm_strided); alpha is multiplied by exp(log_alpha[0]) (device)."""
   _chk(a, F32, "sgemm.a"); _chk(b, F32, "sgemm.b"); _chk(out, F32, "sgemm.out")
   _lib.call("bv_sgemm_strided", _p(a), sam, sak, _p(b), sbk, sbn, _p(out), out.stride(0), M, N, K,
-            float(alpha), float(beta), _stream())
+            float(alpha), float(beta), _p(log_alpha), _stream())
   return out
 
 
@@ -248,8 +248,12 @@ def sqnorm_(x, out):
   _lib.call("bv_sqnorm", _p(x), x.numel(), _p(out), _stream())
 
 
-def adam_step_(params, grads, mu, nu, shadow, segs, chunk_seg, count, gsq, clip_norm, b1, b2, eps,
-               bc1, bc2, stats):
+def adam_step_(params, grads, mu, nu, shadow, segs, chunk_seg, count, sched, gsq, clip_norm, b1, b2,
+               eps, bc1, bc2, stats):
+  """segs: device int32/float32 table of bv_adam_seg; sched: python list of floats (<= 8)."""
+  import ctypes
+  arr = (ctypes.c_float * len(sched))(*[float(v) for v in sched])
   _lib.call("bv_adam_step", _p(params), _p(grads), _p(mu), int(mu.dtype == BF16), _p(nu), _p(shadow),
-            _p(segs), _p(chunk_seg), count, _p(gsq), float(clip_norm or 0.0), float(b1), float(b2),
-            float(eps), float(bc1), float(bc2), _p(stats), _stream())
+            _p(segs), _p(chunk_seg), count, ctypes.cast(arr, ctypes.c_void_p), len(sched), _p(gsq),
+            float(clip_norm or 0.0), float(b1), float(b2), float(eps), float(bc1), float(bc2),
+            _p(stats), _stream())

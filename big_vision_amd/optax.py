@@ -1,0 +1,193 @@
+"""Optimizer chain of big_vision/optax.py:75-149 as ONE fused HIP kernel launch.
+
+`make(config, store, sched_kw=...)` reads the same config fields as
+`bv_optax.make` (schedule, grad_clip_norm, optax_name, optax, lr, lr_mults, wd,
+wd_mults) and resolves them per Flax leaf name with the reference's first-match
+regex semantics (utils.py:1195-1212).  The chain
+
+  clip_by_global_norm(not frozen) -> scale_by_adam -> scale(lr) -> lr_mults ->
+  add_decayed_weights -> scale_by_schedule / set_to_zero(frozen) -> scale(-1)
+  -> optax.apply_updates
+
+runs as bv_sqnorm + bv_adam_step over the flat parameter buffer.  Frozen
+parameters (schedule None) live past the trainable prefix of the store: no
+gradient, no Adam state (optax_test.py:301-318), excluded from the clip norm
+(optax.py:105) and from l2_grads (trainers/proj/image_text/siglip.py:316).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from big_vision_amd import ops
+from big_vision_amd import utils as u
+from big_vision_amd.params import ParamStore, make_masks
+
+MAX_SCHED = 8
+
+
+def frozen_patterns(config) -> List[str]:
+  """Regexes of config.schedule whose schedule is None (= frozen params).
+
+  Only valid as a pre-filter when earlier patterns cannot shadow later ones;
+  `make` re-validates against the store with full first-match semantics.
+  """
+  schedule = config.get("schedule", {})
+  if not isinstance(schedule, (tuple, list)):
+    return []
+  return [p for p, s in schedule if s is None]
+
+
+def frozen_leaves(config, leaf_names) -> set:
+  """Exact first-match resolution of frozen leaves (optax.py:82-84,152-174)."""
+  schedule = config.get("schedule", {})
+  if not isinstance(schedule, (tuple, list)):
+    return set()
+  pats, scheds = zip(*schedule)
+  masks = make_masks(leaf_names, pats)
+  return {n for n in leaf_names for m, s in zip(masks, scheds) if s is None and m[n]}
+
+
+class Optimizer:
+  """State + update of the fused chain (the `opt` half of the train state)."""
+
+  def __init__(self, config, store: ParamStore, *, sched_kw):
+    self.store = store
+    dev = store.device
+    leaves = store.leaf_names()
+    # ---- schedules (optax.py:79-97)
+    schedule = config.get("schedule", {})
+    if not isinstance(schedule, (tuple, list)):
+      schedule = [(".*", schedule)]
+    pats, scheds = zip(*schedule)
+    masks = make_masks(leaves, pats)
+    not_covered = [n for n in leaves if not any(m[n] for m in masks)]
+    assert not not_covered, f"All params must be covered (use `None` for freezing): {not_covered}"
+    kw = dict(sched_kw)
+    if "global_batch_size" in kw:
+      kw["batch_size"] = kw.pop("global_batch_size")
+    self.schedule_fns = []
+    sched_idx_of_leaf: Dict[str, int] = {}
+    frozen = set()
+    for m, s in zip(masks, scheds):
+      names = [n for n in leaves if m[n]]
+      if s is None:
+        frozen.update(names)
+        continue
+      s = dict(s)
+      assert "base" not in s, s
+      mult = s.pop("mult", 1.0)
+      self.schedule_fns.append(u.create_learning_rate_schedule(base=mult, **kw, **s))
+      for n in names:
+        sched_idx_of_leaf[n] = len(self.schedule_fns) - 1
+    assert len(self.schedule_fns) <= MAX_SCHED, "too many schedule groups"
+    frozen_entries = {store.leaf_index[n][0] for n in frozen}
+    if frozen_entries != set(store.frozen):
+      raise ValueError("The parameter store was not laid out for this config.schedule: "
+                       f"frozen in config {sorted(frozen_entries)[:4]}... vs store {sorted(store.frozen)[:4]}...")
+    # ---- lr multipliers, weight decay (optax.py:114-138)
+    lr_mult = {n: 1.0 for n in leaves}
+    if config.get("lr_mults"):
+      p2, mults = zip(*config["lr_mults"])
+      assert all(mu > 0 for mu in mults), (
+          f"Use schedule=None for parameter freezing instead of lr_mults={mults}")
+      for m, mu in zip(make_masks(leaves, p2), mults):
+        for n in leaves:
+          if m[n]:
+            lr_mult[n] = mu
+    assert "weight_decay" not in config, "Deprecated option. Use wd and schedule."
+    assert config.get("weight_decay_decouple", True), "Coupled weight decay not supported anymore."
+    wd = {n: 0.0 for n in leaves}
+    if config.get("wd"):
+      wd_mults = config.get("wd_mults", [(".*/kernel$", 1.0)])
+      p3, mults = zip(*wd_mults)
+      for m, mu in zip(make_masks(leaves, p3), mults):
+        for n in leaves:
+          if m[n]:
+            wd[n] = config["wd"] * mu
+    # ---- optimizer proper (optax.py:108-112)
+    assert "optim" not in config, "Deprecated option, use config.optax."
+    self.name = config["optax_name"]
+    okw = dict(config.get("optax", {}) or {})
+    if self.name == "scale_by_adam":
+      self.b1, self.b2, self.eps = okw.get("b1", 0.9), okw.get("b2", 0.999), okw.get("eps", 1e-8)
+      assert okw.get("eps_root", 0.0) == 0.0, "eps_root is not supported"
+      mu_dtype = okw.get("mu_dtype")
+      mu_dtype = torch.bfloat16 if str(mu_dtype) in ("bfloat16", "torch.bfloat16") else torch.float32
+    else:
+      raise NotImplementedError(f"optax_name={self.name!r}: only scale_by_adam is on the fused path")
+    self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
+    assert not config.get("grad_clip_per_example"), "per-example clipping is not supported"
+    self.lr = float(config["lr"])
+    # ---- per-entry hyper-parameter table + chunk map
+    n_tr = store.trainable_count
+    seg_rows, chunk_seg = [], np.zeros(n_tr // 1024, np.int32)
+    for e in store.entries.values():
+      if e.name in store.frozen:
+        continue
+      lv = [leaf for leaf, _ in e.flax_leaves()]
+      hp = {(lr_mult[l], wd[l], sched_idx_of_leaf[l]) for l in lv}
+      if len(hp) != 1:
+        raise NotImplementedError(f"fused tensor {e.name} has mixed optimizer hyper-parameters {hp}")
+      (lm, w, si), = hp
+      seg_rows.append((self.lr * lm, w, si))
+      c0, c1 = e.offset // 1024, (e.offset + e.numel + 1023) // 1024
+      chunk_seg[c0:c1] = len(seg_rows) - 1
+    segs = np.zeros((len(seg_rows), 4), np.float32)
+    for i, (le, w, si) in enumerate(seg_rows):
+      segs[i, 0], segs[i, 1] = le, w
+      segs[i, 2:3].view(np.int32)[0] = si
+    self.segs = torch.from_numpy(segs).to(dev)
+    self.chunk_seg = torch.from_numpy(chunk_seg).to(dev)
+    self.mu = torch.zeros(n_tr, device=dev, dtype=mu_dtype)
+    self.nu = torch.zeros(n_tr, device=dev, dtype=torch.float32)
+    self.count = 0
+    self.gsq = torch.zeros(1, device=dev, dtype=torch.float64)
+    self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
+    self._frozen_sq = None
+
+  def frozen_sqnorm(self):
+    if self._frozen_sq is None:
+      acc = torch.zeros(1, device=self.store.device, dtype=torch.float64)
+      tail = self.store.master[self.store.trainable_count:]
+      if tail.numel():
+        ops.sqnorm_(tail, acc)
+      self._frozen_sq = acc
+    return self._frozen_sq
+
+  def step(self):
+    """tx.update + optax.apply_updates on the store; returns device scalars
+    (l2_grads, l2_params, l2_updates) without synchronising."""
+    st = self.store
+    n_tr = st.trainable_count
+    k = self.count
+    sched = [fn(k) for fn in self.schedule_fns]   # scale_by_schedule uses the pre-increment count
+    self.gsq.zero_()
+    ops.sqnorm_(st.grad, self.gsq)
+    self.stats.zero_()
+    ops.adam_step_(st.master, st.grad, self.mu, self.nu, st.shadow, self.segs, self.chunk_seg, n_tr,
+                   sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
+                   1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
+    self.count = k + 1
+    return {"l2_grads": torch.sqrt(self.gsq[0]),
+            "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
+            "l2_updates": torch.sqrt(self.stats[1])}
+
+  # checkpoint-ish helpers
+  def state_dict(self):
+    return {"mu": self.mu, "nu": self.nu, "count": self.count}
+
+
+def make(config, store: ParamStore, *, sched_kw):
+  """Returns (optimizer, schedule_fns) like bv_optax.make returns (tx, sched_fns)."""
+  opt = Optimizer(config, store, sched_kw=sched_kw)
+  return opt, opt.schedule_fns
+
+
+def get_count(opt: Optimizer, jittable=False):
+  """optax.py:30-41."""
+  del jittable
+  return opt.count

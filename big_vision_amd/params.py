@@ -48,6 +48,7 @@ class ParamTree(dict):
   """Nested dict of parameter views that remembers the store it came from."""
   store = None
   buf = "master"
+  prefix = ""   # '/'-terminated path of this node below the store root
 
 
 def _nest(flat: Dict[str, torch.Tensor], store, buf) -> ParamTree:
@@ -60,6 +61,7 @@ def _nest(flat: Dict[str, torch.Tensor], store, buf) -> ParamTree:
       if p not in node:
         child = ParamTree()
         child.store, child.buf = store, buf
+        child.prefix = f"{node.prefix}{p}/"
         dict.__setitem__(node, p, child)
       node = node[p]
     dict.__setitem__(node, parts[-1], v)

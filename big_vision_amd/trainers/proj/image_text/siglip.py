@@ -1,0 +1,150 @@
+"""SigLIP training step on gfx950 kernels + RCCL, mirroring the reference trainer.
+
+Reference: big_vision/trainers/proj/image_text/siglip.py — `update_fn`
+(:271-323) with its inner `loss_fn` (:287-308), and the explicit-collective
+statement of the same algorithm in _deprecated_contrastive.py (:117-160,
+:308-355).  What is kept: the function names and signatures
+(`update_fn(train_state, rng, batch) -> (train_state, measurements)`), the
+config fields consumed, the measurement names, the error behaviour.  What is
+new: forward, backward, loss, collectives and optimizer are explicit sequences
+of libbvhip kernels and RCCL calls (no jit, no autograd).
+
+Data-parallel algorithm ("convention A"): rank r owns
+rows [r*n, (r+1)*n) of zimg and ztxt.  all_gather(ztxt) -> local logits
+[n, B] with the positive diagonal at column r*n + i -> G = dL/dS with the GLOBAL
+1/B -> dzimg local, dztxt_partial [B, E] -> reduce_scatter -> all parameter
+gradients are partial sums of the global gradient -> all_reduce(SUM).
+"""
+from __future__ import annotations
+
+import importlib
+
+import torch
+
+from big_vision_amd import dp
+from big_vision_amd import ops
+from big_vision_amd import optax as bv_optax
+from big_vision_amd import utils as u
+
+F32 = torch.float32
+
+
+def sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm: dp.Comm):
+  """Global-batch pairwise sigmoid loss (siglip.py:291-306) and its gradients.
+
+  zimg, ztxt: this rank's L2-normalised embeddings [n, E] (fp32).
+  Returns (stats f64[3] = [loss share, dL/dt', dL/db], dzimg [n,E], dztxt [n,E]).
+  """
+  n, E = zimg.shape
+  B = n * comm.size
+  ztxt_all = comm.all_gather_rows(ztxt)
+  raw = torch.empty((n, B), device=zimg.device, dtype=F32)
+  ops.sgemm(zimg, E, 1, ztxt_all, 1, E, raw, n, B, E)                       # zimg . ztxt_all^T
+  stats = torch.zeros(3, device=zimg.device, dtype=torch.float64)
+  ops.siglip_loss_(raw, t_param, b_param, stats, comm.rank * n, B)            # raw := G
+  dzimg = torch.empty((n, E), device=zimg.device, dtype=F32)
+  ops.sgemm(raw, B, 1, ztxt_all, E, 1, dzimg, n, E, B, log_alpha=t_param)    # t G ztxt_all
+  dztxt_all = torch.empty((B, E), device=zimg.device, dtype=F32)
+  ops.sgemm(raw, 1, B, zimg, E, 1, dztxt_all, B, E, n, log_alpha=t_param)    # t G^T zimg
+  dztxt = comm.reduce_scatter_rows(dztxt_all)
+  return stats, dzimg, dztxt
+
+
+def loss_fn(model, params, images, labels, comm=None):
+  """Forward-only loss, the `loss_fn(params)` closure of siglip.py:287-308."""
+  comm = comm or dp.Comm()
+  zimg, ztxt, extras = model.apply({"params": params}, images, labels, train=True, collect=False)
+  stats, _, _ = sigmoid_loss_fwd_bwd(zimg, ztxt, extras["t/parameter"], extras.get("b"), comm)
+  loss = stats[:1].clone()
+  comm.all_reduce_scalars_(loss)
+  return loss[0]
+
+
+def make_train_state(model, config, image_shape, text_shape, *, rng=0, comm=None, total_steps=None,
+                     device=None):
+  """Parameter store + optimizer laid out for `config` (replaces siglip.py:190-260)."""
+  from big_vision_amd.models.vit import _seed_of
+  comm = comm or dp.Comm()
+  frozen = bv_optax.frozen_leaves(config, model.leaf_names(image_shape, text_shape))
+  store = model.make_store(image_shape, text_shape, device=device, frozen_leaves=frozen)
+  store.init_random(_seed_of(rng))
+  store.refresh_shadow()
+  store.want_grads = True
+  batch_size = config.get("input", {}).get("batch_size", image_shape[0] * comm.size)
+  total_steps = total_steps if total_steps is not None else u.steps(
+      "total", config, None, batch_size)
+  sched_kw = dict(total_steps=total_steps, batch_size=batch_size, data_size=None)
+  opt, sched_fns = bv_optax.make(config, store, sched_kw=sched_kw)
+  return {"params": store.tree(), "opt": opt}, sched_fns
+
+
+def make_update_fn(model, config, comm=None):
+  """Builds `update_fn(train_state, rng, batch)` (siglip.py:271-323)."""
+  comm = comm or dp.Comm()
+  assert "mixup" not in config, "Mixup is not supported for SigLIP."
+  micro = int(config.get("microbatch", 0) or 0)
+
+  def update_fn(train_state, rng, batch):
+    del rng  # dropout is 0 on this path; kept for signature parity
+    images, labels = batch["image"], batch["labels"]
+    params, opt = train_state["params"], train_state["opt"]
+    store = params.store
+    store.want_grads = True
+    store.zero_grad()
+    n = images.shape[0]
+    ex = model.executor(store, "", tuple(images.shape[:1]) + tuple(images.shape[1:]), tuple(labels.shape))
+    img_frozen = all(e in store.frozen for e in store.entries if e.startswith("img/"))
+    txt_frozen = all(e in store.frozen for e in store.entries if e.startswith("txt/"))
+    t_param = store.t("t")
+    b_param = store.t("b") if "b" in store.entries else None
+
+    if micro and n > micro:
+      assert n % micro == 0, f"per-device batch {n} not divisible by microbatch {micro}"
+      # Pass 1: embeddings of all micro-batches (no activations kept).
+      zi, zt = [], []
+      for s in range(0, n, micro):
+        a, b, _, _ = ex.fwd(images[s:s + micro], labels[s:s + micro], save=False)
+        zi.append(a); zt.append(b)
+      zimg, ztxt = torch.cat(zi), torch.cat(zt)
+      stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
+      # Pass 2: recompute each micro-batch with activations and back-propagate
+      # its slice of the embedding gradients (grads accumulate in the flat buffer).
+      for s in range(0, n, micro):
+        _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro], save=True)
+        ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
+               None if txt_frozen else dztxt[s:s + micro].contiguous())
+    else:
+      zimg, ztxt, _, ctx = ex.fwd(images, labels, save=True)
+      stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
+      ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt)
+
+    # dL/dt', dL/db (scalars computed by the loss kernel) into the flat grad buffer.
+    gt = store.g("t")
+    if gt is not None:
+      gt += stats[1].to(F32)
+    if b_param is not None and store.g("b") is not None:
+      store.g("b").add_(stats[2].to(F32))
+
+    # DP: sum partial gradients and the loss shares (pmean of the reference).
+    comm.all_reduce_sum_(store.grad)
+    loss = stats[:1].clone()
+    comm.all_reduce_scalars_(loss)
+
+    measurements = {"training_loss": loss[0]}
+    measurements.update(opt.step())
+    return {"params": params, "opt": opt}, measurements
+
+  return update_fn
+
+
+def check_finite(measurements):
+  """NaN/Inf abort of siglip.py:468-470 (synchronises)."""
+  for k, v in measurements.items():
+    if not torch.isfinite(torch.as_tensor(v)).all():
+      raise RuntimeError(f"measurement '{k}' is not finite: {v}")
+
+
+def get_model(config):
+  """Model registry by module path (siglip.py:190-191)."""
+  model_mod = importlib.import_module(f"big_vision_amd.models.{config.model_name}")
+  return model_mod, model_mod.Model(**config.get("model", {}))

@@ -1,0 +1,224 @@
+"""Host-side utilities mirroring the subset of big_vision/utils.py the hot path uses.
+
+Pure Python / numpy (no device code): tree naming (utils.py:616-862), regex
+masks (:1169-1212), duration -> steps (:1002-1067), learning-rate schedules
+(:1070-1143) and .npz parameter loading (:133-227).  Function names, argument
+meaning and error behaviour follow the reference.
+"""
+from __future__ import annotations
+
+import math
+import re
+from collections.abc import Mapping
+
+import numpy as np
+
+
+# ------------------------------------------------------------- tree utils ----
+def _traverse_with_names(tree, with_inner_nodes=False):
+  """Sorted-key traversal yielding ('a/b/c', leaf) — utils.py:616-641."""
+  if tree is None:
+    return
+  if isinstance(tree, Mapping):
+    for key in sorted(tree.keys()):
+      for path, v in _traverse_with_names(tree[key], with_inner_nodes):
+        yield (key + "/" + path).rstrip("/"), v
+    if with_inner_nodes:
+      yield "", tree
+  elif isinstance(tree, (list, tuple)):
+    for idx in range(len(tree)):
+      for path, v in _traverse_with_names(tree[idx], with_inner_nodes):
+        yield (str(idx) + "/" + path).rstrip("/"), v
+    if with_inner_nodes:
+      yield "", tree
+  else:
+    yield "", tree
+
+
+def tree_flatten_with_names(tree):
+  """[(name, value), ...] in sorted-name order, plus a treedef stand-in."""
+  nv = list(_traverse_with_names(tree))
+  return nv, [n for n, _ in nv]
+
+
+def recover_tree(keys, values):
+  """Unflattens '/'-joined names into nested dicts — utils.py:836-862."""
+  tree = {}
+  sub_trees = {}
+  for k, v in zip(keys, values):
+    if "/" not in k:
+      tree[k] = v
+    else:
+      k_left, k_right = k.split("/", 1)
+      sub_trees.setdefault(k_left, ([], []))
+      sub_trees[k_left][0].append(k_right)
+      sub_trees[k_left][1].append(v)
+  for k, (sk, sv) in sub_trees.items():
+    tree[k] = recover_tree(sk, sv)
+  return tree
+
+
+def tree_unflatten(names_and_vals):
+  return recover_tree(*zip(*names_and_vals))
+
+
+def tree_map_with_names(f, tree, *rest):
+  names_and_vals, _ = tree_flatten_with_names(tree)
+  rest_vals = [[v for _, v in tree_flatten_with_names(t)[0]] for t in rest]
+  out = [f(n, v, *[rv[i] for rv in rest_vals]) for i, (n, v) in enumerate(names_and_vals)]
+  return recover_tree([n for n, _ in names_and_vals], out)
+
+
+def tree_map(f, tree, *rest):
+  return tree_map_with_names(lambda _n, v, *r: f(v, *r), tree, *rest)
+
+
+def check_and_compile_patterns(patterns):
+  """utils.py:1169-1192."""
+  if isinstance(patterns, str):
+    patterns = [patterns]
+  assert isinstance(patterns, (list, tuple)), patterns
+
+  def check_and_compile(pattern):
+    assert not pattern.startswith("/"), (
+        f"Big vision parameter names never start with '/': '{pattern}")
+    return re.compile(pattern)
+
+  return list(map(check_and_compile, patterns))
+
+
+def make_mask_trees(tree, patterns, *, log=None):
+  """One boolean mask tree per pattern, only the first match counts (utils.py:1195-1212)."""
+  compiled = check_and_compile_patterns(patterns)
+
+  def matchfirst(name, _):
+    matches = []
+    for pattern in compiled:
+      matches.append(not any(matches) and bool(pattern.fullmatch(name)))
+    return np.array(matches)
+
+  multimask = tree_map_with_names(matchfirst, tree)
+  return [tree_map(lambda m, i=idx: bool(m[i]), multimask) for idx in range(len(patterns))]
+
+
+# --------------------------------------------------------------- durations ---
+def steps(prefix, config, data_size=None, batch_size=None, total_steps=None, default=ValueError):
+  """Duration `prefix` from config in steps — utils.py:1002-1067."""
+  suffixes = {"steps", "examples", "epochs", "percent"}
+  matches = {f"{prefix}_{s}" for s in suffixes
+             if (x := config.get(f"{prefix}_{s}")) is not None and x >= 0}
+  assert len(matches) <= 1, f"Only one of '{matches}' should be defined."
+  if f"{prefix}_steps" in matches:
+    return config[f"{prefix}_steps"]
+
+  def to_integer(x):
+    return max(1, round(x)) if x else 0
+
+  if batch_size and f"{prefix}_examples" in matches:
+    return to_integer(config[f"{prefix}_examples"] / batch_size)
+  if batch_size and data_size and f"{prefix}_epochs" in matches:
+    return to_integer(config[f"{prefix}_epochs"] * (data_size / batch_size))
+  if total_steps and f"{prefix}_percent" in matches:
+    pct = config[f"{prefix}_percent"]
+    assert 0.0 <= pct <= 1.0, (
+        f"Percents should lie in [0.0, 1.0], but {prefix}_percent is {pct}")
+    return to_integer(pct * total_steps)
+  if default is ValueError:
+    raise ValueError(
+        f"Cannot convert {prefix} to steps, due to missing batch_size "
+        f"({batch_size}), data_size ({data_size}), total_steps ({total_steps})"
+        ", or corresponding entry in config:\n" + "\n".join(config.keys()))
+  return default
+
+
+def create_learning_rate_schedule(total_steps, batch_size=None, data_size=None, base=1.0,
+                                  decay_type="stair", scale_with_batchsize=False, **kw):
+  """step -> learning-rate multiplier (float32-rounded) — utils.py:1070-1143."""
+
+  def to_steps(name, default=0):
+    return steps(name, kw, data_size, batch_size, total_steps, default=default)
+
+  warmup_steps = to_steps("warmup")
+  cooldown_steps = to_steps("cooldown")
+  assert (total_steps <= 1) or (warmup_steps < total_steps), "warmup_steps is >= total_steps"
+
+  def step_fn(step):
+    lr = base
+    if scale_with_batchsize:
+      lr = lr * batch_size / 256.0
+    progress = (step - warmup_steps) / float(total_steps - warmup_steps)
+    progress = min(max(progress, 0.0), 1.0)
+    if decay_type in ("linear", "polynomial"):
+      power = kw.get("power", 1)
+      zero = kw.get("end", kw.get("linear_end", 0))
+      lr = zero + (lr - zero) * (1.0 - progress) ** power
+    elif decay_type == "cosine":
+      lr = lr * 0.5 * (1.0 + math.cos(math.pi * progress))
+    elif decay_type == "rsqrt":
+      t = to_steps("timescale", default=kw.get("timescale", 10_000))
+      shift = to_steps("shift", default=kw.get("shift", 0))
+      if warmup_steps <= step:
+        lr = lr / math.sqrt(1 + (step + shift - warmup_steps) / t)
+      else:
+        lr = lr / math.sqrt(1 + shift / t)
+    elif decay_type == "stair":
+      i = int(np.searchsorted(np.array(kw.get("steps", [])), step + 1))
+      lr = lr * ([1.0] + list(kw.get("mults", [])))[i]
+    else:
+      raise ValueError(f"Unknown lr type {decay_type}")
+    if warmup_steps:
+      lr = lr * min(1.0, step / warmup_steps)
+    if cooldown_steps:
+      lr = lr * min(1.0, (total_steps - step) / cooldown_steps)
+    return float(np.float32(lr))
+
+  return step_fn
+
+
+# ---------------------------------------------------------------- npz I/O ----
+def npload(fname):
+  """Loads an .npz (or .npy) file into {name: array} — utils.py:133-151."""
+  loaded = np.load(fname, allow_pickle=False)
+  if isinstance(loaded, np.ndarray):
+    return loaded
+  out = {}
+  for k in loaded.files:
+    v = loaded[k]
+    if v.dtype.kind == "V" and v.dtype.itemsize == 2:  # bf16 stored as 2-byte void (:827-833)
+      v = (v.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+    out[k] = v
+  return out
+
+
+def load_checkpoint_np(npz, tree=None):
+  """utils.py:154-169: flat npz keys -> nested tree."""
+  if isinstance(npz, str):
+    npz = npload(npz)
+  keys, values = zip(*list(npz.items()))
+  return recover_tree(keys, values)
+
+
+def load_params(ckpt, **kw):
+  """Loads a parameter tree from `path.npz[:sub/key]` — utils.py:172-227."""
+  del kw
+  if isinstance(ckpt, str) and ":" in ckpt and not ckpt.startswith(("gs:", "http")) or \
+     isinstance(ckpt, str) and ckpt.count(":") > (1 if ckpt.startswith(("gs:", "http")) else 0):
+    ckpt, key = ckpt.rsplit(":", 1)
+  else:
+    key = None
+  params = load_checkpoint_np(ckpt) if isinstance(ckpt, str) else ckpt
+  if isinstance(params, Mapping):
+    if "params" in params:
+      params = params["params"]
+    elif "opt" in params and "target" in params["opt"]:
+      params = params["opt"]["target"]
+  if key is not None:
+    for k in key.split("/"):
+      params = params[k]
+  return params
+
+
+def save_params_npz(fname, tree):
+  names_and_vals, _ = tree_flatten_with_names(tree)
+  np.savez(fname, **{n: np.asarray(v.detach().cpu() if hasattr(v, "detach") else v)
+                     for n, v in names_and_vals})

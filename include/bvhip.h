@@ -69,6 +69,7 @@ int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void
  * + beta * C[m,n]; element (m,k) of A is A[m*sam + k*sak] etc. */
 int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                      float* C, long ldc, int M, int N, int K, float alpha, float beta,
+                     const float* log_alpha /*device, optional: alpha *= exp(*log_alpha)*/,
                      void* stream);
 
 /* ------------------------------------------------------------ LayerNorm ----
@@ -172,22 +173,24 @@ int bv_sqnorm(const float* x, long count, double* sqnorm_out, void* stream);
  * apply_updates (trainers/proj/image_text/siglip.py:312-313), over a flat fp32
  * parameter buffer of `count` elements (multiple of 1024).  Chunk c (1024
  * elements) uses hyper-parameters segs[chunk_seg[c]] (both device arrays):
- * lr_eff = lr*lr_mult, wd_eff = wd*wd_mult, sched = schedule value at this
- * step.  mu may be bf16 (mu_bf16=1, optax mu_dtype) or fp32.  gsq points at
+ * lr_eff = lr*lr_mult, wd_eff = wd*wd_mult, sched_idx selects one of the (at
+ * most BV_MAX_SCHED) per-step schedule values passed by value from the host.  mu may be bf16 (mu_bf16=1, optax mu_dtype) or fp32.  gsq points at
  * sum(g^2) over the not-frozen grads (device double); clip_norm <= 0 disables
  * clipping.  bc1 = 1-b1^k, bc2 = 1-b2^k.  Also refreshes the bf16 shadow of the
  * params (may be NULL) and accumulates stats[0] += sum p_new^2,
  * stats[1] += sum update^2 (device doubles; stats may be NULL). */
+#define BV_MAX_SCHED 8
 typedef struct {
   float lr_eff;
   float wd_eff;
-  float sched;
-  float pad_;
+  int sched_idx; /* index into the per-step schedule values `sched` (host array) */
+  int pad_;
 } bv_adam_seg;
 int bv_adam_step(float* params, const float* grads, void* mu, int mu_bf16, float* nu,
                  void* shadow_bf16, const bv_adam_seg* segs, const int* chunk_seg, long count,
-                 const double* gsq, float clip_norm, float b1, float b2, float eps, float bc1,
-                 float bc2, double* stats, void* stream);
+                 const float* sched /*host, nsched values*/, int nsched, const double* gsq,
+                 float clip_norm, float b1, float b2, float eps, float bc1, float bc2,
+                 double* stats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -375,13 +375,13 @@ def test_sqnorm_and_adam_vs_oracle(dev):
     upd = orc.update({"a": {"kernel": gk[:3072].double(), "bias": gk[3072:].double()}}, params)
     params = O.tree_map(lambda a, u: a + u, params, upd)
     sched = orc.schedule_fns[0](k)
-    segs = torch.tensor([cfg["lr"], cfg["wd"], sched, 0.0, cfg["lr"], 0.0, sched, 0.0], device=dev)
+    segs = torch.tensor([cfg["lr"], cfg["wd"], 0.0, 0.0, cfg["lr"], 0.0, 0.0, 0.0], device=dev)  # sched_idx 0
     gd = gk.to(dev)
     gsq = torch.zeros(1, device=dev, dtype=torch.float64)
     ops.sqnorm_(gd, gsq)
     assert_close(gsq.cpu()[0], (gk.double() ** 2).sum(), 1e-6, 0, "sqnorm")
     stats = torch.zeros(2, device=dev, dtype=torch.float64)
-    ops.adam_step_(p, gd, mu, nu, shadow, segs, chunk_seg, count, gsq, 1.0, 0.9, 0.999, 1e-8,
+    ops.adam_step_(p, gd, mu, nu, shadow, segs, chunk_seg, count, [sched], gsq, 1.0, 0.9, 0.999, 1e-8,
                    1 - 0.9 ** (k + 1), 1 - 0.999 ** (k + 1), stats)
     ref = torch.cat([params["a"]["kernel"], params["a"]["bias"]])
     assert_close(p.cpu(), ref, 1e-5, 1e-6, f"adam params step {k}")
