@@ -1,0 +1,224 @@
+"""Headline benchmark: image-text pairs/sec of one full SigLIP training step.
+
+Workload (BASELINE.json `metric`, SURVEY.md §8d / Appendix B "C3"): ViT-B/16@224
+image tower (MAP pooling) + 12-layer text transformer B (64 tokens, vocab 32 000),
+pairwise sigmoid loss over the GLOBAL batch 4096, Adam + clip + wd + cosine
+schedule.  One "step" = forward + backward + gradient sync + optimizer update
+on one batch of synthetic pairs already resident in HBM.  The global batch is
+fixed at 4096 for every N ("strong" scaling): each of the N ranks owns 4096/N
+pairs and processes them in micro-batches of 512 (two-pass embedding /
+recompute scheme of big_vision_amd/trainers/proj/image_text/siglip.py when
+4096/N > 512; single pass at N=8).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     : the dominant kernel (the forward-layout bf16 MFMA GEMM) timed
+                 live with HIP events on the launch stream over the timed steps;
+                 achieved = algorithmic FLOPs (2*M*N*K per launch) / event time.
+  cpu_baseline : the CPU oracle (oracle/bv_oracle.py, kind "port") running the
+                 same model's full step on a bounded sample of pairs on the
+                 host cores (rank 0, N=1 only).  Checker/baseline only — the
+                 timed product path never touches oracle/.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GLOBAL_BATCH = 4096
+MICRO = 512
+RES, SEQ, VOCAB, EMB = 224, 64, 32_000, 768
+IMAGE_CFG = dict(variant="B/16", pool_type="map")
+TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
+BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+DOMINANT = ("bv_gemm_bf16", 1, 0)   # forward-layout GEMM: A k-major, B k-minor
+DOMINANT_KERNEL = "gemm_bf16_kernel<true, false>"
+
+
+class GemmObserver:
+  """Brackets every launch of the dominant kernel with HIP events on the
+  stream it is launched on (torch's current stream)."""
+
+  def __init__(self):
+    self.recs = []
+    self.active = False
+
+  def begin(self, name, args):
+    if not self.active or name != DOMINANT[0] or (args[0], args[1]) != DOMINANT[1:]:
+      return None
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return (e0, e1, 2.0 * args[9] * args[10] * args[11])
+
+  def end(self, tok):
+    tok[1].record()
+    self.recs.append(tok)
+
+  def summary(self):
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.recs)
+    flops = sum(f for _, _, f in self.recs)
+    return len(self.recs), ms, flops
+
+
+def make_config(total_steps):
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  c = ConfigDict()
+  # Optimizer settings of the only in-repo SigLIP-trainer config
+  # (configs/proj/image_text/siglip_lit_coco.py:93-106), see SURVEY.md App. B.
+  c.optax_name = "scale_by_adam"
+  c.lr = 1e-3
+  c.wd = 1e-2
+  c.schedule = dict(decay_type="cosine", warmup_steps=max(1, total_steps // 30))
+  c.grad_clip_norm = 1.0
+  c.total_steps = total_steps
+  c.microbatch = MICRO
+  return c
+
+
+def synthetic_batch(n, dev, seed):
+  """U(-1,1) NHWC fp32 images + sticky-EOS int32 tokens, on device."""
+  g = torch.Generator(device=dev).manual_seed(seed)
+  image = torch.rand((n, RES, RES, 3), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+  text = torch.randint(2, VOCAB, (n, SEQ), generator=g, device=dev, dtype=torch.int32)
+  lens = torch.randint(4, SEQ, (n,), generator=g, device=dev)
+  pos = torch.arange(SEQ, device=dev)[None, :]
+  text = torch.where(pos >= lens[:, None], torch.ones_like(text), text)
+  return image.contiguous(), text.contiguous()
+
+
+def cpu_baseline(sample_pairs):
+  """Full SigLIP step (fwd + bwd + Adam chain) of the SAME model on the CPU oracle."""
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  import bv_oracle as O
+  cores = torch.get_num_threads()
+  params = O.init_two_towers(0, (RES, RES), SEQ, image_cfg=IMAGE_CFG, text_cfg=TEXT_CFG,
+                             out_dim=(None, EMB), temperature_init=10.0, bias_init=-10.0,
+                             dtype=torch.float32)
+  params = O.tree_map(lambda v: v.requires_grad_(True), params)
+  cfg = make_config(100).to_dict()
+  cfg.pop("microbatch")
+  tx = O.OptaxOracle(cfg, O.tree_map(lambda v: v.detach(), params),
+                     sched_kw=dict(total_steps=100, batch_size=sample_pairs))
+
+  def step(n):
+    image, text = O.synthetic_batch(1, n, RES, SEQ, VOCAB)
+    loss, _ = O.siglip_step_loss(params, image, text, image_cfg=IMAGE_CFG, text_cfg=TEXT_CFG,
+                                 out_dim=(None, EMB))
+    loss.backward()
+    grads = O.tree_map(lambda v: v.grad, params)
+    with torch.no_grad():
+      upd = tx.update(grads, O.tree_map(lambda v: v.detach(), params))
+      for (_, p), (_, du) in zip(O.tree_flatten_with_names(params), O.tree_flatten_with_names(upd)):
+        p.add_(du)
+        p.grad = None
+    return float(loss.detach())
+
+  step(2)  # page in / thread-pool warm-up
+  t0 = time.perf_counter()
+  step(sample_pairs)
+  dt = time.perf_counter() - t0
+  return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+          "sample": f"1 full step (fwd+bwd+Adam) of the same ViT-B/16+text-B model on {sample_pairs} "
+                    f"pairs, fp32 torch-CPU oracle, {dt:.1f} s"}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=4)
+  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+  ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--cpu-sample", type=int, default=32)
+  args = ap.parse_args()
+
+  from big_vision_amd import _lib, dp
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+
+  if not torch.cuda.is_available():
+    raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
+  comm = dp.init_from_env()
+  world = comm.size
+  assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+  local = int(os.environ.get("LOCAL_RANK", "0"))
+  torch.cuda.set_device(local)
+  dev = torch.device("cuda", local)
+  assert args.global_batch % world == 0
+  n = args.global_batch // world
+
+  model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, EMB),
+                           temperature_init=10.0, bias_init=-10.0)
+  total_steps = max(100, args.steps + args.warmup)
+  config = make_config(total_steps)
+  image, text = synthetic_batch(n, dev, seed=1 + comm.rank)
+  state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,
+                                     total_steps=total_steps, device=dev)
+  update_fn = siglip.make_update_fn(model, config, comm=comm)
+  batch = {"image": image, "labels": text}
+
+  obs = GemmObserver()
+  if not args.no_roofline:
+    _lib.observer = obs
+  meas = None
+  for _ in range(args.warmup):
+    state, meas = update_fn(state, None, batch)
+  comm.barrier()
+  torch.cuda.synchronize()
+  obs.active = True
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    state, meas = update_fn(state, None, batch)
+  torch.cuda.synchronize()
+  comm.barrier()
+  dt = time.perf_counter() - t0
+  obs.active = False
+  _lib.observer = None
+  t = torch.tensor([dt], device=dev, dtype=torch.float64)
+  if world > 1:
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+  dt = float(t.item())
+  loss = float(meas["training_loss"].item())
+  siglip.check_finite(meas)
+
+  if comm.rank != 0:
+    return
+  value = args.global_batch * args.steps / dt
+  line = {
+      "metric": "image-text pairs/sec training step, ViT-B/16 SigLIP bs4096",
+      "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+      "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+      "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
+                             "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
+                 "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": MICRO,
+                 "recompute": "two-pass (embeddings, then fwd+bwd per micro-batch)" if n > MICRO else "none",
+                 "parallelism": f"dp{world}", "final_loss": loss},
+  }
+  if not args.no_roofline:
+    launches, ms, flops = obs.summary()
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    line["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach,
+                        "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                        "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
+                        "share_of_step_time": ms / (1e3 * dt)}
+  if world == 1 and not args.no_cpu_baseline:
+    line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+  print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+  main()

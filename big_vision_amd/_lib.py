@@ -72,8 +72,17 @@ def load():
   return lib
 
 
+# Optional launch observer (bench.py installs one to bracket selected kernels
+# with HIP events on the launch stream); None on the normal path.
+observer = None
+
+
 def call(name, *args):
   lib = load()
+  obs = observer
+  tok = obs.begin(name, args) if obs is not None else None
   rc = getattr(lib, name)(*args)
+  if tok is not None:
+    obs.end(tok)
   if rc != 0:
     raise RuntimeError(f"{name} failed (rc={rc}): {lib.bv_last_error().decode()}")

@@ -1,0 +1,112 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes drive big_vision_amd.dp.Comm
+(the RCCL layer on GPUs) through the sharded sigmoid-loss exchange of
+trainers/proj/image_text/siglip.py ("convention A"):
+
+  all_gather(ztxt) -> local rows [n,B] with the positive diagonal at r*n+i ->
+  G with the GLOBAL 1/B -> dzimg local, dztxt partial [B,E] -> reduce_scatter
+  -> parameter-gradient all-reduce(SUM) of partial sums.
+
+The per-rank arithmetic here is plain torch-CPU (the HIP kernels need a GPU);
+what is under test is the collective choreography: its result must equal the
+oracle's single-program global-batch loss and autograd gradients
+(siglip.py:287-308) and the reference pmap convention (1/n + pmean,
+_deprecated_contrastive.py:139-141,343-344).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, n, E, out):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                    WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+  from big_vision_amd import dp
+  import bv_oracle as O
+  comm = dp.init_from_env(backend="gloo")
+  assert comm.size == world and comm.rank == rank
+  B = n * world
+  g = torch.Generator().manual_seed(0)
+  zimg_all = torch.nn.functional.normalize(torch.randn(B, E, generator=g, dtype=torch.float64), dim=1)
+  ztxt_all = torch.nn.functional.normalize(torch.randn(B, E, generator=g, dtype=torch.float64), dim=1)
+  w = torch.randn(E, generator=g, dtype=torch.float64)       # a "parameter" shared by all ranks
+  tp, b = torch.tensor([2.3], dtype=torch.float64), torch.tensor([-10.0], dtype=torch.float64)
+  zimg, ztxt = zimg_all[rank * n:(rank + 1) * n], ztxt_all[rank * n:(rank + 1) * n]
+
+  # ---- convention A with the product's collectives
+  gathered = comm.all_gather_rows(ztxt.contiguous())
+  assert torch.equal(gathered, ztxt_all), "all_gather_rows must place rank r at rows [r*n,(r+1)*n)"
+  t = torch.exp(tp)
+  S = t * (zimg * w) @ gathered.T + b                       # embeddings depend on the shared param w
+  m = -torch.ones(n, B, dtype=torch.float64)
+  m[torch.arange(n), rank * n + torch.arange(n)] = 1.0
+  loss_share = -(O.log_sigmoid(m * S)).sum() / B
+  G = -(1.0 / B) * m * torch.sigmoid(-m * S)
+  dzimg = t * G @ gathered                                    # d/d(zimg*w)
+  dztxt_partial = t * G.T @ (zimg * w)
+  dztxt = comm.reduce_scatter_rows(dztxt_partial.contiguous())
+  flat = torch.cat([(dzimg * zimg).sum(0), (G * (S - b)).sum().view(1), G.sum().view(1)])  # [dw, dt', db]
+  comm.all_reduce_sum_(flat, bucket_bytes=64)                 # several small buckets
+  loss = loss_share.view(1).clone()
+  comm.all_reduce_scalars_(loss)
+
+  # ---- oracle: single-program global loss + autograd
+  wr, tr, br = w.clone().requires_grad_(True), tp.clone().requires_grad_(True), b.clone().requires_grad_(True)
+  zt = ztxt_all.clone().requires_grad_(True)
+  ref, _ = O.siglip_loss_global(zimg_all * wr, zt, torch.exp(tr), br)
+  ref.backward()
+  assert abs(loss.item() - ref.item()) < 1e-12
+  assert torch.allclose(flat[:E], wr.grad, atol=1e-12)
+  assert abs(flat[E].item() - tr.grad.item()) < 1e-12 and abs(flat[E + 1].item() - br.grad.item()) < 1e-12
+  assert torch.allclose(dztxt, zt.grad[rank * n:(rank + 1) * n], atol=1e-12)
+
+  # ---- reference pmap convention B: local 1/n loss, then pmean == convention A
+  shards = list(ztxt_all.split(n))
+  lb = O.sigmoid_loss_per_device(zimg * w, shards, rank, t, b).view(1).clone()
+  comm.all_reduce_scalars_(lb)
+  assert abs(lb.item() / world - ref.item()) < 1e-12
+  comm.barrier()
+  out.put((rank, loss.item()))
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_sigmoid_loss_equals_global(world):
+  ctx = mp.get_context("spawn")
+  out = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, 5, 16, out)) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(180)
+    assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
+  res = dict(out.get(timeout=5) for _ in range(world))
+  assert len(res) == world and abs(res[0] - res[1]) < 1e-15
+
+
+def test_single_process_comm_is_identity():
+  sys.path.insert(0, ROOT)
+  from big_vision_amd import dp
+  c = dp.Comm()
+  x = torch.arange(6.0).view(3, 2)
+  assert c.size == 1 and c.rank == 0
+  assert c.all_gather_rows(x) is x and c.reduce_scatter_rows(x) is x
+  c.all_reduce_sum_(x); c.all_reduce_scalars_(x); c.barrier()
+  assert torch.equal(x, torch.arange(6.0).view(3, 2))

@@ -1,0 +1,143 @@
+"""Host-side logic that needs no GPU: Flax-compatible parameter naming / layout,
+regex masks, durations and schedules (the reference's known answers,
+big_vision/utils_test.py:228-281), config-driven freezing, ConfigDict."""
+import numpy as np
+import pytest
+import torch
+
+import bv_oracle as O
+from big_vision_amd import optax as bv_optax
+from big_vision_amd import utils as u
+from big_vision_amd.compat.ml_collections import ConfigDict
+from big_vision_amd.models import vit
+from big_vision_amd.models.proj.image_text import two_towers
+from big_vision_amd.params import ParamStore, make_masks
+
+IMG = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+TXT = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+
+
+def _model(**kw):
+  return two_towers.Model(image=IMG, text=TXT, out_dim=(None, 128), temperature_init=10.0,
+                          bias_init=-10.0, **kw)
+
+
+def test_param_tree_matches_flax_names_and_shapes():
+  """Leaf names/shapes == the reference's Flax tree, as restated by the oracle init."""
+  model = _model()
+  store = model.make_store((4, 32, 32, 3), (4, 16), device="cpu")
+  ours = {k: tuple(v.shape) for k, v in u.tree_flatten_with_names(store.tree())[0]}
+  ref = O.init_two_towers(0, (32, 32), 16, image_cfg=IMG, text_cfg=TXT, out_dim=(None, 128),
+                          temperature_init=10.0, bias_init=-10.0)
+  want = {k: tuple(v.shape) for k, v in O.tree_flatten_with_names(ref)}
+  assert ours == want
+  assert "img/Transformer/encoderblock_0/MultiHeadDotProductAttention_0/query/kernel" in ours
+  assert ours["img/Transformer/encoderblock_0/MultiHeadDotProductAttention_0/query/kernel"] == (128, 2, 64)
+  assert ours["img/MAPHead_0/probe"] == (1, 1, 128) and ours["t"] == (1,) and ours["b"] == (1,)
+
+
+def test_b16_variant_table():
+  """models/vit.py:284-303."""
+  assert vit.decode_variant("B/16") == dict(width=768, depth=12, mlp_dim=3072, num_heads=12, patch_size=(16, 16))
+  assert vit.decode_variant("S/16")["mlp_dim"] == 1536 and vit.decode_variant("L/16")["depth"] == 24
+  assert vit.decode_variant("mu/16")["width"] == 32 and vit.decode_variant(None) == {}
+
+
+def test_store_roundtrip_and_fused_views():
+  """load_tree(tree) -> tree() is the identity; q/k/v leaves are views of the fused tensor."""
+  model = _model()
+  store = model.make_store((4, 32, 32, 3), (4, 16), device="cpu")
+  ref = O.init_two_towers(3, (32, 32), 16, image_cfg=IMG, text_cfg=TXT, out_dim=(None, 128),
+                          temperature_init=10.0, bias_init=-10.0)
+  store.load_tree(ref)
+  back = dict(u.tree_flatten_with_names(store.tree())[0])
+  for k, v in O.tree_flatten_with_names(ref):
+    assert torch.equal(back[k], v), k
+  A = "img/Transformer/encoderblock_1/MultiHeadDotProductAttention_0"
+  fused = store.t(f"{A}/qkv/kernel")
+  assert fused.shape == (128, 3, 2, 64)
+  assert torch.equal(fused[:, 1], back[f"{A}/key/kernel"])
+  # every storage tensor starts on a 1024-element boundary (fused optimizer addressing)
+  assert all(e.offset % 1024 == 0 for e in store.entries.values())
+  with pytest.raises(ValueError):
+    store.load_tree({"img": {}}, strict=True)
+
+
+def test_frozen_towers_are_laid_out_last():
+  """config.schedule [("img/.*", None), ...] (siglip_lit_coco.py:101-104): no grads / Adam state."""
+  model = _model()
+  cfg = ConfigDict(dict(schedule=[("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=1))]))
+  names = model.leaf_names((4, 32, 32, 3), (4, 16))
+  frozen = bv_optax.frozen_leaves(cfg, names)
+  assert frozen and all(n.startswith("img/") for n in frozen)
+  store = model.make_store((4, 32, 32, 3), (4, 16), device="cpu", frozen_leaves=frozen)
+  offs = {e.name: e.offset for e in store.entries.values()}
+  assert max(o for n, o in offs.items() if not n.startswith("img/")) < \
+      min(o for n, o in offs.items() if n.startswith("img/"))
+  assert store.trainable_count < store.count
+  assert store.g("img/embedding/kernel") is None and store.g("t") is not None
+
+
+def test_make_masks_first_match_wins():
+  """utils.py:1195-1212."""
+  names = ["a/kernel", "a/bias", "b/kernel"]
+  m1, m2 = make_masks(names, ["a/.*", ".*/kernel"])
+  assert m1 == {"a/kernel": True, "a/bias": True, "b/kernel": False}
+  assert m2 == {"a/kernel": False, "a/bias": False, "b/kernel": True}
+  with pytest.raises(AssertionError):
+    make_masks(names, ["/a"])
+
+
+def test_tree_names_sorted_traversal():
+  """utils_test.py:144-225 style: '/'-joined names, sorted keys."""
+  tree = {"b": {"y": 1, "x": 2}, "a": 3}
+  names = [n for n, _ in u.tree_flatten_with_names(tree)[0]]
+  assert names == ["a", "b/x", "b/y"]
+
+
+@pytest.mark.parametrize("data_size,batch_size,total,cfg,expected", [
+    (1000, None, None, dict(foo_steps=3), 3), (1000, 100, None, dict(foo_epochs=3), 30),
+    (None, 100, None, dict(foo_examples=300), 3), (None, None, 10, dict(foo_percent=0.30), 3),
+    (None, None, 10, dict(foo_percent=0.0), 0), (1001, 100, None, dict(foo_epochs=3), 30),
+    (None, 101, None, dict(foo_examples=300), 3), (None, None, 11, dict(foo_percent=0.30), 3)])
+def test_steps_known_answers(data_size, batch_size, total, cfg, expected):
+  """big_vision/utils_test.py:228-255 on the PRODUCT's utils.steps."""
+  assert u.steps("foo", cfg, data_size=data_size, batch_size=batch_size, total_steps=total) == expected
+  with pytest.raises(ValueError):
+    u.steps("bar", cfg, data_size=data_size, batch_size=batch_size, total_steps=total)
+
+
+@pytest.mark.parametrize("decay_type,extra,step,expected", [
+    ("linear", {}, 13, .5), ("polynomial", {"end": .1, "power": 2}, 13, .325), ("cosine", {}, 13, .5),
+    ("rsqrt", {"timescale": 1}, 13, 0.3333333), ("stair", {"steps": [10], "mults": [.5]}, 5, 1.),
+    ("stair", {"steps": [10], "mults": [.5]}, 10, .5), ("rsqrt", {"timescale": 1}, 3, .6),
+    ("rsqrt", {"timescale": 1}, 20, .05)])
+def test_lr_schedule_known_answers(decay_type, extra, step, expected):
+  """big_vision/utils_test.py:258-281 on the PRODUCT's schedule factory."""
+  fn = u.create_learning_rate_schedule(total_steps=21, batch_size=512, base=.5, decay_type=decay_type,
+                                       scale_with_batchsize=True, warmup_steps=5, cooldown_steps=5, **extra)
+  assert abs(float(fn(step)) - expected) < 5e-7
+
+
+def test_error_conventions():
+  with pytest.raises(ValueError):
+    vit.Model(num_classes=None, variant="B/16", pool_type="nope")
+  with pytest.raises(ValueError):
+    vit.Model(num_classes=None, variant="B/16", posemb="nope")
+  with pytest.raises(NotImplementedError):
+    vit.Model(num_classes=None, width=96, num_heads=3)   # head_dim 32: not on the kernel path
+
+
+def test_posemb_sincos_2d_matches_oracle():
+  a = vit.posemb_sincos_2d(3, 5, 64)
+  b = O.posemb_sincos_2d(3, 5, 64).numpy()
+  assert a.shape == (1, 15, 64) and np.allclose(a, b, atol=1e-6)
+
+
+def test_configdict_surface():
+  c = ConfigDict()
+  c.lr = 1e-3
+  c.model = dict(image=dict(variant="B/16"), out_dim=(None, 768))
+  assert c.model.image.variant == "B/16" and c["model"]["out_dim"] == (None, 768)
+  assert c.get("missing", 7) == 7 and "lr" in c
+  assert c.to_dict()["model"]["image"] == {"variant": "B/16"}
