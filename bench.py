@@ -79,7 +79,8 @@ def make_config(total_steps):
   c.optax_name = "scale_by_adam"
   c.lr = 1e-3
   c.wd = 1e-2
-  c.schedule = dict(decay_type="cosine", warmup_steps=max(1, total_steps // 30))
+  # siglip_lit_coco.py:100: warmup = max(0.03 * total, 100) steps.
+  c.schedule = dict(decay_type="cosine", warmup_steps=max(100, int(0.03 * total_steps)))
   c.grad_clip_norm = 1.0
   c.total_steps = total_steps
   c.microbatch = MICRO
@@ -106,10 +107,10 @@ def cpu_baseline(sample_pairs):
                              out_dim=(None, EMB), temperature_init=10.0, bias_init=-10.0,
                              dtype=torch.float32)
   params = O.tree_map(lambda v: v.requires_grad_(True), params)
-  cfg = make_config(100).to_dict()
+  cfg = make_config(20_000).to_dict()
   cfg.pop("microbatch")
   tx = O.OptaxOracle(cfg, O.tree_map(lambda v: v.detach(), params),
-                     sched_kw=dict(total_steps=100, batch_size=sample_pairs))
+                     sched_kw=dict(total_steps=20_000, batch_size=sample_pairs))
 
   def step(n):
     image, text = O.synthetic_batch(1, n, RES, SEQ, VOCAB)
@@ -141,7 +142,7 @@ def main():
   ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
   ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events")
   ap.add_argument("--no-cpu-baseline", action="store_true")
-  ap.add_argument("--cpu-sample", type=int, default=32)
+  ap.add_argument("--cpu-sample", type=int, default=16)
   args = ap.parse_args()
 
   from big_vision_amd import _lib, dp
@@ -161,7 +162,7 @@ def main():
 
   model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, EMB),
                            temperature_init=10.0, bias_init=-10.0)
-  total_steps = max(100, args.steps + args.warmup)
+  total_steps = max(20_000, args.steps + args.warmup)
   config = make_config(total_steps)
   image, text = synthetic_batch(n, dev, seed=1 + comm.rank)
   state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,

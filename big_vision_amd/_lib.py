@@ -7,6 +7,11 @@ fails, a RuntimeError is raised.  Build it with `python big_vision_amd/build.py`
 import ctypes
 import os
 
+# torch bundles its own libamdhip64; it must be loaded BEFORE libbvhip.so so both
+# share ONE HIP runtime (otherwise libbvhip binds /opt/rocm's copy and launches
+# fail with "no ROCm-capable device").
+import torch  # noqa: F401  pylint: disable=unused-import
+
 from ctypes import c_int, c_long, c_float, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -19,6 +24,7 @@ PROTOTYPES = {
     "bv_version": [],
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
                      c_int, P, P, c_long, c_int, P, c_float, c_int, P],
+    "bv_gemm_fast_path": [c_int],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
@@ -33,6 +39,7 @@ PROTOTYPES = {
     "bv_colsum": [P, c_int, c_long, P, c_int, c_int, P],
     "bv_batchsum": [P, P, c_int, c_int, c_int, P],
     "bv_cast_bf16": [P, P, c_long, P],
+    "bv_transpose_bf16": [P, P, c_int, c_int, c_long, c_long, P],
     "bv_concat_cls": [P, P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_fwd": [P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_bwd": [P, P, c_int, c_int, c_int, P],

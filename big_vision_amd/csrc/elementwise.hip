@@ -271,7 +271,43 @@ inline int grid_for(long work_items, int per_block, int cap) {
   return (int)g;
 }
 
+// ----------------------------------------------------------- transpose -----
+// dst[c][r] = src[r][c], bf16, 64x64 tiles through LDS ([64][66] halfwords:
+// the odd word pitch makes the column reads conflict-free).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ src,
+                                                             uint16_t* __restrict__ dst, int rows,
+                                                             int cols, long lds, long ldd) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = src[(long)(r0 + r) * lds + c0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    if (c0 + c < cols && r0 + tx < rows) dst[(long)(c0 + c) * ldd + r0 + tx] = tile[tx][c];
+  }
+}
+
 }  // namespace
+
+// bf16 transpose: dst[cols][rows] = src[rows][cols]^T (row strides lds / ldd
+// elements).  Keeps the [out][in] image of the Flax (in,out) kernels that the
+// forward projections (models/vit.py:72,77,93-98) consume on the k-major GEMM path.
+extern "C" int bv_transpose_bf16(const void* src, void* dst, int rows, int cols, long lds, long ldd,
+                                 void* stream) {
+  BV_REQUIRE(rows > 0 && cols > 0 && lds >= cols && ldd >= rows,
+             "bv_transpose_bf16: bad shape rows=%d cols=%d lds=%ld ldd=%ld", rows, cols, lds, ldd);
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  BV_REQUIRE(grid.y <= 65535, "bv_transpose_bf16: too many rows");
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, (uint16_t*)dst, rows, cols, lds, ldd);
+  return bv_check_launch("bv_transpose_bf16");
+}
 
 // models/vit.py:212-217 — im2col of the stride-P VALID patch conv.
 extern "C" int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream) {

@@ -1,0 +1,470 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950 (MI355X): 8 waves, direct-to-LDS loads,
+// ping-pong wave groups.  The fast path behind bv_gemm_bf16 for the large
+// transformer projections (reference call sites: big_vision/models/vit.py:72,77,
+// 93-98 and their backward transposes, trainers/proj/image_text/siglip.py:311).
+//
+//   KM = true  ("NT"): A [M][K] and B [N][K], reduction dim contiguous.
+//        forward  Y = X W    with W^T taken from the transposed bf16 weight shadow
+//        dX = dY W^T         with W in its natural Flax (in,out) layout
+//   KM = false ("TN"): A [K][M] and B [K][N], reduction dim is the slow axis.
+//        dW = X^T dY (split-K, fp32 atomics into the flat gradient buffer)
+//
+// Structure (one workgroup = one 256x256 C tile, 512 threads = 8 waves as 2(M) x 4(N),
+// each wave owns 128x64 = acc[8][4] fragments of v_mfma_f32_16x16x32_bf16):
+//   * operands are staged by global_load_lds_dwordx4 (no VGPR round trip) in
+//     16 KiB half-tiles (128 rows x 64 k); A ring = 2 K-tiles, B ring = 3 K-tiles
+//     -> 160 KiB LDS, one workgroup per CU;
+//   * a K-tile is consumed in 4 phases (one 64x32 quadrant of the wave's C tile
+//     x K=64 = 16 MFMAs each).  Every phase = {LDS fragment reads + ONE half-tile
+//     of global->LDS loads} barrier {16 MFMAs} barrier.  Waves 4-7 run one
+//     barrier behind waves 0-3, so on every SIMD one wave issues MFMAs while its
+//     partner issues LDS reads / loads (the matrix pipe never waits for memory);
+//   * loads run 6 half-tiles ahead of the math; the only VMEM wait is one counted
+//     s_waitcnt vmcnt(4) per K-tile (never 0 in steady state);
+//   * LDS images are written lane-linearly by the DMA, so the bank-conflict
+//     swizzle is applied to the per-lane GLOBAL source address and again on the
+//     fragment read (same involution on both sides).
+//
+// LDS images.  KM: half-tile = [128 rows][8 x 16 B]; position p of row r holds
+// global k-chunk p ^ f(r); fA(r) = (r>>1)&7, fB(r) = ((r>>4)&3)<<1 | (r>>1)&1 —
+// both make every ds_read_b128 lane group hit 16 distinct 16-B bank slots.
+// B fragment j of a wave maps lane-row c to column (c>>2)*16 + j*4 + (c&3), so a
+// lane ends up with 16 CONTIGUOUS output columns per row (32/64-byte stores).
+// !KM: half-tile = [64 k][128 rows] in natural order (256 B per k-row); 32-B slot q
+// of k-row k lives at slot q ^ swzk(k); fragments come out of ds_read_b64_tr_b16.
+#include "bv_common.h"
+#include "bvhip_internal.h"
+
+namespace {
+
+constexpr int HALF = 16384;                // one half-tile, bytes
+constexpr int A_STAGES = 2, B_STAGES = 3;
+constexpr int A_BYTES = A_STAGES * 2 * HALF;
+constexpr int SMEM = (A_STAGES + B_STAGES) * 2 * HALF;  // 163840 = all of the CU's LDS
+
+struct G256Params {
+  const bf16* A;
+  const bf16* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const void* aux;
+  long lda, ldb, ldc, ldaux;
+  int M, N, K;
+  int aux_rows;
+  int tiles_n;
+  int ntiles;          // tiles_m * tiles_n
+  int ktiles_per_split;
+  int epi;
+  int out_f32;
+  float alpha;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gl_void;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ int swzk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- LDS reads: inline asm so the compiler attaches no implicit vmcnt/lgkmcnt
+// waits to them (it would drain the in-flight DMA before every read); every
+// consumer is fenced by an explicit s_waitcnt lgkmcnt(0) + sched_barrier.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr64(uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+__device__ __forceinline__ void glds16(const bf16* src, char* dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst_wave_base, 16, 0, 0);
+}
+
+template <bool KM>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a
+  // contiguous range of tile ids (n fastest) so co-resident blocks share A panels.
+  const int bid = blockIdx.x;
+  const int nwg = p.ntiles;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int nk_all = p.K >> 6;
+  const int nk = min(p.ktiles_per_split, nk_all - kt0);
+
+  // ---- per-lane global source pointers of the DMA (half 0, piece g = 0, K-tile kt0)
+  const bf16* srcA;
+  const bf16* srcB;
+  long stepA, stepB;      // advance per K-tile
+  long gA, gB;            // offset of piece g = 1
+  long hA, hB;            // offset of half 1
+  if constexpr (KM) {
+    const int r = wave * 8 + (lane >> 3);           // row within the half-tile (g = 0)
+    const int pos = lane & 7;
+    const int cA = pos ^ ((r >> 1) & 7);
+    const int cB = pos ^ ((((r >> 4) & 3) << 1) | ((r >> 1) & 1));
+    srcA = p.A + (long)(m0 + r) * p.lda + (long)kt0 * 64 + cA * 8;
+    srcB = p.B + (long)(n0 + r) * p.ldb + (long)kt0 * 64 + cB * 8;
+    stepA = 64; stepB = 64;
+    gA = 64 * p.lda; gB = 64 * p.ldb;
+    hA = 128 * p.lda; hB = 128 * p.ldb;
+  } else {
+    const int k = wave * 4 + (lane >> 4);           // k-row within the tile (g = 0)
+    const int piece = lane & 15;
+    const int qs = (piece >> 1) ^ swzk(k);
+    const int off = qs * 16 + (piece & 1) * 8;
+    srcA = p.A + (long)(kt0 * 64 + k) * p.lda + m0 + off;
+    srcB = p.B + (long)(kt0 * 64 + k) * p.ldb + n0 + off;
+    stepA = 64 * p.lda; stepB = 64 * p.ldb;
+    gA = 32 * p.lda; gB = 32 * p.ldb;
+    hA = 128; hB = 128;
+  }
+  char* const ldsA = smem;
+  char* const ldsB = smem + A_BYTES;
+  const int wave_off = wave * 1024;
+
+  // issue one half-tile (2 DMA instructions per thread)
+  auto issueA = [&](int t, int h) {
+    char* d = ldsA + ((t & 1) * 2 + h) * HALF + wave_off;
+    const bf16* s = srcA + (long)t * stepA + (h ? hA : 0);
+    glds16(s, d);
+    glds16(s + gA, d + 8192);
+  };
+  auto issueB = [&](int t, int bs, int h) {
+    char* d = ldsB + (bs * 2 + h) * HALF + wave_off;
+    const bf16* s = srcB + (long)t * stepB + (h ? hB : 0);
+    glds16(s, d);
+    glds16(s + gB, d + 8192);
+  };
+
+  // ---- per-lane LDS read addresses (relative to the stage base)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t ra0, ra1, rb0, rb1;   // A/B fragment base for k-step 0 / 1 (KM) or ka/kb rows (!KM)
+  if constexpr (KM) {
+    const int swA = (lr >> 1) & 7;
+    const int swB = ((lr >> 2) << 1) | ((lr >> 1) & 1);
+    ra0 = lds0 + wr * HALF + lr * 128 + ((lg ^ swA) << 4);
+    ra1 = ra0 ^ 64;
+    rb0 = lds0 + A_BYTES + (wc >> 1) * HALF + ((wc & 1) * 64 + (lr >> 2) * 16 + (lr & 3)) * 128 +
+          ((lg ^ swB) << 4);
+    rb1 = rb0 ^ 64;
+  } else {
+    // tr read: lane supplies the 8-byte chunk [k = lg*8 + (lr>>2) (+4)][rows 4*(lr&3)..+3]
+    const int ka = lg * 8 + (lr >> 2), kb = ka + 4;
+    ra0 = lds0 + wr * HALF + ka * 256 + ((lr & 3) << 3);
+    ra1 = lds0 + wr * HALF + kb * 256 + ((lr & 3) << 3);
+    rb0 = lds0 + A_BYTES + (wc >> 1) * HALF + ka * 256 + ((lr & 3) << 3);
+    rb1 = lds0 + A_BYTES + (wc >> 1) * HALF + kb * 256 + ((lr & 3) << 3);
+  }
+  // !KM: 32-B slot swizzle depends on the k-row: slot (rb ^ swzk(k)); k-step ks adds 32 to k
+  // (swzk unchanged), so the per-lane xor masks are constants:
+  const int xka = KM ? 0 : swzk(lg * 8 + (lr >> 2));
+  const int xkb = KM ? 0 : swzk(lg * 8 + (lr >> 2) + 4);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bfg[4][2];
+
+  // A fragments of 64-row sub-tile `sub` (4 frags x 2 k-steps) of stage base `sa`
+  auto readA = [&](uint32_t sa, int sub) {
+    if constexpr (KM) {
+      const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
+      if (sub == 0) {
+        af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
+        af[1][0] = lds_read128<2048>(a0);  af[1][1] = lds_read128<2048>(a1);
+        af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
+        af[3][0] = lds_read128<6144>(a0);  af[3][1] = lds_read128<6144>(a1);
+      } else {
+        af[0][0] = lds_read128<8192>(a0);  af[0][1] = lds_read128<8192>(a1);
+        af[1][0] = lds_read128<10240>(a0); af[1][1] = lds_read128<10240>(a1);
+        af[2][0] = lds_read128<12288>(a0); af[2][1] = lds_read128<12288>(a1);
+        af[3][0] = lds_read128<14336>(a0); af[3][1] = lds_read128<14336>(a1);
+      }
+    } else {
+      // 16-row block rb = sub*4 + i lives at 32-B slot rb ^ swzk(k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rbk = sub * 4 + i;
+        const uint32_t pa = ra0 + sa + ((rbk ^ xka) << 5);
+        const uint32_t pb = ra1 + sa + ((rbk ^ xkb) << 5);
+        const s16x4 x0 = lds_read_tr64<0>(pa), y0 = lds_read_tr64<0>(pb);
+        const s16x4 x1 = lds_read_tr64<8192>(pa), y1 = lds_read_tr64<8192>(pb);
+        af[i][0] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(x0, y0, 0, 1, 2, 3, 4, 5, 6, 7));
+        af[i][1] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(x1, y1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    }
+  };
+  // B fragments j = 2*sub, 2*sub+1 (2 frags x 2 k-steps) of stage base `sb`
+  auto readB = [&](uint32_t sb, int sub) {
+    if constexpr (KM) {
+      const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
+      if (sub == 0) {
+        bfg[0][0] = lds_read128<0>(b0);    bfg[0][1] = lds_read128<0>(b1);
+        bfg[1][0] = lds_read128<512>(b0);  bfg[1][1] = lds_read128<512>(b1);
+      } else {
+        bfg[2][0] = lds_read128<1024>(b0); bfg[2][1] = lds_read128<1024>(b1);
+        bfg[3][0] = lds_read128<1536>(b0); bfg[3][1] = lds_read128<1536>(b1);
+      }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = sub * 2 + jj;
+        const int rbk = (wc & 1) * 4 + j;
+        const uint32_t pa = rb0 + sb + ((rbk ^ xka) << 5);
+        const uint32_t pb = rb1 + sb + ((rbk ^ xkb) << 5);
+        const s16x4 x0 = lds_read_tr64<0>(pa), y0 = lds_read_tr64<0>(pb);
+        const s16x4 x1 = lds_read_tr64<8192>(pa), y1 = lds_read_tr64<8192>(pb);
+        const bf16x8 f0 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(x0, y0, 0, 1, 2, 3, 4, 5, 6, 7));
+        const bf16x8 f1 = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(x1, y1, 0, 1, 2, 3, 4, 5, 6, 7));
+        if (sub == 0) { bfg[jj][0] = f0; bfg[jj][1] = f1; }
+        else { bfg[2 + jj][0] = f0; bfg[2 + jj][1] = f1; }
+      }
+    }
+  };
+
+#define BV_MFMA_QUAD(I0, J0)                                                                   \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+          acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+              bfg[(J0) + j][ks], af[i][ks], acc[(I0) + i][(J0) + j], 0, 0, 0);                 \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+
+#define BV_MID()                                          \
+  do {                                                    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+#define BV_END()                             \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+  } while (0)
+
+  // ---- prologue: B(0), A(0), B(1) in flight; tile 0 must have landed.
+  issueB(0, 0, 0); issueB(0, 0, 1);
+  issueA(0, 0); issueA(0, 1);
+  if (nk > 1) {
+    issueB(1, 1, 0); issueB(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+
+  int bs = 0;  // B ring slot of the current tile
+  for (int t = 0; t < nk; ++t) {
+    const uint32_t sa = (t & 1) * 2 * HALF;
+    const uint32_t sb = bs * 2 * HALF;
+    const int bs1 = (bs == 2) ? 0 : bs + 1;          // slot of tile t+1
+    const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of tile t+2
+    // -------- phase 0: quadrant (0,0)
+    readA(sa, 0);
+    readB(sb, 0);
+    if (t + 1 < nk) issueA(t + 1, 0);
+    BV_MID();
+    BV_MFMA_QUAD(0, 0);
+    BV_END();
+    // -------- phase 1: quadrant (0,1)
+    readB(sb, 1);
+    if (t + 1 < nk) issueA(t + 1, 1);
+    BV_MID();
+    BV_MFMA_QUAD(0, 2);
+    BV_END();
+    // -------- phase 2: quadrant (1,1)
+    readA(sa, 1);
+    if (t + 2 < nk) issueB(t + 2, bs2, 0);
+    BV_MID();
+    BV_MFMA_QUAD(4, 2);
+    BV_END();
+    // -------- phase 3: quadrant (1,0); retire tile t+1's loads for the next iteration
+    if (t + 2 < nk) {
+      issueB(t + 2, bs2, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BV_MID();
+    BV_MFMA_QUAD(4, 0);
+    BV_END();
+    bs = bs1;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
+#undef BV_MFMA_QUAD
+#undef BV_MID
+#undef BV_END
+
+  // ---- epilogue
+  const int epi = p.epi;
+  if constexpr (KM) {
+    // lane holds C[m][n .. n+15], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + lg*16 (+ j*4 + r)
+    const int nb = n0 + wc * 64 + lg * 16;
+    float bv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[e] = 0.f;
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + j * 4);
+        bv[j * 4 + 0] = b.x; bv[j * 4 + 1] = b.y; bv[j * 4 + 2] = b.z; bv[j * 4 + 3] = b.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + lr;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha + bv[j * 4 + r];
+      if (epi == BV_EPI_RESIDUAL || epi == BV_EPI_POS) {
+        const long arow = (epi == BV_EPI_POS) ? (long)(m % p.aux_rows) : (long)m;
+        const float* x = reinterpret_cast<const float*>(p.aux) + arow * p.ldaux + nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 a = *reinterpret_cast<const float4*>(x + j * 4);
+          v[j * 4 + 0] += a.x; v[j * 4 + 1] += a.y; v[j * 4 + 2] += a.z; v[j * 4 + 3] += a.w;
+        }
+      } else if (epi == BV_EPI_GELU_BWD) {
+        const uint4* h = reinterpret_cast<const uint4*>(
+            reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + nb);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const uint4 u = h[hh];
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[hh * 8 + e * 2 + 0] *= gelu_tanh_grad_f(bflo(w[e]));
+            v[hh * 8 + e * 2 + 1] *= gelu_tanh_grad_f(bfhi(w[e]));
+          }
+        }
+      }
+      if (p.out_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(c + j * 4) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
+      } else {
+        bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + nb;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          uint4 o;
+          o.x = pack_bf2(v[hh * 8 + 0], v[hh * 8 + 1]);
+          o.y = pack_bf2(v[hh * 8 + 2], v[hh * 8 + 3]);
+          o.z = pack_bf2(v[hh * 8 + 4], v[hh * 8 + 5]);
+          o.w = pack_bf2(v[hh * 8 + 6], v[hh * 8 + 7]);
+          *reinterpret_cast<uint4*>(c + hh * 8) = o;
+        }
+        if (epi == BV_EPI_GELU) {
+          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + nb;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            uint4 o;
+            o.x = pack_bf2(gelu_tanh_f(v[hh * 8 + 0]), gelu_tanh_f(v[hh * 8 + 1]));
+            o.y = pack_bf2(gelu_tanh_f(v[hh * 8 + 2]), gelu_tanh_f(v[hh * 8 + 3]));
+            o.z = pack_bf2(gelu_tanh_f(v[hh * 8 + 4]), gelu_tanh_f(v[hh * 8 + 5]));
+            o.w = pack_bf2(gelu_tanh_f(v[hh * 8 + 6]), gelu_tanh_f(v[hh * 8 + 7]));
+            *reinterpret_cast<uint4*>(c2 + hh * 8) = o;
+          }
+        }
+      }
+    }
+  } else {
+    // TN (dW): lane holds C[m][n .. n+3], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + j*16 + lg*4;
+    // fp32 output, accumulated with atomics (split-K and += into the gradient buffer).
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + lg * 4;
+        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+        if (epi == BV_EPI_ATOMIC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r] * p.alpha);
+        } else {
+          *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha,
+                                                      acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Internal entry used by bv_gemm_bf16 (gemm_bf16.hip).  Returns 1 if the problem
+// was launched on the 256x256 path, 0 if it does not qualify (caller falls back).
+int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
+                   void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
+                   const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
+                   float alpha, int split_k, void* stream) {
+  if (a_kmajor != b_kmajor) return 0;
+  if ((M & 255) || (N & 255) || (K & 63)) return 0;
+  const bool km = a_kmajor != 0;
+  if (km && epilogue == BV_EPI_ATOMIC) return 0;
+  if (!km && !(epilogue == BV_EPI_ATOMIC || (epilogue == BV_EPI_NONE && out_f32 && !bias))) return 0;
+  if ((lda & 7) || (ldb & 7) || (ldc & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) ||
+      ((uintptr_t)C & 15))
+    return 0;
+  if (aux && ((ldaux & 7) || ((uintptr_t)aux & 15))) return 0;
+  if (bias && ((uintptr_t)bias & 15)) return 0;
+  if (C2 && ((uintptr_t)C2 & 15)) return 0;
+
+  G256Params p;
+  p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.C2 = C2;
+  p.bias = bias; p.aux = aux;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
+  p.M = M; p.N = N; p.K = K; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
+  p.epi = epilogue; p.out_f32 = out_f32; p.alpha = alpha;
+  const int tiles_m = M >> 8;
+  p.tiles_n = N >> 8;
+  p.ntiles = tiles_m * p.tiles_n;
+  const int nk = K >> 6;
+  int splits = 1;
+  if (epilogue == BV_EPI_ATOMIC) {
+    if (split_k > 0) {
+      splits = split_k;
+    } else {
+      splits = (2 * 256) / p.ntiles;          // ~2 rounds of one workgroup per CU
+      const int max_splits = nk / 8 > 0 ? nk / 8 : 1;
+      if (splits > max_splits) splits = max_splits;
+    }
+    if (splits < 1) splits = 1;
+    if (splits > nk) splits = nk;
+  }
+  p.ktiles_per_split = (nk + splits - 1) / splits;
+  splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  if (splits > 65535) return 0;
+  dim3 grid(p.ntiles, splits), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  if (km) hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
+  return 1;
+}

@@ -257,6 +257,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 
 }  // namespace
 
+// gemm256.hip
+int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
+                   void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
+                   const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
+                   float alpha, int split_k, void* stream);
+static int g_fast_path = 1;
+extern "C" int bv_gemm_fast_path(int enable) {
+  const int old = g_fast_path;
+  if (enable >= 0) g_fast_path = enable != 0;
+  return old;
+}
+
 // See include/bvhip.h for the contract.
 extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
                             long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
@@ -279,6 +291,10 @@ extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda,
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
+
+  if (g_fast_path && bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K,
+                                     epilogue, bias, aux, ldaux, aux_rows, C2, alpha, split_k, stream))
+    return bv_check_launch("bv_gemm_bf16(256x256)");
 
   GemmParams p;
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.C2 = C2;

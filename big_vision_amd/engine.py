@@ -139,10 +139,22 @@ class _W:
       sh, ma = sh.view(shape2d), ma.view(shape2d)
       g = g.view(shape2d) if g is not None else None
     self.bf, self.f32, self.grad = sh, ma, g
+    self.store = store
+    self._t, self._t_ver = None, -1
+
+  def bf_t(self):
+    """[out][in] bf16 image of a 2-D (in,out) kernel, re-transposed only when the
+    shadow changed (once per optimizer step): lets the forward projections run
+    on the k-major ("NT") GEMM path."""
+    ver = self.store.shadow_version
+    if self._t_ver != ver:
+      self._t = ops.transpose_bf16(self.bf, self._t)
+      self._t_ver = ver
+    return self._t
 
 
 def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
-  return ops.gemm(x_bf, w.bf, a_kmajor=True, b_kmajor=False, bias=None if b is None else b.f32, **kw)
+  return ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=None if b is None else b.f32, **kw)
 
 
 def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):

@@ -188,6 +188,18 @@ def cast_bf16(x, out=None):
   return out
 
 
+def transpose_bf16(x, out=None):
+  """out[c][r] = x[r][c] (bf16, 2-D, contiguous rows)."""
+  _chk(x, BF16, "transpose.x")
+  lds = _rowmajor2d(x, "transpose.x")
+  rows, cols = x.shape
+  if out is None:
+    out = torch.empty((cols, rows), device=x.device, dtype=BF16)
+  ldd = _rowmajor2d(out, "transpose.out")
+  _lib.call("bv_transpose_bf16", _p(x), _p(out), rows, cols, lds, ldd, _stream())
+  return out
+
+
 def concat_cls(cls, x, n, L, D):
   y = torch.empty((n * (L + 1), D), device=x.device, dtype=F32)
   _lib.call("bv_concat_cls", _p(cls), _p(x), _p(y), n, L, D, _stream())

@@ -172,6 +172,7 @@ class Optimizer:
                    sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
                    1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
     self.count = k + 1
+    st.shadow_version += 1     # the kernel refreshed the bf16 shadow of the trainable prefix
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}

@@ -107,6 +107,7 @@ class ParamStore:
       for leaf, sl in e.flax_leaves():
         self.leaf_index[leaf] = (e.name, sl)
     self._shadow_dirty = True
+    self.shadow_version = 0   # bumped whenever the bf16 shadow changes (cast / optimizer step)
 
   # ------------------------------------------------------------ accessors --
   def _buf(self, buf):
@@ -185,6 +186,7 @@ class ParamStore:
       from big_vision_amd import ops
       ops.cast_bf16(self.master, self.shadow)
       self._shadow_dirty = False
+      self.shadow_version += 1
 
   def mark_dirty(self):
     self._shadow_dirty = True

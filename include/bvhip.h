@@ -63,6 +63,12 @@ int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                  float alpha, int split_k /*0 = auto*/, void* stream);
 
+/* Dispatch control (diagnostics / A-B benchmarking): problems with M,N multiples
+ * of 256, K a multiple of 64 and both operands in the same layout run on the
+ * 256x256x64 direct-to-LDS kernel; everything else on the general 128x128x64
+ * kernel.  enable = 0/1 sets the switch, -1 only queries; returns the old value. */
+int bv_gemm_fast_path(int enable);
+
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,
  * trainers/proj/image_text/siglip.py:291).  C[m,n] = alpha * sum_k A(m,k) B(k,n)
@@ -129,6 +135,11 @@ int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int c
 int bv_batchsum(const float* x, float* out, int n, int L, int D, void* stream);
 /* fp32 -> bf16 cast of a flat buffer (bf16 weight shadows). */
 int bv_cast_bf16(const float* x, void* y, long count, void* stream);
+/* dst[cols][rows] = src[rows][cols]^T, bf16 (row strides in elements): the
+ * [out][in] image of a Flax (in,out) kernel, consumed by the forward
+ * projections (models/vit.py:72,77,93-98) on the k-major GEMM path. */
+int bv_transpose_bf16(const void* src, void* dst, int rows, int cols, long lds, long ldd,
+                      void* stream);
 /* y[i][0] = cls, y[i][1+l] = x[i][l] (cls-token concat, models/vit.py:223-225), fp32. */
 int bv_concat_cls(const float* cls, const float* x, float* y, int n, int L, int D, void* stream);
 

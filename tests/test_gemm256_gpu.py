@@ -1,0 +1,142 @@
+"""Parity + race screen for the 256x256x64 direct-to-LDS GEMM path (gemm256.hip),
+reached through bv_gemm_bf16 when M,N % 256 == 0, K % 64 == 0 and both operands
+share a layout.  Reference = fp32 matmul on the same bf16-rounded inputs (the
+only differences are accumulation order and output rounding).  Each case is
+launched several times back-to-back and must be bit-identical run to run (a
+staging race shows up as run-to-run differences) and match the general
+128x128 kernel to accumulation-order noise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=F32):
+  g = torch.Generator(device="cpu").manual_seed(seed)
+  return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dev).to(dtype)
+
+
+def close(a, b, rtol, atol, name):
+  a = a.double(); b = b.double()
+  err = (a - b).abs()
+  bad = err > atol + rtol * b.abs()
+  assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} bad, max err {err.max().item():.3e}"
+
+
+@pytest.fixture()
+def fast(dev):
+  from big_vision_amd import _lib
+  _lib.call("bv_gemm_fast_path", 1)
+  yield
+  _lib.call("bv_gemm_fast_path", 1)
+
+
+def _general(fn):
+  from big_vision_amd import _lib
+  _lib.load().bv_gemm_fast_path(0)
+  try:
+    return fn()
+  finally:
+    _lib.load().bv_gemm_fast_path(1)
+
+
+NT_SHAPES = [(256, 256, 64), (256, 256, 128), (512, 768, 768), (1024, 2304, 768), (768, 768, 3072),
+             (2048, 3072, 768), (256, 512, 192)]
+
+
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_nt_matches_reference(dev, fast, M, N, K):
+  """dX layout: A [M][K], B [N][K] (asymmetric operands catch transposes)."""
+  from big_vision_amd import ops
+  a = rnd((M, K), dev, 1, dtype=BF16)
+  b = rnd((N, K), dev, 2, 0.05, dtype=BF16)
+  bias = rnd((N,), dev, 3)
+  ref = a.float() @ b.float().T + bias
+  outs = [ops.gemm(a, b, a_kmajor=True, b_kmajor=True, bias=bias, out_dtype=F32) for _ in range(4)]
+  close(outs[0], ref, 1e-4, 2e-3, "nt f32")
+  for o in outs[1:]:
+    assert torch.equal(o, outs[0]), "run-to-run difference (staging race?)"
+  gen = _general(lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, bias=bias, out_dtype=F32))
+  close(outs[0], gen, 1e-5, 1e-3, "nt vs general kernel")
+  o16 = ops.gemm(a, b, a_kmajor=True, b_kmajor=True, bias=bias, out_dtype=BF16)
+  close(o16, ref, 1e-2, 1e-2, "nt bf16")
+
+
+def test_nt_epilogues(dev, fast):
+  from big_vision_amd import ops
+  M, N, K, L = 784 * 0 + 512, 512, 256, 128
+  x = rnd((M, K), dev, 8, dtype=BF16)
+  w = rnd((N, K), dev, 9, 0.1, dtype=BF16)
+  b = rnd((N,), dev, 10)
+  pre = x.float() @ w.float().T + b
+  res = rnd((M, N), dev, 11)
+  kw = dict(a_kmajor=True, b_kmajor=True)
+  y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
+  close(y, pre + res, 1e-4, 2e-3, "residual")
+  pos = rnd((L, N), dev, 12)
+  y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L, **kw)
+  close(y, pre + pos.repeat(M // L, 1), 1e-4, 2e-3, "pos")
+  g = torch.empty((M, N), device=dev, dtype=BF16)
+  h = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g, **kw)
+  close(h, pre, 1e-2, 1e-2, "gelu pre")
+  close(g, torch.nn.functional.gelu(pre, approximate="tanh"), 1e-2, 1e-2, "gelu out")
+  hh = rnd((M, N), dev, 15, dtype=BF16)
+  hf = hh.float().requires_grad_(True)
+  torch.nn.functional.gelu(hf, approximate="tanh").sum().backward()
+  ref = (x.float() @ w.float().T) * hf.grad
+  out = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=hh, **kw)
+  close(out, ref, 1e-2, 2e-2, "gelu bwd")
+  y = ops.gemm(x, w, out_dtype=BF16, alpha=0.5, **kw)
+  close(y, 0.5 * (x.float() @ w.float().T), 1e-2, 1e-2, "alpha")
+
+
+def test_nt_strided_views(dev, fast):
+  """Operands / outputs that are column slices of wider buffers (lda/ldb/ldc > width)."""
+  from big_vision_amd import ops
+  M, N, K = 512, 256, 128
+  abuf = rnd((M, 3 * K), dev, 1, dtype=BF16)
+  bbuf = rnd((N, 2 * K), dev, 2, dtype=BF16)
+  cbuf = torch.zeros((M, 2 * N), device=dev, dtype=F32)
+  a, b = abuf[:, K:2 * K], bbuf[:, K:]
+  ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out=cbuf[:, N:])
+  close(cbuf[:, N:], a.float() @ b.float().T, 1e-4, 2e-3, "strided")
+  assert torch.count_nonzero(cbuf[:, :N]) == 0
+
+
+TN_SHAPES = [(256, 256, 64, 1), (256, 256, 1024, 0), (768, 768, 4096, 0), (768, 2304, 6272, 0),
+             (3072, 768, 2048, 3), (256, 512, 320, 5)]
+
+
+@pytest.mark.parametrize("Din,Dout,T,split", TN_SHAPES)
+def test_tn_dw_matches_reference(dev, fast, Din, Dout, T, split):
+  """dW += X^T dY: both operands k-minor, split-K fp32 atomics, accumulating."""
+  from big_vision_amd import ops
+  x = rnd((T, Din), dev, 5, dtype=BF16)
+  dy = rnd((T, Dout), dev, 6, 0.25, dtype=BF16)
+  base = rnd((Din, Dout), dev, 7)
+  ref = base.double() + x.double().T @ dy.double()
+  tol = 2e-5 * (T ** 0.5) * 4
+  for _ in range(3):
+    out = base.clone()
+    ops.gemm(x, dy, a_kmajor=False, b_kmajor=False, out=out, epilogue=ops.EPI_ATOMIC, split_k=split)
+    close(out, ref, 1e-4, tol, "tn dw")
+  out1 = torch.zeros((Din, Dout), device=dev)
+  ops.gemm(x, dy, a_kmajor=False, b_kmajor=False, out=out1, epilogue=ops.EPI_ATOMIC, split_k=1)
+  out2 = torch.zeros((Din, Dout), device=dev)
+  ops.gemm(x, dy, a_kmajor=False, b_kmajor=False, out=out2, epilogue=ops.EPI_ATOMIC, split_k=1)
+  assert torch.equal(out1, out2), "split_k=1 must be deterministic (staging race?)"
+
+
+def test_big_shape_spot_check(dev, fast):
+  """ViT-B/16 fc1 at n=64 (T=12544): row subset against fp64."""
+  from big_vision_amd import ops
+  T, D, Mlp = 12544, 768, 3072
+  x = rnd((T, D), dev, 21, dtype=BF16)
+  wt = rnd((Mlp, D), dev, 22, 0.03, dtype=BF16)
+  y = ops.gemm(x, wt, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+  rows = torch.arange(0, T, 97, device=dev)
+  ref = x[rows].double() @ wt.double().T
+  close(y[rows], ref, 1e-4, 2e-3, "fc1 rows")
+  y2 = ops.gemm(x, wt, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+  assert torch.equal(y, y2)

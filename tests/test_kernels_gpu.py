@@ -389,3 +389,13 @@ def test_sqnorm_and_adam_vs_oracle(dev):
     assert_close(stats.cpu()[0], (ref ** 2).sum(), 1e-5, 0, "l2_params^2")
     u = torch.cat([upd["a"]["kernel"], upd["a"]["bias"]])
     assert_close(stats.cpu()[1], (u ** 2).sum(), 1e-4, 1e-12, "l2_updates^2")
+
+
+@pytest.mark.parametrize("rows,cols", [(768, 2304), (64, 64), (70, 130), (3072, 768)])
+def test_transpose_bf16(dev, rows, cols):
+  from big_vision_amd import ops
+  x = rnd((rows, cols), dev, 3, dtype=BF16)
+  y = ops.transpose_bf16(x)
+  assert torch.equal(y, x.t().contiguous())
+  wide = rnd((rows, cols + 8), dev, 4, dtype=BF16)
+  assert torch.equal(ops.transpose_bf16(wide[:, :cols]), wide[:, :cols].t().contiguous())
