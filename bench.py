@@ -15,7 +15,7 @@ recompute scheme of big_vision_amd/trainers/proj/image_text/siglip.py when
       --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     : the dominant kernel (the forward-layout bf16 MFMA GEMM) timed
+  roofline     : the dominant kernel (the 256x256 k-major bf16 MFMA GEMM: forward + dX) timed
                  live with HIP events on the launch stream over the timed steps;
                  achieved = algorithmic FLOPs (2*M*N*K per launch) / event time.
   cpu_baseline : the CPU oracle (oracle/bv_oracle.py, kind "port") running the
@@ -41,8 +41,8 @@ RES, SEQ, VOCAB, EMB = 224, 64, 32_000, 768
 IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-DOMINANT = ("bv_gemm_bf16", 1, 0)   # forward-layout GEMM: A k-major, B k-minor
-DOMINANT_KERNEL = "gemm_bf16_kernel<true, false>"
+DOMINANT = ("bv_gemm_bf16", 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
+DOMINANT_KERNEL = "gemm256_kernel<true>"
 
 
 class GemmObserver:
@@ -56,6 +56,8 @@ class GemmObserver:
   def begin(self, name, args):
     if not self.active or name != DOMINANT[0] or (args[0], args[1]) != DOMINANT[1:]:
       return None
+    if (args[9] & 255) or (args[10] & 255) or (args[11] & 63):
+      return None   # small/ragged problems run on the general 128x128 kernel, not the dominant one
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

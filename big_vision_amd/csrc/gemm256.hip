@@ -97,16 +97,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 15, lg = lane >> 4;
 
-  // ---- XCD-aware tile mapping: block b runs on XCD b%8; give every XCD a
-  // contiguous range of tile ids (n fastest) so co-resident blocks share A panels.
+  // ---- XCD-aware work mapping.  The grid is 1-D over (split, tile); block b runs on
+  // XCD b%8.  Every XCD gets a contiguous range of work ids with the tile index
+  // fastest (n fastest inside it), so the blocks co-resident on one XCD share A row
+  // panels (NT) or the same K-chunk of both operands (TN split-K) through its L2.
   const int bid = blockIdx.x;
-  const int nwg = p.ntiles;
+  const int nwg = gridDim.x;
   const int q8 = nwg >> 3, r8 = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  const int split = work / p.ntiles;
+  const int tile = work - split * p.ntiles;
   const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int m0 = tm * 256, n0 = tn * 256;
-  const int kt0 = blockIdx.y * p.ktiles_per_split;
+  const int kt0 = split * p.ktiles_per_split;
   const int nk_all = p.K >> 6;
   const int nk = min(p.ktiles_per_split, nk_all - kt0);
 
@@ -461,8 +465,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   }
   p.ktiles_per_split = (nk + splits - 1) / splits;
   splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-  if (splits > 65535) return 0;
-  dim3 grid(p.ntiles, splits), block(512);
+  dim3 grid(p.ntiles * splits), block(512);
   hipStream_t s = (hipStream_t)stream;
   if (km) hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);

@@ -27,9 +27,9 @@ def close(a, b, rtol, atol, name):
 @pytest.fixture()
 def fast(dev):
   from big_vision_amd import _lib
-  _lib.call("bv_gemm_fast_path", 1)
+  _lib.load().bv_gemm_fast_path(1)      # returns the previous setting, not a status
   yield
-  _lib.call("bv_gemm_fast_path", 1)
+  _lib.load().bv_gemm_fast_path(1)
 
 
 def _general(fn):
