@@ -25,6 +25,7 @@ PROTOTYPES = {
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
                      c_int, P, P, c_long, c_int, P, c_float, c_int, P],
     "bv_gemm_fast_path": [c_int],
+    "bv_set_workspace": [P, c_long],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],

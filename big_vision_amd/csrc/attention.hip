@@ -516,10 +516,18 @@ int launch_bwd(const void* qkv, const void* d_o, const float* lse, const float* 
 
 }  // namespace
 
+// attention2.hip (LDS-resident operands); the kernels above remain as the general
+// fallback selected by bv_gemm_fast_path(0).
+int bv_attn2_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
+int bv_attn2_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                 void* dqkv, int n, int L, int H, void* stream);
+int bv_fast_path_enabled();
+
 extern "C" int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_fwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_fwd: L=%d > 576 not supported", L);
   BV_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)o % 16 == 0, "bv_attn_fwd: unaligned pointers");
+  if (bv_fast_path_enabled()) return bv_attn2_fwd(qkv, o, lse, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   if (L <= 64) return launch_fwd<4>(qkv, o, lse, n, L, H, s);
   if (L <= 224) return launch_fwd<14>(qkv, o, lse, n, L, H, s);
@@ -531,6 +539,7 @@ extern "C" int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            float* delta, void* dqkv, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_bwd: L=%d > 576 not supported", L);
+  if (bv_fast_path_enabled()) return bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * L * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,

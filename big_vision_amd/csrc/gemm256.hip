@@ -58,6 +58,7 @@ struct G256Params {
   int epi;
   int out_f32;
   float alpha;
+  float* slab;         // split-K partial slabs (TN), or nullptr
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -88,7 +89,11 @@ __device__ __forceinline__ void glds16(const bf16* src, char* dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst_wave_base, 16, 0, 0);
 }
 
-template <bool KM>
+// PROBE != 0 variants exist only for tools/probes/gemm256_probe.hip (bottleneck
+// ablation, results are garbage): 1 = LDS fragment reads only for the first K-tile,
+// 2 = (TN) plain b128 reads instead of transpose reads, 3 = no DMA after the
+// prologue, 4 = no MFMAs.  The library instantiates PROBE = 0 only.
+template <bool KM, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
   const int tid = threadIdx.x;
@@ -147,12 +152,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 
   // issue one half-tile (2 DMA instructions per thread)
   auto issueA = [&](int t, int h) {
+    if (PROBE == 3 && t > 1) return;
     char* d = ldsA + ((t & 1) * 2 + h) * HALF + wave_off;
     const bf16* s = srcA + (long)t * stepA + (h ? hA : 0);
     glds16(s, d);
     glds16(s + gA, d + 8192);
   };
   auto issueB = [&](int t, int bs, int h) {
+    if (PROBE == 3 && t > 1) return;
     char* d = ldsB + (bs * 2 + h) * HALF + wave_off;
     const bf16* s = srcB + (long)t * stepB + (h ? hB : 0);
     glds16(s, d);
@@ -191,9 +198,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   bf16x8 af[4][2], bfg[4][2];
 
   // A fragments of 64-row sub-tile `sub` (4 frags x 2 k-steps) of stage base `sa`
+  bool probe_skip_reads = false;
   auto readA = [&](uint32_t sa, int sub) {
-    if constexpr (KM) {
-      const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
+    if (PROBE == 1 && probe_skip_reads) return;
+    if constexpr (KM || PROBE == 2) {
+      const uint32_t a0 = (ra0 + sa) & (PROBE == 2 ? ~15u : ~0u), a1 = (ra1 + sa) & (PROBE == 2 ? ~15u : ~0u);
       if (sub == 0) {
         af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
         af[1][0] = lds_read128<2048>(a0);  af[1][1] = lds_read128<2048>(a1);
@@ -221,8 +230,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   };
   // B fragments j = 2*sub, 2*sub+1 (2 frags x 2 k-steps) of stage base `sb`
   auto readB = [&](uint32_t sb, int sub) {
-    if constexpr (KM) {
-      const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
+    if (PROBE == 1 && probe_skip_reads) return;
+    if constexpr (KM || PROBE == 2) {
+      const uint32_t b0 = (rb0 + sb) & (PROBE == 2 ? ~15u : ~0u), b1 = (rb1 + sb) & (PROBE == 2 ? ~15u : ~0u);
       if (sub == 0) {
         bfg[0][0] = lds_read128<0>(b0);    bfg[0][1] = lds_read128<0>(b1);
         bfg[1][0] = lds_read128<512>(b0);  bfg[1][1] = lds_read128<512>(b1);
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #define BV_MFMA_QUAD(I0, J0)                                                                   \
   do {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                             \
+    if (PROBE != 4)                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     BV_MFMA_QUAD(4, 0);
     BV_END();
     bs = bs1;
+    probe_skip_reads = true;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
 #undef BV_MFMA_QUAD
@@ -400,28 +412,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       }
     }
   } else {
-    // TN (dW): lane holds C[m][n .. n+3], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + j*16 + lg*4;
-    // fp32 output, accumulated with atomics (split-K and += into the gradient buffer).
+    // TN (dW): lane holds C[m][n .. n+3], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + j*16 + lg*4.
+    if (p.slab) {
+      // split-K partial: fully coalesced 16-B stores into this block's 256 KiB slab,
+      // layout [wave][i][j][lane][4]; gemm256_reduce_kernel sums the slabs into C.
+      float* sl = p.slab + ((long)split * p.ntiles + tile) * 65536 + (wave * 32) * 256 + lane * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + lr;
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wc * 64 + j * 16 + lg * 4;
-        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-        if (epi == BV_EPI_ATOMIC) {
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<float4*>(sl + (i * 4 + j) * 256) =
+              make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r] * p.alpha);
-        } else {
-          *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha,
-                                                      acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + lr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + lg * 4;
+          float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+          if (epi == BV_EPI_ATOMIC) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r] * p.alpha);
+          } else {
+            *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha,
+                                                        acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+          }
         }
       }
     }
   }
 }
 
+// C[m][n..n+3] += alpha * sum_s slab[s][tile][...]  (deterministic split-K combine).
+// One thread per float4 of a tile; slab layout [wave][i][j][lane][4] as written above.
+__global__ __launch_bounds__(256) void gemm256_reduce_kernel(const float* __restrict__ slab,
+                                                             float* __restrict__ C, long ldc,
+                                                             int ntiles, int tiles_n, int splits,
+                                                             float alpha, int accumulate) {
+  const int tile = blockIdx.x >> 6;                      // 64 blocks of 256 float4 per tile
+  const int q = ((blockIdx.x & 63) << 8) + threadIdx.x;  // float4 index inside the tile, 0..16383
+  const int lane = q & 63, ij = (q >> 6) & 31, wave = q >> 11;
+  const int i = ij >> 2, j = ij & 3, wr = wave >> 2, wc = wave & 3, lr = lane & 15, lg = lane >> 4;
+  const float* s = slab + (long)tile * 65536 + (long)q * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < splits; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(s + (long)k * ntiles * 65536);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m = tm * 256 + wr * 128 + i * 16 + lr;
+  const int n = tn * 256 + wc * 64 + j * 16 + lg * 4;
+  float4* c = reinterpret_cast<float4*>(C + (long)m * ldc + n);
+  float4 o = make_float4(a.x * alpha, a.y * alpha, a.z * alpha, a.w * alpha);
+  if (accumulate) {
+    const float4 old = *c;
+    o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+  }
+  *c = o;
+}
+
 }  // namespace
+
+static void* g_ws = nullptr;
+static long g_ws_bytes = 0;
+extern "C" int bv_set_workspace(void* ptr, long bytes) {
+  g_ws = ptr;
+  g_ws_bytes = ptr ? bytes : 0;
+  return BV_OK;
+}
 
 // Internal entry used by bv_gemm_bf16 (gemm_bf16.hip).  Returns 1 if the problem
 // was launched on the 256x256 path, 0 if it does not qualify (caller falls back).
@@ -452,11 +511,14 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   p.ntiles = tiles_m * p.tiles_n;
   const int nk = K >> 6;
   int splits = 1;
+  p.slab = nullptr;
   if (epilogue == BV_EPI_ATOMIC) {
+    // split-K so that tiles x splits ~ one workgroup per CU (256): the K loop is the
+    // whole cost, every extra split adds a 256 KiB partial tile of output traffic.
     if (split_k > 0) {
       splits = split_k;
     } else {
-      splits = (2 * 256) / p.ntiles;          // ~2 rounds of one workgroup per CU
+      splits = 256 / p.ntiles;
       const int max_splits = nk / 8 > 0 ? nk / 8 : 1;
       if (splits > max_splits) splits = max_splits;
     }
@@ -465,9 +527,16 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   }
   p.ktiles_per_split = (nk + splits - 1) / splits;
   splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  const long slab_bytes = (long)p.ntiles * splits * 65536 * 4;
+  const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && g_ws && slab_bytes <= g_ws_bytes &&
+                        (ldc & 3) == 0;
+  if (use_slab) p.slab = (float*)g_ws;
   dim3 grid(p.ntiles * splits), block(512);
   hipStream_t s = (hipStream_t)stream;
   if (km) hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
+  if (use_slab)
+    hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)g_ws,
+                       (float*)C, ldc, p.ntiles, p.tiles_n, splits, alpha, 1);
   return 1;
 }

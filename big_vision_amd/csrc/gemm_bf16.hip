@@ -263,6 +263,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                    float alpha, int split_k, void* stream);
 static int g_fast_path = 1;
+int bv_fast_path_enabled() { return g_fast_path; }
 extern "C" int bv_gemm_fast_path(int enable) {
   const int old = g_fast_path;
   if (enable >= 0) g_fast_path = enable != 0;

@@ -36,6 +36,18 @@ def _rowmajor2d(t, name):
   return t.stride(0)
 
 
+_workspace = None
+WORKSPACE_BYTES = 64 << 20   # 256 split-K partial tiles of 256 KiB (one per CU)
+
+
+def _ensure_workspace(device):
+  """Registers the split-K scratch of the weight-gradient GEMMs (bv_set_workspace) once."""
+  global _workspace
+  if _workspace is None or _workspace.device != device:
+    _workspace = torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8)
+    _lib.call("bv_set_workspace", _workspace.data_ptr(), WORKSPACE_BYTES)
+
+
 # ------------------------------------------------------------------- GEMMs --
 def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=None, N=None, K=None,
          epilogue=EPI_NONE, bias=None, aux=None, aux_rows=0, out2=None, alpha=1.0, split_k=0):
@@ -60,6 +72,8 @@ def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=Non
     ldaux = _rowmajor2d(aux, "gemm.aux")
   if bias is not None:
     _chk(bias, F32, "gemm.bias")
+  if epilogue == EPI_ATOMIC:
+    _ensure_workspace(a.device)
   _lib.call("bv_gemm_bf16", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
             int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
             float(alpha), split_k, _stream())

@@ -63,10 +63,18 @@ int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                  float alpha, int split_k /*0 = auto*/, void* stream);
 
-/* Dispatch control (diagnostics / A-B benchmarking): problems with M,N multiples
- * of 256, K a multiple of 64 and both operands in the same layout run on the
- * 256x256x64 direct-to-LDS kernel; everything else on the general 128x128x64
- * kernel.  enable = 0/1 sets the switch, -1 only queries; returns the old value. */
+/* Caller-provided scratch (device memory, >= 64 MiB recommended) for split-K
+ * partial tiles of the weight-gradient GEMMs (EPI_ATOMIC): with a workspace the
+ * partials are written with plain coalesced stores and combined by a second
+ * small kernel (deterministic); without one (ptr = NULL) fp32 atomics are used.
+ * The workspace is process-global: calls that use it must be stream-ordered. */
+int bv_set_workspace(void* ptr, long bytes);
+
+/* Dispatch control (diagnostics / A-B benchmarking).  With the switch on (default)
+ * GEMMs with M,N multiples of 256, K a multiple of 64 and both operands in the
+ * same layout run on the 256x256x64 direct-to-LDS kernel (everything else on the
+ * general 128x128x64 kernel) and bv_attn_fwd/bwd use the LDS-resident kernels.
+ * enable = 0/1 sets the switch, -1 only queries; returns the old value. */
 int bv_gemm_fast_path(int enable);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive

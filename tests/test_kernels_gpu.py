@@ -178,8 +178,20 @@ def _attn_ref(qkv, n, L, H):
   return o.reshape(n * L, H * 64), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("n,L,H", [(3, 196, 2), (2, 64, 3), (2, 5, 1), (1, 197, 2), (1, 441, 1), (1, 576, 1)])
-def test_attention(dev, n, L, H):
+@pytest.mark.parametrize("fast", [1, 0])
+@pytest.mark.parametrize("n,L,H", [(3, 196, 2), (2, 64, 3), (2, 5, 1), (1, 197, 2), (1, 441, 1), (1, 576, 1),
+                                   (2, 224, 1), (1, 33, 2)])
+def test_attention(dev, n, L, H, fast):
+  """fast=1: LDS-resident kernels (attention2.hip); fast=0: the general fallback kernels."""
+  from big_vision_amd import ops, _lib
+  _lib.load().bv_gemm_fast_path(fast)
+  try:
+    _attention_case(dev, n, L, H)
+  finally:
+    _lib.load().bv_gemm_fast_path(1)
+
+
+def _attention_case(dev, n, L, H):
   from big_vision_amd import ops
   qkv = rnd((n * L, 3 * H * 64), dev, 1, 1.5, dtype=BF16)
   qr = qkv.double().requires_grad_(True)

@@ -53,6 +53,11 @@ def main():
       _lib.load().bv_gemm_fast_path(fast)
       ms = timeit(lambda: ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=dw, epilogue=ops.EPI_ATOMIC))
       res[f"tn{'256' if fast else '128'}_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
+    _lib.load().bv_gemm_fast_path(1)
+    _lib.load().bv_set_workspace(None, 0)     # fp32-atomic split-K for comparison
+    ms = timeit(lambda: ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=dw, epilogue=ops.EPI_ATOMIC))
+    res[f"tn256atomic_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
+    ops._workspace = None
   _lib.load().bv_gemm_fast_path(1)
   qkv = torch.randn(T, 3 * D, device=dev).to(BF16)
   ms = timeit(lambda: ops.attn_fwd(qkv, n, L, H))

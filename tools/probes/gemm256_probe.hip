@@ -1,0 +1,83 @@
+// Bottleneck ablation of the 256x256 GEMM main loop (standalone, no torch):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I big_vision_amd/csrc tools/probes/gemm256_probe.hip \
+//         big_vision_amd/csrc/c_api.cpp -o /tmp/gemm256_probe && /tmp/gemm256_probe
+// Variants (see PROBE in gemm256.hip): 0 full, 1 no LDS reads after tile 0,
+// 2 (TN) b128 reads instead of transpose reads, 3 no DMA after the prologue, 4 no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../big_vision_amd/csrc/gemm256.hip"
+
+template <bool KM, int PROBE>
+static float run(G256Params p, int grid, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((gemm256_kernel<KM, PROBE>), dim3(grid), dim3(512), 0, 0, p);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((gemm256_kernel<KM, PROBE>), dim3(grid), dim3(512), 0, 0, p);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(e));
+  return ms / iters;
+}
+
+static void fill(void* d, size_t n_bf16) {
+  std::vector<unsigned short> h(n_bf16);
+  unsigned s = 12345;
+  for (size_t i = 0; i < n_bf16; ++i) {
+    s = s * 1664525u + 1013904223u;
+    float f = ((s >> 8) & 0xffff) / 65536.0f * 2.f - 1.f;   // U(-1,1)
+    unsigned u; memcpy(&u, &f, 4);
+    h[i] = (unsigned short)(u >> 16);
+  }
+  hipMemcpy(d, h.data(), n_bf16 * 2, hipMemcpyHostToDevice);
+}
+
+int main() {
+  const int T = 100352;
+  struct Shape { const char* name; int in, out; } shapes[] = {{"qkv", 768, 2304}, {"out", 768, 768}, {"fc1", 768, 3072}, {"fc2", 3072, 768}};
+  void *x, *y, *w, *c;
+  hipError_t e1 = hipMalloc(&x, (size_t)T * 3072 * 2), e2 = hipMalloc(&y, (size_t)T * 3072 * 2);
+  hipError_t e3 = hipMalloc(&w, (size_t)3072 * 3072 * 2), e4 = hipMalloc(&c, (size_t)T * 3072 * 4);
+  printf("malloc: %d %d %d %d  %p %p %p %p\n", e1, e2, e3, e4, x, y, w, c); fflush(stdout);
+  fill(x, (size_t)T * 3072); fill(y, (size_t)T * 3072); fill(w, (size_t)3072 * 3072);
+  hipMemset(c, 0, (size_t)T * 3072 * 4);
+  for (auto& s : shapes) {
+    const double fl = 2.0 * T * s.in * s.out;
+    {  // TN: dW[in][out] = X^T dY, split-K atomics
+      G256Params p{};
+      p.A = (const bf16*)x; p.B = (const bf16*)y; p.C = c; p.lda = s.in; p.ldb = s.out; p.ldc = s.out;
+      p.M = s.in; p.N = s.out; p.K = T; p.aux_rows = 1; p.tiles_n = s.out / 256;
+      p.ntiles = (s.in / 256) * p.tiles_n; p.epi = BV_EPI_ATOMIC; p.out_f32 = 1; p.alpha = 1.f;
+      const int nk = T / 64;
+      for (int rounds = 1; rounds <= 2; ++rounds) {
+        int splits = rounds * 256 / p.ntiles; if (splits < 1) splits = 1;
+        p.ktiles_per_split = (nk + splits - 1) / splits;
+        splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
+        const int grid = p.ntiles * splits;
+        float t0 = run<false, 0>(p, grid, 5), t1 = run<false, 1>(p, grid, 5), t2 = run<false, 2>(p, grid, 5),
+              t3 = run<false, 3>(p, grid, 5), t4 = 0;
+        printf("TN %-4s grid %4d (splits %3d): full %.3f ms %6.0f TF | noLDSread %.3f | b128reads %.3f | noDMA %.3f | noMFMA %.3f\n",
+               s.name, grid, splits, t0, fl / t0 / 1e9, t1, t2, t3, t4);
+      }
+    }
+    {  // NT: Y[T][out] = X[T][in] W^T[out][in]
+      G256Params p{};
+      p.A = (const bf16*)x; p.B = (const bf16*)w; p.C = c; p.lda = s.in; p.ldb = s.in; p.ldc = s.out;
+      p.M = T; p.N = s.out; p.K = s.in; p.aux_rows = 1; p.tiles_n = s.out / 256;
+      p.ntiles = (T / 256) * p.tiles_n; p.epi = BV_EPI_NONE; p.out_f32 = 0; p.alpha = 1.f;
+      p.ktiles_per_split = s.in / 64;
+      const int grid = p.ntiles;
+      float t0 = run<true, 0>(p, grid, 5), t1 = run<true, 1>(p, grid, 5), t3 = run<true, 3>(p, grid, 5), t4 = 0;
+      printf("NT %-4s grid %4d: full %.3f ms %6.0f TF | noLDSread %.3f | noDMA %.3f | noMFMA %.3f\n", s.name, grid,
+             t0, fl / t0 / 1e9, t1, t3, t4);
+    }
+  }
+  return 0;
+}
