@@ -40,13 +40,39 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 __device__ __forceinline__ int t64_swz(int row) { return ((row >> 1) & 3) << 1; }
 
-// Stage src[L][64] (row stride ld elements) into a T64 tile of `rows` rows (rows >= L are zero).
-__device__ __forceinline__ void t64_stage(char* T, const bf16* src, long ld, int L, int rows, int tid) {
-  for (int idx = tid; idx < rows * 8; idx += 256) {
-    const int row = idx >> 3, pc = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < L) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + pc * 8);
-    *reinterpret_cast<uint4*>(T + row * 128 + ((pc ^ t64_swz(row)) << 4)) = v;
+// Stage two [L][64] matrices (row strides ld0/ld1 elements) into T64 tiles of ROWS rows
+// (rows >= L are zero).  All global loads of a batch are issued before the first LDS store, so a tile
+// costs one memory round trip per 8 pieces per thread, not one per piece.
+template <int ROWS>
+__device__ __forceinline__ void t64_stage2(char* T0, const bf16* src0, long ld0, char* T1,
+                                           const bf16* src1, long ld1, int L, int tid) {
+  constexpr int N = ROWS * 8 / 256;     // 16-byte pieces per thread and tile
+  constexpr int B = N < 8 ? N : 8;
+  static_assert(ROWS % 32 == 0, "tile rows must be a multiple of 32");
+#pragma unroll
+  for (int b0 = 0; b0 < N; b0 += B) {
+    uint4 v0[B], v1[B];
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (b0 + j) * 256;
+      const int row = idx >> 3, pc = idx & 7;
+      v0[j] = make_uint4(0, 0, 0, 0);
+      v1[j] = make_uint4(0, 0, 0, 0);
+      if (b0 + j < N && row < L) {
+        v0[j] = *reinterpret_cast<const uint4*>(src0 + (long)row * ld0 + pc * 8);
+        v1[j] = *reinterpret_cast<const uint4*>(src1 + (long)row * ld1 + pc * 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B; ++j) {
+      const int idx = tid + (b0 + j) * 256;
+      const int row = idx >> 3, pc = idx & 7;
+      if (b0 + j < N) {
+        const int off = row * 128 + ((pc ^ t64_swz(row)) << 4);
+        *reinterpret_cast<uint4*>(T0 + off) = v0[j];
+        *reinterpret_cast<uint4*>(T1 + off) = v1[j];
+      }
+    }
   }
 }
 // Row operand: 8 consecutive d (chunk) of row `row`.
@@ -103,8 +129,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16* __restric
   const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
   const bf16* kb_ = qb_ + (long)H * DH;
   const bf16* vb_ = qb_ + 2L * H * DH;
-  t64_stage(Kt, kb_, ld, L, KF * 16, tid);
-  t64_stage(Vt, vb_, ld, L, KF * 16, tid);
+  t64_stage2<KF * 16>(Kt, kb_, ld, Vt, vb_, ld, L, tid);
   __syncthreads();
   const float c = scale * LOG2E;
 
@@ -238,8 +263,7 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __rest
   const bf16* kb_ = qb_ + (long)H * DH;
   const bf16* vb_ = qb_ + 2L * H * DH;
   const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
-  t64_stage(Kt, kb_, ld, L, KF * 16, tid);
-  t64_stage(Vt, vb_, ld, L, KF * 16, tid);
+  t64_stage2<KF * 16>(Kt, kb_, ld, Vt, vb_, ld, L, tid);
   __syncthreads();
   const float c = scale * LOG2E;
 
@@ -337,8 +361,7 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(const bf16* __res
   const bf16* kb_ = qb_ + (long)H * DH;
   const bf16* vb_ = qb_ + 2L * H * DH;
   const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
-  t64_stage(Qt, qb_, ld, L, QN * 16, tid);
-  t64_stage(Gt, dob_, ldo, L, QN * 16, tid);
+  t64_stage2<QN * 16>(Qt, qb_, ld, Gt, dob_, ldo, L, tid);
   for (int idx = tid; idx < QN * 16; idx += 256) {
     // rows >= L: lse = +inf makes P = exp2(-inf) = 0 without an explicit mask
     lse_s[idx] = idx < L ? lse[((long)i * H + h) * L + idx] * LOG2E : INFINITY;
