@@ -52,19 +52,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// flax nn.gelu(approximate=True): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+// Written as x * sigmoid(2u) = x / (1 + exp2(-2 log2(e) u)): one v_exp_f32 + one v_rcp_f32,
+// no IEEE division (these run inside GEMM epilogues, 128 evaluations per lane and tile).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  (flax nn.gelu approximate=True)
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  const float e = __expf(2.0f * u);
-  const float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  const float k = -2.0f * 1.4426950408889634f * 0.7978845608028654f;   // -2 log2(e) sqrt(2/pi)
+  const float z = k * x * (1.0f + 0.044715f * x * x);
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));   // sigmoid(2u)
+  return x * sg;
 }
+// d/dx [x sigmoid(2u)] = s + x s (1 - s) 2 u',  u' = sqrt(2/pi) (1 + 3*0.044715 x^2)
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   const float c = 0.7978845608028654f;
   const float x2 = x * x;
-  const float u = c * (x + 0.044715f * x * x2);
-  const float e = __expf(2.0f * u);
-  const float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x2);
+  const float z = (-2.0f * 1.4426950408889634f * c) * x * (1.0f + 0.044715f * x2);
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+  return sg + x * sg * (1.0f - sg) * (2.0f * c) * (1.0f + 3.0f * 0.044715f * x2);
 }
 #endif

@@ -54,11 +54,13 @@ struct G256Params {
   int aux_rows;
   int tiles_n;
   int ntiles;          // tiles_m * tiles_n
+  int splits;          // split-K factor (work items = ntiles * splits)
   int ktiles_per_split;
   int epi;
   int out_f32;
   float alpha;
   float* slab;         // split-K partial slabs (TN), or nullptr
+  int skew_cycles;     // > 0: spread the workgroups' start over this many cycles (see kernel)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -92,8 +94,26 @@ __device__ __forceinline__ void glds16(const bf16* src, char* dst_wave_base) {
 // PROBE != 0 variants exist only for tools/probes/gemm256_probe.hip (bottleneck
 // ablation, results are garbage): 1 = LDS fragment reads only for the first K-tile,
 // 2 = (TN) plain b128 reads instead of transpose reads, 3 = no DMA after the
-// prologue, 4 = no MFMAs.  The library instantiates PROBE = 0 only.
-template <bool KM, int PROBE = 0>
+// prologue, 5 = no epilogue stores (bf16 outputs).  The library instantiates PROBE = 0 only.
+//
+// The kernel is PERSISTENT: the grid is one workgroup per CU (<= 256); each workgroup
+// walks a list of work items (tile, split) and keeps the DMA pipeline running across
+// item boundaries, so the loads of the next tile's first K-tiles are in flight while
+// the current tile's epilogue runs (no per-tile pipeline fill).
+struct Cursor {   // position of a load stream / of the math: item j (of this block), K-tile t
+  int j, t, nk;
+  long offA, offB;   // element offsets of K-tile 0 of item j (added to the per-lane pointers)
+  int m0, n0, tile, split;
+};
+
+// 16-B chunk swizzle of the k-major LDS images: chunk c of row r sits at c ^ kswz(r).
+// Conflict-free for ds_read_b128 under BOTH fragment-row maps used below (rows
+// j*16 + c and (j>>1)*32 + (c>>2)*8 + (j&1)*4 + (c&3)), brute-forced over the lane groups.
+__device__ __forceinline__ int kswz(int r) {
+  return ((r >> 1) & 1) | (((r >> 3) & 1) << 1) | ((((r >> 2) ^ (r >> 4)) & 1) << 2);
+}
+
+template <bool KM, int PROBE = 0, int EPI = BV_EPI_NONE, bool OUTF32 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
   const int tid = threadIdx.x;
@@ -102,24 +122,56 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 15, lg = lane >> 4;
 
-  // ---- XCD-aware work mapping.  The grid is 1-D over (split, tile); block b runs on
-  // XCD b%8.  Every XCD gets a contiguous range of work ids with the tile index
-  // fastest (n fastest inside it), so the blocks co-resident on one XCD share A row
-  // panels (NT) or the same K-chunk of both operands (TN split-K) through its L2.
-  const int bid = blockIdx.x;
-  const int nwg = gridDim.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
+  // ---- XCD-aware work distribution.  Block b runs on XCD b%8.  Work ids (tile index
+  // fastest, n fastest inside it, then split) are cut into 8 contiguous chunks, one per
+  // XCD; the blocks of an XCD take consecutive ids of their chunk, round after round, so
+  // co-resident blocks share A row panels (NT) or the same K-chunk of both operands (TN
+  // split-K) through that XCD's L2.
+  const int bid = blockIdx.x, G = gridDim.x;
+  const int nwork = p.ntiles * p.splits;
   const int xcd = bid & 7, idx = bid >> 3;
-  const int work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-  const int split = work / p.ntiles;
-  const int tile = work - split * p.ntiles;
-  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int kt0 = split * p.ktiles_per_split;
+  const int q8 = nwork >> 3, r8 = nwork & 7;
+  const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cl = q8 + (xcd < r8 ? 1 : 0);
+  const int bpx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+  const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
+  if (nmy == 0) return;
   const int nk_all = p.K >> 6;
-  const int nk = min(p.ktiles_per_split, nk_all - kt0);
+  // All workgroups of a launch run identical tiles, so left alone they stay in lockstep
+  // and hit their epilogues together: a chip-wide store burst during which nobody
+  // computes (the next tile's first counted vmcnt wait also retires the older stores).
+  // For launches of many rounds the host asks for a start skew of one tile period spread
+  // over the workgroups of each XCD; the phases persist, the store traffic becomes steady.
+  if (p.skew_cycles > 0) {
+    const int n = (int)(((long)p.skew_cycles * idx / bpx) >> 13);   // s_sleep 127 ~ 8128 cycles
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
-  // ---- per-lane global source pointers of the DMA (half 0, piece g = 0, K-tile kt0)
+  auto load_item = [&](Cursor& c) {
+    const int w = cs + idx + c.j * bpx;
+    c.split = w / p.ntiles;
+    c.tile = w - c.split * p.ntiles;
+    const int tm = c.tile / p.tiles_n, tn = c.tile - tm * p.tiles_n;
+    c.m0 = tm * 256; c.n0 = tn * 256;
+    const int kt0 = c.split * p.ktiles_per_split;
+    c.nk = min(p.ktiles_per_split, nk_all - kt0);
+    if constexpr (KM) {
+      c.offA = (long)c.m0 * p.lda + (long)kt0 * 64;
+      c.offB = (long)c.n0 * p.ldb + (long)kt0 * 64;
+    } else {
+      c.offA = (long)kt0 * 64 * p.lda + c.m0;
+      c.offB = (long)kt0 * 64 * p.ldb + c.n0;
+    }
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.t == c.nk) {
+      c.t = 0;
+      ++c.j;
+      if (c.j < nmy) load_item(c);
+    }
+  };
+
+  // ---- per-lane global source pointers of the DMA (item offset 0, half 0, piece g = 0)
   const bf16* srcA;
   const bf16* srcB;
   long stepA, stepB;      // advance per K-tile
@@ -128,10 +180,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   if constexpr (KM) {
     const int r = wave * 8 + (lane >> 3);           // row within the half-tile (g = 0)
     const int pos = lane & 7;
-    const int cA = pos ^ ((r >> 1) & 7);
-    const int cB = pos ^ ((((r >> 4) & 3) << 1) | ((r >> 1) & 1));
-    srcA = p.A + (long)(m0 + r) * p.lda + (long)kt0 * 64 + cA * 8;
-    srcB = p.B + (long)(n0 + r) * p.ldb + (long)kt0 * 64 + cB * 8;
+    const int cA = pos ^ kswz(r);
+    const int cB = pos ^ kswz(r);
+    srcA = p.A + (long)r * p.lda + cA * 8;
+    srcB = p.B + (long)r * p.ldb + cB * 8;
     stepA = 64; stepB = 64;
     gA = 64 * p.lda; gB = 64 * p.ldb;
     hA = 128 * p.lda; hB = 128 * p.ldb;
@@ -140,8 +192,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     const int piece = lane & 15;
     const int qs = (piece >> 1) ^ swzk(k);
     const int off = qs * 16 + (piece & 1) * 8;
-    srcA = p.A + (long)(kt0 * 64 + k) * p.lda + m0 + off;
-    srcB = p.B + (long)(kt0 * 64 + k) * p.ldb + n0 + off;
+    srcA = p.A + (long)k * p.lda + off;
+    srcB = p.B + (long)k * p.ldb + off;
     stepA = 64 * p.lda; stepB = 64 * p.ldb;
     gA = 32 * p.lda; gB = 32 * p.ldb;
     hA = 128; hB = 128;
@@ -149,19 +201,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   char* const ldsA = smem;
   char* const ldsB = smem + A_BYTES;
   const int wave_off = wave * 1024;
+  bool probe_no_dma = false;
 
-  // issue one half-tile (2 DMA instructions per thread)
-  auto issueA = [&](int t, int h) {
-    if (PROBE == 3 && t > 1) return;
-    char* d = ldsA + ((t & 1) * 2 + h) * HALF + wave_off;
-    const bf16* s = srcA + (long)t * stepA + (h ? hA : 0);
+  // issue one half-tile (2 DMA instructions per thread) of the K-tile under cursor c
+  auto issueA = [&](const Cursor& c, int slot, int h) {
+    if (PROBE == 3 && probe_no_dma) return;
+    char* d = ldsA + (slot * 2 + h) * HALF + wave_off;
+    const bf16* s = srcA + c.offA + (long)c.t * stepA + (h ? hA : 0);
     glds16(s, d);
     glds16(s + gA, d + 8192);
   };
-  auto issueB = [&](int t, int bs, int h) {
-    if (PROBE == 3 && t > 1) return;
-    char* d = ldsB + (bs * 2 + h) * HALF + wave_off;
-    const bf16* s = srcB + (long)t * stepB + (h ? hB : 0);
+  auto issueB = [&](const Cursor& c, int slot, int h) {
+    if (PROBE == 3 && probe_no_dma) return;
+    char* d = ldsB + (slot * 2 + h) * HALF + wave_off;
+    const bf16* s = srcB + c.offB + (long)c.t * stepB + (h ? hB : 0);
     glds16(s, d);
     glds16(s + gB, d + 8192);
   };
@@ -170,12 +223,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   uint32_t ra0, ra1, rb0, rb1;   // A/B fragment base for k-step 0 / 1 (KM) or ka/kb rows (!KM)
   if constexpr (KM) {
-    const int swA = (lr >> 1) & 7;
-    const int swB = ((lr >> 2) << 1) | ((lr >> 1) & 1);
-    ra0 = lds0 + wr * HALF + lr * 128 + ((lg ^ swA) << 4);
+    // A fragment i: rows i*16 + lr.  B fragment j: fp32 output -> rows j*16 + lr (a lane ends
+    // up with 4 consecutive columns per fragment, 16-B stores, 64 B contiguous per row and
+    // instruction); bf16 output -> rows (j>>1)*32 + (lr>>2)*8 + (j&1)*4 + (lr&3) (a lane ends
+    // up with 8 consecutive columns per fragment PAIR: again 16-B stores, 64 B per row).
+    // Bit 4 of the row (odd fragments) flips chunk bit 2 = byte 64: odd fragments swap the
+    // two k-step bases instead of recomputing the address.
+    const int brow = OUTF32 ? lr : (lr >> 2) * 8 + (lr & 3);
+    ra0 = lds0 + wr * HALF + lr * 128 + ((lg ^ kswz(lr)) << 4);
     ra1 = ra0 ^ 64;
-    rb0 = lds0 + A_BYTES + (wc >> 1) * HALF + ((wc & 1) * 64 + (lr >> 2) * 16 + (lr & 3)) * 128 +
-          ((lg ^ swB) << 4);
+    rb0 = lds0 + A_BYTES + (wc >> 1) * HALF + ((wc & 1) * 64 + brow) * 128 + ((lg ^ kswz(brow)) << 4);
     rb1 = rb0 ^ 64;
   } else {
     // tr read: lane supplies the 8-byte chunk [k = lg*8 + (lr>>2) (+4)][rows 4*(lr&3)..+3]
@@ -205,14 +262,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       const uint32_t a0 = (ra0 + sa) & (PROBE == 2 ? ~15u : ~0u), a1 = (ra1 + sa) & (PROBE == 2 ? ~15u : ~0u);
       if (sub == 0) {
         af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
-        af[1][0] = lds_read128<2048>(a0);  af[1][1] = lds_read128<2048>(a1);
+        af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
         af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
-        af[3][0] = lds_read128<6144>(a0);  af[3][1] = lds_read128<6144>(a1);
+        af[3][0] = lds_read128<6144>(a1);  af[3][1] = lds_read128<6144>(a0);
       } else {
         af[0][0] = lds_read128<8192>(a0);  af[0][1] = lds_read128<8192>(a1);
-        af[1][0] = lds_read128<10240>(a0); af[1][1] = lds_read128<10240>(a1);
+        af[1][0] = lds_read128<10240>(a1); af[1][1] = lds_read128<10240>(a0);
         af[2][0] = lds_read128<12288>(a0); af[2][1] = lds_read128<12288>(a1);
-        af[3][0] = lds_read128<14336>(a0); af[3][1] = lds_read128<14336>(a1);
+        af[3][0] = lds_read128<14336>(a1); af[3][1] = lds_read128<14336>(a0);
       }
     } else {
       // 16-row block rb = sub*4 + i lives at 32-B slot rb ^ swzk(k)
@@ -233,12 +290,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     if (PROBE == 1 && probe_skip_reads) return;
     if constexpr (KM || PROBE == 2) {
       const uint32_t b0 = (rb0 + sb) & (PROBE == 2 ? ~15u : ~0u), b1 = (rb1 + sb) & (PROBE == 2 ? ~15u : ~0u);
+      constexpr int O1 = OUTF32 ? 2048 : 512, O2 = OUTF32 ? 4096 : 4096, O3 = OUTF32 ? 6144 : 4608;
       if (sub == 0) {
         bfg[0][0] = lds_read128<0>(b0);    bfg[0][1] = lds_read128<0>(b1);
-        bfg[1][0] = lds_read128<512>(b0);  bfg[1][1] = lds_read128<512>(b1);
+        bfg[1][0] = lds_read128<O1>(b1);   bfg[1][1] = lds_read128<O1>(b0);
       } else {
-        bfg[2][0] = lds_read128<1024>(b0); bfg[2][1] = lds_read128<1024>(b1);
-        bfg[3][0] = lds_read128<1536>(b0); bfg[3][1] = lds_read128<1536>(b1);
+        bfg[2][0] = lds_read128<O2>(b0);   bfg[2][1] = lds_read128<O2>(b1);
+        bfg[3][0] = lds_read128<O3>(b1);   bfg[3][1] = lds_read128<O3>(b0);
       }
     } else {
 #pragma unroll
@@ -281,132 +339,176 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     __builtin_amdgcn_s_barrier();            \
   } while (0)
 
-  // ---- prologue: B(0), A(0), B(1) in flight; tile 0 must have landed.
-  issueB(0, 0, 0); issueB(0, 0, 1);
-  issueA(0, 0); issueA(0, 1);
-  if (nk > 1) {
-    issueB(1, 1, 0); issueB(1, 1, 1);
+  // ---- prologue: B(0), A(0), B(1) in flight; K-tile 0 must have landed.
+  Cursor cur{};            // the math
+  cur.j = 0; cur.t = 0;
+  load_item(cur);
+  Cursor ca = cur, cb = cur;   // A stream runs 1 K-tile ahead, B stream 2 K-tiles ahead
+  issueB(cb, 0, 0); issueB(cb, 0, 1);
+  issueA(ca, 0, 0); issueA(ca, 0, 1);
+  advance(ca);
+  advance(cb);
+  if (cb.j < nmy) {
+    issueB(cb, 1, 0); issueB(cb, 1, 1);
+    advance(cb);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
+    cb.j = nmy;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
 
-  int bs = 0;  // B ring slot of the current tile
-  for (int t = 0; t < nk; ++t) {
-    const uint32_t sa = (t & 1) * 2 * HALF;
-    const uint32_t sb = bs * 2 * HALF;
-    const int bs1 = (bs == 2) ? 0 : bs + 1;          // slot of tile t+1
-    const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of tile t+2
-    // -------- phase 0: quadrant (0,0)
-    readA(sa, 0);
-    readB(sb, 0);
-    if (t + 1 < nk) issueA(t + 1, 0);
-    BV_MID();
-    BV_MFMA_QUAD(0, 0);
-    BV_END();
-    // -------- phase 1: quadrant (0,1)
-    readB(sb, 1);
-    if (t + 1 < nk) issueA(t + 1, 1);
-    BV_MID();
-    BV_MFMA_QUAD(0, 2);
-    BV_END();
-    // -------- phase 2: quadrant (1,1)
-    readA(sa, 1);
-    if (t + 2 < nk) issueB(t + 2, bs2, 0);
-    BV_MID();
-    BV_MFMA_QUAD(4, 2);
-    BV_END();
-    // -------- phase 3: quadrant (1,0); retire tile t+1's loads for the next iteration
-    if (t + 2 < nk) {
-      issueB(t + 2, bs2, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int gk = 0;  // K-tiles consumed so far (ring position)
+  int bs = 0;  // B ring slot of the current K-tile
+  for (int jt = 0; jt < nmy; ++jt) {
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+    const int nkc = cur.nk;
+    for (int t = 0; t < nkc; ++t) {
+      const uint32_t sa = (gk & 1) * 2 * HALF;
+      const uint32_t sb = bs * 2 * HALF;
+      const int bs1 = (bs == 2) ? 0 : bs + 1;          // slot of K-tile gk+1
+      const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of K-tile gk+2
+      const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
+      // -------- phase 0: quadrant (0,0)
+      readA(sa, 0);
+      readB(sb, 0);
+      if (moreA) issueA(ca, (gk + 1) & 1, 0);
+      BV_MID();
+      BV_MFMA_QUAD(0, 0);
+      BV_END();
+      // -------- phase 1: quadrant (0,1)
+      readB(sb, 1);
+      if (moreA) issueA(ca, (gk + 1) & 1, 1);
+      BV_MID();
+      BV_MFMA_QUAD(0, 2);
+      BV_END();
+      // -------- phase 2: quadrant (1,1)
+      readA(sa, 1);
+      if (moreB) issueB(cb, bs2, 0);
+      BV_MID();
+      BV_MFMA_QUAD(4, 2);
+      BV_END();
+      // -------- phase 3: quadrant (1,0); retire K-tile gk+1's loads for the next iteration
+      if (moreB) {
+        issueB(cb, bs2, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      BV_MID();
+      BV_MFMA_QUAD(4, 0);
+      BV_END();
+      if (moreA) advance(ca);
+      if (moreB) advance(cb);
+      bs = bs1;
+      ++gk;
+      probe_skip_reads = true;
+      probe_no_dma = true;
     }
-    BV_MID();
-    BV_MFMA_QUAD(4, 0);
-    BV_END();
-    bs = bs1;
-    probe_skip_reads = true;
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
-#undef BV_MFMA_QUAD
-#undef BV_MID
-#undef BV_END
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align both wave groups for the epilogue
+    const int m0 = cur.m0, n0 = cur.n0, tile = cur.tile, split = cur.split;
 
   // ---- epilogue
   const int epi = p.epi;
   if constexpr (KM) {
-    // lane holds C[m][n .. n+15], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + lg*16 (+ j*4 + r)
-    const int nb = n0 + wc * 64 + lg * 16;
+    // lane holds, per row fragment i (m = m0 + wr*128 + i*16 + lr) and B fragment j, the 4
+    // columns nc[j] .. nc[j]+3:  fp32 output: nc[j] = n0 + wc*64 + j*16 + lg*4;  bf16 output:
+    // nc[j] = n0 + wc*64 + (j>>1)*32 + lg*8 + (j&1)*4 (fragments 2jp, 2jp+1 are adjacent: 8
+    // columns = one 16-byte bf16 store).  Either way one store instruction covers 16 rows x
+    // 64 contiguous bytes.  EPI is a compile-time constant and the auxiliary loads of 4 row
+    // fragments are issued together before their first use (one memory round trip per
+    // batch: the whole CU is in its epilogue at the same time, nothing else hides it).
+    int nc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      nc[j] = n0 + wc * 64 + (OUTF32 ? j * 16 + lg * 4 : (j >> 1) * 32 + lg * 8 + (j & 1) * 4);
     float bv[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) bv[e] = 0.f;
     if (p.bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + j * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + nc[j]);
         bv[j * 4 + 0] = b.x; bv[j * 4 + 1] = b.y; bv[j * 4 + 2] = b.z; bv[j * 4 + 3] = b.w;
       }
     }
+    const int mrow0 = m0 + wr * 128 + lr;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + lr;
-      float v[16];
+    for (int ib = 0; ib < 8; ib += 4) {
+      float4 ax[4][4];
+      uint4 hx[4][2];
+      if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int ii = 0; ii < 4; ++ii) {
+          const int m = mrow0 + (ib + ii) * 16;
+          const long arow = (EPI == BV_EPI_POS) ? (long)(m % p.aux_rows) : (long)m;
+          const float* x = reinterpret_cast<const float*>(p.aux) + arow * p.ldaux;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha + bv[j * 4 + r];
-      if (epi == BV_EPI_RESIDUAL || epi == BV_EPI_POS) {
-        const long arow = (epi == BV_EPI_POS) ? (long)(m % p.aux_rows) : (long)m;
-        const float* x = reinterpret_cast<const float*>(p.aux) + arow * p.ldaux + nb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 a = *reinterpret_cast<const float4*>(x + j * 4);
-          v[j * 4 + 0] += a.x; v[j * 4 + 1] += a.y; v[j * 4 + 2] += a.z; v[j * 4 + 3] += a.w;
+          for (int j = 0; j < 4; ++j) ax[ii][j] = *reinterpret_cast<const float4*>(x + nc[j]);
         }
-      } else if (epi == BV_EPI_GELU_BWD) {
-        const uint4* h = reinterpret_cast<const uint4*>(
-            reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + nb);
+      } else if constexpr (EPI == BV_EPI_GELU_BWD) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const uint4 u = h[hh];
-          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[hh * 8 + e * 2 + 0] *= gelu_tanh_grad_f(bflo(w[e]));
-            v[hh * 8 + e * 2 + 1] *= gelu_tanh_grad_f(bfhi(w[e]));
-          }
+        for (int ii = 0; ii < 4; ++ii) {
+          const int m = mrow0 + (ib + ii) * 16;
+          const bf16* h = reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux;
+          hx[ii][0] = *reinterpret_cast<const uint4*>(h + nc[0]);
+          hx[ii][1] = *reinterpret_cast<const uint4*>(h + nc[2]);
         }
       }
-      if (p.out_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + nb;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = ib + ii;
+        const int m = mrow0 + i * 16;
+        float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<float4*>(c + j * 4) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
-      } else {
-        bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + nb;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          uint4 o;
-          o.x = pack_bf2(v[hh * 8 + 0], v[hh * 8 + 1]);
-          o.y = pack_bf2(v[hh * 8 + 2], v[hh * 8 + 3]);
-          o.z = pack_bf2(v[hh * 8 + 4], v[hh * 8 + 5]);
-          o.w = pack_bf2(v[hh * 8 + 6], v[hh * 8 + 7]);
-          *reinterpret_cast<uint4*>(c + hh * 8) = o;
+          for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha + bv[j * 4 + r];
+        if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j * 4 + 0] += ax[ii][j].x; v[j * 4 + 1] += ax[ii][j].y;
+            v[j * 4 + 2] += ax[ii][j].z; v[j * 4 + 3] += ax[ii][j].w;
+          }
+        } else if constexpr (EPI == BV_EPI_GELU_BWD) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[hh * 8 + e * 2 + 0] *= gelu_tanh_grad_f(bflo(w[e]));
+              v[hh * 8 + e * 2 + 1] *= gelu_tanh_grad_f(bfhi(w[e]));
+            }
+          }
         }
-        if (epi == BV_EPI_GELU) {
-          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + nb;
+        if constexpr (OUTF32) {
+          float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(c + nc[j]) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
+        } else {
+          bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc;
+          if (PROBE == 5 && v[0] != 12345.678f) continue;   // probe: keep the math live, skip the stores
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             uint4 o;
-            o.x = pack_bf2(gelu_tanh_f(v[hh * 8 + 0]), gelu_tanh_f(v[hh * 8 + 1]));
-            o.y = pack_bf2(gelu_tanh_f(v[hh * 8 + 2]), gelu_tanh_f(v[hh * 8 + 3]));
-            o.z = pack_bf2(gelu_tanh_f(v[hh * 8 + 4]), gelu_tanh_f(v[hh * 8 + 5]));
-            o.w = pack_bf2(gelu_tanh_f(v[hh * 8 + 6]), gelu_tanh_f(v[hh * 8 + 7]));
-            *reinterpret_cast<uint4*>(c2 + hh * 8) = o;
+            o.x = pack_bf2(v[hh * 8 + 0], v[hh * 8 + 1]);
+            o.y = pack_bf2(v[hh * 8 + 2], v[hh * 8 + 3]);
+            o.z = pack_bf2(v[hh * 8 + 4], v[hh * 8 + 5]);
+            o.w = pack_bf2(v[hh * 8 + 6], v[hh * 8 + 7]);
+            *reinterpret_cast<uint4*>(c + nc[hh * 2]) = o;
+          }
+          if constexpr (EPI == BV_EPI_GELU) {
+            bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              uint4 o;
+              o.x = pack_bf2(gelu_tanh_f(v[hh * 8 + 0]), gelu_tanh_f(v[hh * 8 + 1]));
+              o.y = pack_bf2(gelu_tanh_f(v[hh * 8 + 2]), gelu_tanh_f(v[hh * 8 + 3]));
+              o.z = pack_bf2(gelu_tanh_f(v[hh * 8 + 4]), gelu_tanh_f(v[hh * 8 + 5]));
+              o.w = pack_bf2(gelu_tanh_f(v[hh * 8 + 6]), gelu_tanh_f(v[hh * 8 + 7]));
+              *reinterpret_cast<uint4*>(c2 + nc[hh * 2]) = o;
+            }
           }
         }
       }
@@ -442,6 +544,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       }
     }
   }
+    // ---- next work item: clear the accumulators, move the math cursor
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cur.t = cur.nk - 1;
+    advance(cur);
+  }
+#undef BV_MFMA_QUAD
+#undef BV_MID
+#undef BV_END
 }
 
 // C[m][n..n+3] += alpha * sum_s slab[s][tile][...]  (deterministic split-K combine).
@@ -474,6 +587,12 @@ __global__ __launch_bounds__(256) void gemm256_reduce_kernel(const float* __rest
 
 }  // namespace
 
+static int g_skew = 1;
+extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
+  const int old = g_skew;
+  if (enable >= 0) g_skew = enable != 0;
+  return old;
+}
 static void* g_ws = nullptr;
 static long g_ws_bytes = 0;
 extern "C" int bv_set_workspace(void* ptr, long bytes) {
@@ -531,10 +650,20 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && g_ws && slab_bytes <= g_ws_bytes &&
                         (ldc & 3) == 0;
   if (use_slab) p.slab = (float*)g_ws;
-  dim3 grid(p.ntiles * splits), block(512);
+  p.splits = splits;
+  const int nwork = p.ntiles * splits;
+  // start skew (see kernel): one tile period (~3600 cycles per K-tile + epilogue) when every
+  // workgroup has >= 8 tiles, so the skewed tail costs < 1/8 of the launch.
+  p.skew_cycles = (km && g_skew && nwork >= 8 * 256) ? nk * 3600 + 3000 : 0;
+  dim3 grid(nwork < 256 ? nwork : 256), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
-  if (km) hipLaunchKernelGGL((gemm256_kernel<true>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
+  if (!km) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_POS) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_POS, true>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU, false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_GELU_BWD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD, false>), grid, block, 0, s, p);
+  else if (out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, false>), grid, block, 0, s, p);
   if (use_slab)
     hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)g_ws,
                        (float*)C, ldc, p.ntiles, p.tiles_n, splits, alpha, 1);

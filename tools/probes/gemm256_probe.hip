@@ -60,7 +60,8 @@ int main() {
         int splits = rounds * 256 / p.ntiles; if (splits < 1) splits = 1;
         p.ktiles_per_split = (nk + splits - 1) / splits;
         splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
-        const int grid = p.ntiles * splits;
+        p.splits = splits;
+        const int grid = p.ntiles * splits < 256 ? p.ntiles * splits : 256;
         float t0 = run<false, 0>(p, grid, 5), t1 = run<false, 1>(p, grid, 5), t2 = run<false, 2>(p, grid, 5),
               t3 = run<false, 3>(p, grid, 5), t4 = 0;
         printf("TN %-4s grid %4d (splits %3d): full %.3f ms %6.0f TF | noLDSread %.3f | b128reads %.3f | noDMA %.3f | noMFMA %.3f\n",
@@ -73,9 +74,10 @@ int main() {
       p.M = T; p.N = s.out; p.K = s.in; p.aux_rows = 1; p.tiles_n = s.out / 256;
       p.ntiles = (T / 256) * p.tiles_n; p.epi = BV_EPI_NONE; p.out_f32 = 0; p.alpha = 1.f;
       p.ktiles_per_split = s.in / 64;
-      const int grid = p.ntiles;
-      float t0 = run<true, 0>(p, grid, 5), t1 = run<true, 1>(p, grid, 5), t3 = run<true, 3>(p, grid, 5), t4 = 0;
-      printf("NT %-4s grid %4d: full %.3f ms %6.0f TF | noLDSread %.3f | noDMA %.3f | noMFMA %.3f\n", s.name, grid,
+      p.splits = 1;
+      const int grid = p.ntiles < 256 ? p.ntiles : 256;
+      float t0 = run<true, 0>(p, grid, 5), t1 = run<true, 1>(p, grid, 5), t3 = run<true, 3>(p, grid, 5), t4 = run<true, 5>(p, grid, 5);
+      printf("NT %-4s grid %4d: full %.3f ms %6.0f TF | noLDSread %.3f | noDMA %.3f | noStores %.3f\n", s.name, grid,
              t0, fl / t0 / 1e9, t1, t3, t4);
     }
   }
