@@ -207,7 +207,9 @@ def main():
       "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
                              "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
                  "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": MICRO,
-                 "recompute": "two-pass (embeddings, then fwd+bwd per micro-batch)" if n > MICRO else "none",
+                 "recompute": (f"{max(0, n // MICRO - update_fn.state_cache['keep_n'])} of {n // MICRO} micro-batches "
+                               "re-run their forward in pass 2 (activations of the others stay in HBM)")
+                              if n > MICRO else "none",
                  "parallelism": f"dp{world}", "final_loss": loss},
   }
   if not args.no_roofline:

@@ -488,7 +488,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
             *reinterpret_cast<float4*>(c + nc[j]) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
         } else {
           bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc;
-          if (PROBE == 5 && v[0] != 12345.678f) continue;   // probe: keep the math live, skip the stores
+          if (PROBE == 5) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
+#pragma unroll
+            for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(v[e]));
+            continue;
+          }
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             uint4 o;
@@ -654,7 +658,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   const int nwork = p.ntiles * splits;
   // start skew (see kernel): one tile period (~3600 cycles per K-tile + epilogue) when every
   // workgroup has >= 8 tiles, so the skewed tail costs < 1/8 of the launch.
-  p.skew_cycles = (km && g_skew && nwork >= 8 * 256) ? nk * 3600 + 3000 : 0;
+  p.skew_cycles = (km && g_skew > 1 && nwork >= 8 * 256) ? nk * 3600 + 3000 : 0;
   dim3 grid(nwork < 256 ? nwork : 256), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
   if (!km) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);

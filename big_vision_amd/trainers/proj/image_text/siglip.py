@@ -83,6 +83,7 @@ def make_update_fn(model, config, comm=None):
   comm = comm or dp.Comm()
   assert "mixup" not in config, "Mixup is not supported for SigLIP."
   micro = int(config.get("microbatch", 0) or 0)
+  state_cache = {"keep_n": 1}
 
   def update_fn(train_state, rng, batch):
     del rng  # dropout is 0 on this path; kept for signature parity
@@ -100,19 +101,42 @@ def make_update_fn(model, config, comm=None):
 
     if micro and n > micro:
       assert n % micro == 0, f"per-device batch {n} not divisible by microbatch {micro}"
-      # Pass 1: embeddings of all micro-batches (no activations kept).
-      zi, zt = [], []
-      for s in range(0, n, micro):
-        a, b, _, _ = ex.fwd(images[s:s + micro], labels[s:s + micro], save=False)
+      # Pass 1: embeddings of all micro-batches.  The sigmoid loss couples the whole batch,
+      # so every tower backward has to wait for all embeddings.  The activations of as many
+      # micro-batches as fit in HBM (288 GB on MI355X) are KEPT; only the rest is recomputed
+      # in pass 2 (a pure memory/compute trade: results are identical either way).
+      starts = list(range(0, n, micro))
+      keep_cfg = config.get("microbatch_keep", "auto")
+      keep_n = len(starts) if keep_cfg == "all" else (0 if keep_cfg in (0, "none") else None)
+      if isinstance(keep_cfg, int) and keep_cfg > 0:
+        keep_n = keep_cfg
+      zi, zt, kept = [], [], {}
+      for k, s in enumerate(starts):
+        keep = (keep_n is None and k == 0) or (keep_n is not None and len(kept) < keep_n)
+        if keep_n is None and k > 0:
+          keep = len(kept) < state_cache["keep_n"]
+        before = torch.cuda.memory_allocated(images.device)
+        a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=keep)
+        if keep:
+          kept[s] = c
+          if keep_n is None and k == 0:
+            per_ctx = max(1, torch.cuda.memory_allocated(images.device) - before)
+            free, total = torch.cuda.mem_get_info(images.device)
+            reserved_slack = torch.cuda.memory_reserved(images.device) - torch.cuda.memory_allocated(images.device)
+            budget = max(0, free + reserved_slack - int(0.12 * total))   # leave 12 % of HBM untouched
+            state_cache["keep_n"] = 1 + int(budget // (per_ctx + per_ctx // 8))
         zi.append(a); zt.append(b)
       zimg, ztxt = torch.cat(zi), torch.cat(zt)
       stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
-      # Pass 2: recompute each micro-batch with activations and back-propagate
-      # its slice of the embedding gradients (grads accumulate in the flat buffer).
-      for s in range(0, n, micro):
-        _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro], save=True)
+      # Pass 2: back-propagate every micro-batch's slice of the embedding gradients (grads
+      # accumulate in the flat buffer); recompute the forward where it was not kept.
+      for s in starts:
+        ctx = kept.pop(s, None)
+        if ctx is None:
+          _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro], save=True)
         ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
                None if txt_frozen else dztxt[s:s + micro].contiguous())
+        del ctx
     else:
       zimg, ztxt, _, ctx = ex.fwd(images, labels, save=True)
       stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
@@ -134,6 +158,7 @@ def make_update_fn(model, config, comm=None):
     measurements.update(opt.step())
     return {"params": params, "opt": opt}, measurements
 
+  update_fn.state_cache = state_cache   # diagnostics: how many micro-batches keep their activations
   return update_fn
 
 

@@ -122,3 +122,35 @@ def test_b16_siglip_step_small_batch(dev):
   image_cfg = dict(variant="B/16", pool_type="map")
   text_cfg = dict(variant="B")
   _run_case(dev, image_cfg, text_cfg, E=768, n=4, res=224, seq=64, vocab=32_000)
+
+
+@pytest.mark.parametrize("keep", [0, 1, "all", "auto"])
+def test_microbatched_step_equals_full_batch(dev, keep):
+  """Two-pass micro-batching (config.microbatch / microbatch_keep) is a pure memory/compute
+  trade: loss and gradients must match the single-pass step on the same batch."""
+  import bv_oracle as O
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  from big_vision_amd import utils as u
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+
+  def run(**kw):
+    model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0,
+                             bias_init=-10.0)
+    config = _cfg(**kw)
+    state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0,
+                                       total_steps=config.total_steps)
+    state, meas = siglip.make_update_fn(model, config)(state, None, batch)
+    grads = {k: v.detach().cpu().double().clone()
+             for k, v in u.tree_flatten_with_names(state["params"].store.tree("grad"))[0]}
+    return meas["training_loss"].item(), grads
+
+  loss_full, g_full = run()
+  loss_mb, g_mb = run(microbatch=2, microbatch_keep=keep)
+  assert abs(loss_full - loss_mb) <= 1e-5 * abs(loss_full)
+  gn = math.sqrt(sum((v ** 2).sum().item() for v in g_full.values()))
+  for k, v in g_full.items():
+    assert (v - g_mb[k]).norm().item() <= 2e-3 * max(v.norm().item(), 1e-3 * gn), k
