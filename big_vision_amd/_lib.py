@@ -29,7 +29,7 @@ PROTOTYPES = {
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
-    "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
+    "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],

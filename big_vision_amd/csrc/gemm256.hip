@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   // For launches of many rounds the host asks for a start skew of one tile period spread
   // over the workgroups of each XCD; the phases persist, the store traffic becomes steady.
   if (p.skew_cycles > 0) {
-    const int n = (int)(((long)p.skew_cycles * idx / bpx) >> 13);   // s_sleep 127 ~ 8128 cycles
+    const int n = (int)(((long)p.skew_cycles * xcd / 8) >> 13);   // s_sleep 127 ~ 8128 cycles
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
 
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void gemm256_reduce_kernel(const float* __rest
 static int g_skew = 1;
 extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
   const int old = g_skew;
-  if (enable >= 0) g_skew = enable != 0;
+  if (enable >= 0) g_skew = enable;
   return old;
 }
 static void* g_ws = nullptr;

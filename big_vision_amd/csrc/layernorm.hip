@@ -80,18 +80,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16* __restrict__ dx_bf,
                                                      float* __restrict__ dscale,
-                                                     float* __restrict__ dbias, int rows, int D,
+                                                     float* __restrict__ dbias,
+                                                     float* __restrict__ dxsum, int rows, int D,
                                                      long row_stride, long row_offset) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][4][D]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
   const int nwaves = gridDim.x * 4;
   const float inv_d = 1.0f / (float)D;
-  float4 ps[MAXV], pb[MAXV];
+  float4 ps[MAXV], pb[MAXV], po[MAXV];
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     pb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    po[it] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   for (int r = wave_global; r < rows; r += nwaves) {
     const long xrow = (long)r * row_stride + row_offset;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
         }
         *reinterpret_cast<float4*>(dx + xrow * D + c) = o;
+        po[it].x += o.x; po[it].y += o.y; po[it].z += o.z; po[it].w += o.w;
         if (dx_bf) {
           uint2 p;
           p.x = pack_bf2(o.x, o.y);
@@ -150,12 +153,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   // cross-wave reduction of the per-column partials, then one atomic per column.
   float* rs = red;               // [4][D]
   float* rb = red + 4 * D;       // [4][D]
+  float* ro = red + 8 * D;       // [4][D]
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int c = lane * 4 + it * 256;
     if (c < D) {
       *reinterpret_cast<float4*>(rs + wave * D + c) = ps[it];
       *reinterpret_cast<float4*>(rb + wave * D + c) = pb[it];
+      *reinterpret_cast<float4*>(ro + wave * D + c) = po[it];
     }
   }
   __syncthreads();
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const float b = rb[c] + rb[D + c] + rb[2 * D + c] + rb[3 * D + c];
     if (dscale) unsafeAtomicAdd(dscale + c, a);
     if (dbias) unsafeAtomicAdd(dbias + c, b);
+    if (dxsum) unsafeAtomicAdd(dxsum + c, ro[c] + ro[D + c] + ro[2 * D + c] + ro[3 * D + c]);
   }
 }
 
@@ -185,22 +191,22 @@ extern "C" int bv_layernorm_fwd(const float* x, const float* scale, const float*
 
 extern "C" int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* scale,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
-                                void* dx_bf16, float* dscale, float* dbias, int rows, int D,
-                                long row_stride, long row_offset, void* stream) {
+                                void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows,
+                                int D, long row_stride, long row_offset, void* stream) {
   BV_REQUIRE(rows > 0 && D > 0, "bv_layernorm_bwd: empty input rows=%d D=%d", rows, D);
   BV_REQUIRE(D % 4 == 0 && D <= 256 * MAXV, "bv_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
   BV_REQUIRE(row_stride >= 1 && row_offset >= 0 && row_offset < row_stride, "bv_layernorm_bwd: bad row_stride/offset");
   BV_REQUIRE(mean && rstd && dx, "bv_layernorm_bwd: mean/rstd/dx required");
   int grid = (rows + 3) / 4;
   if (grid > 512) grid = 512;
-  const size_t shmem = sizeof(float) * 8 * D;
+  const size_t shmem = sizeof(float) * 12 * D;
   if (dy_is_f32)
     hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x,
-                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, rows, D, row_stride,
+                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D, row_stride,
                        row_offset);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x,
-                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, rows, D, row_stride,
+                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D, row_stride,
                        row_offset);
   return bv_check_launch("bv_layernorm_bwd");
 }

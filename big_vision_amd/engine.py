@@ -195,9 +195,11 @@ class MLP:
     out = linear_fwd(g, self.w2, self.b2, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=resid)
     return out, h, g
 
-  def bwd(self, dout_f32, dout_bf, y_bf, h, g):
-    """Returns dy (bf16) = gradient w.r.t. the MLP input y."""
-    linear_bwd_w(g, dout_bf, self.w2, self.b2, dy_for_bias=dout_f32)
+  def bwd(self, dout_f32, dout_bf, y_bf, h, g, bias2_done=False):
+    """Returns dy (bf16) = gradient w.r.t. the MLP input y.  bias2_done: the Dense_1 bias
+    gradient (column sums of dout) was already accumulated by the LayerNorm-backward kernel
+    that produced dout (bv_layernorm_bwd dx_colsum)."""
+    linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
     dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h)
     linear_bwd_w(y_bf, dh, self.w1, self.b1)
     return linear_bwd_x(dh, self.w1)
@@ -228,19 +230,22 @@ class Block:
     x2, h, g = self.mlp.fwd(y1, x1)
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
-  def bwd(self, saved, dx2, dx2_bf, n, L):
+  def bwd(self, saved, dx2, dx2_bf, n, L, b2_done=False, next_b2=None):
+    """b2_done: this block's MlpBlock Dense_1 bias gradient was fused into the producer of dx2;
+    next_b2: gradient buffer of the PREVIOUS block's Dense_1 bias, to be fused into the
+    LayerNorm_0 backward that produces that block's dx2 (bias grads = column sums of dx)."""
     x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g = saved
     T, D, H = n * L, self.D, self.H
-    dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g)
+    dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g, bias2_done=b2_done)
     dx1_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
-    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf)
-    linear_bwd_w(o, dx1_bf, self.wo, self.bo, dy_for_bias=dx1)
+    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad)
+    linear_bwd_w(o, dx1_bf, self.wo, None)      # out-proj bias grad = colsum(dx1): fused above
     d_o = linear_bwd_x(dx1_bf, self.wo)
     dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
     linear_bwd_w(y0, dqkv, self.wqkv, self.bqkv)
     dy0 = linear_bwd_x(dqkv, self.wqkv)
     dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
-    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf)
+    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf, dx_colsum=next_b2)
     return dx, dx_bf
 
 
@@ -267,9 +272,17 @@ class Encoder:
       out["pre_ln"] = x
     return x, saved
 
-  def bwd(self, saved, dx, dx_bf, n, L):
-    for blk, s in zip(reversed(self.blocks), reversed(saved)):
-      dx, dx_bf = blk.bwd(s, dx, dx_bf, n, L)
+  def last_b2_grad(self):
+    """Gradient buffer of the last block's Dense_1 bias: the kernel that produces the
+    encoder's incoming dx (encoder_norm backward) accumulates its column sums there."""
+    return self.blocks[-1].mlp.b2.grad if self.blocks else None
+
+  def bwd(self, saved, dx, dx_bf, n, L, b2_done=False):
+    last = len(self.blocks) - 1
+    for i in range(last, -1, -1):
+      nb2 = self.blocks[i - 1].mlp.b2.grad if i > 0 else None
+      dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L, b2_done=(b2_done if i == last else True),
+                                     next_b2=nb2)
     return dx, dx_bf
 
 
@@ -304,8 +317,8 @@ class MAPHead:
     dz_bf = ops.cast_bf16(dz)
     dyl = self.mlp.bwd(dz, dz_bf, yl, h, g)
     da_bf = torch.empty((n, D), device=dz.device, dtype=BF16)
-    da = self.ln.bwd(dyl, a, mean, rstd, n, D, dres=dz, dx_bf16=da_bf)
-    linear_bwd_w(o, da_bf, self.wo, self.bo, dy_for_bias=da)
+    da = self.ln.bwd(dyl, a, mean, rstd, n, D, dres=dz, dx_bf16=da_bf, dx_colsum=self.bo.grad)
+    linear_bwd_w(o, da_bf, self.wo, None)       # out-proj bias grad fused into the LN backward
     d_o = linear_bwd_x(da_bf, self.wo)
     dq, dkv = ops.map_attn_bwd(q, kv, p, d_o, n, L, H)
     linear_bwd_w(probe_t, dq, self.wq, self.bq)

@@ -91,14 +91,15 @@ class TextExec:
     if m.pool_type in ("last", "first"):
       dxL = torch.zeros((T, D), device=xL.device, dtype=F32)
       dxL_bf.zero_()
-      self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=ctx["off"])
+      self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=ctx["off"],
+                        dx_colsum=self.enc.last_b2_grad())
     elif m.pool_type in ("mean", "gap"):
       dyf = ops.pool_gap_bwd(dz, n, L, D)
-      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     else:
       dy = self.map.bwd(ctx["map"], dz, n, L)
-      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
-    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L)
+      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True)
     if self.table.grad is not None:
       ops.embed_bwd(ctx["ids"].view(-1), dx0, self.table.grad)
     if self.pos.grad is not None:

@@ -162,15 +162,16 @@ class VitExec:
     dxL_bf = torch.empty((T, D), device=xL.device, dtype=BF16)
     if m.pool_type == "map":
       dy = self.map.bwd(ctx["map"], dz, n, L)
-      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
+      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     elif m.pool_type == "gap":
       dyf = ops.pool_gap_bwd(dz, n, L, D)
-      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf)
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     else:
       dxL = torch.zeros((T, D), device=xL.device, dtype=F32)
       dxL_bf.zero_()
-      self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=0)
-    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L)
+      self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=0,
+                        dx_colsum=self.enc.last_b2_grad())
+    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True)
     if m.pool_type == "tok":
       if self.cls.grad is not None:
         ops.colsum(dx0.view(n, L * D)[:, :D], self.cls.grad.view(-1))

@@ -103,15 +103,16 @@ def layernorm_fwd(x, scale, bias, *, rows, D, row_stride=1, row_offset=0, want_b
 
 
 def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_bf16=None,
-                  dscale=None, dbias=None, row_stride=1, row_offset=0):
-  """dx = dres + LN_bwd(dy); dscale/dbias accumulated in place."""
+                  dscale=None, dbias=None, dx_colsum=None, row_stride=1, row_offset=0):
+  """dx = dres + LN_bwd(dy); dscale/dbias (and dx_colsum += column sums of dx) accumulated in place."""
   if dy.dtype not in (BF16, F32):
     raise TypeError("layernorm_bwd.dy must be bf16 or fp32")
   _chk(x, F32, "layernorm_bwd.x")
   if dx is None:
     dx = torch.empty_like(x) if row_stride == 1 else torch.zeros_like(x)
   _lib.call("bv_layernorm_bwd", _p(dy), int(dy.dtype == F32), _p(x), _p(scale), _p(mean), _p(rstd),
-            _p(dres), _p(dx), _p(dx_bf16), _p(dscale), _p(dbias), rows, D, row_stride, row_offset,
+            _p(dres), _p(dx), _p(dx_bf16), _p(dscale), _p(dbias), _p(dx_colsum), rows, D, row_stride,
+            row_offset,
             _stream())
   return dx
 

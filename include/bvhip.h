@@ -97,10 +97,13 @@ int bv_layernorm_fwd(const float* x, const float* scale, const float* bias, void
 /* dx_out[row] = (dres ? dres[row] : 0) + LN_bwd(dy[row]); optional bf16 copy of
  * dx_out; dscale/dbias are ACCUMULATED (+=) with fp32 atomics.  dy is bf16 or
  * fp32 (dy_is_f32).  With row_stride>1 only the selected rows of dx are
- * written (caller zero-fills the rest). */
+ * written (caller zero-fills the rest).  dx_colsum (optional, [D], accumulated):
+ * column sums of dx_out = the bias gradient of the Dense layer that produced
+ * this LayerNorm's input row (out-projection / MLP Dense_1, vit.py:101,110),
+ * fused here so that gradient needs no extra pass over dx. */
 int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* scale,
                      const float* mean, const float* rstd, const float* dres, float* dx,
-                     void* dx_bf16, float* dscale, float* dbias, int rows, int D,
+                     void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows, int D,
                      long row_stride, long row_offset, void* stream);
 
 /* ------------------------------------------------------------ Attention ----

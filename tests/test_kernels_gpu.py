@@ -138,9 +138,11 @@ def test_layernorm(dev, rows, D):
   ref.backward(dy.double())
   dscale = torch.zeros(D, device=dev); dbias = torch.zeros(D, device=dev)
   dx_bf = torch.empty((rows, D), device=dev, dtype=BF16)
+  dxsum = torch.ones(D, device=dev)          # accumulated (+=) into
   dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=rows, D=D, dres=dres, dx_bf16=dx_bf,
-                         dscale=dscale, dbias=dbias)
+                         dscale=dscale, dbias=dbias, dx_colsum=dxsum)
   assert_close(dx, xr.grad + dres.double(), 1e-4, 1e-4, "ln dx")
+  assert_close(dxsum, 1.0 + dx.double().sum(0), 1e-4, 1e-3, "ln dx colsum (fused bias grad)")
   assert_close(dx_bf, xr.grad + dres.double(), 1e-2, 1e-2, "ln dx bf16")
   assert_close(dscale, sr.grad, 1e-4, 1e-3, "ln dscale")
   assert_close(dbias, br.grad, 1e-4, 1e-3, "ln dbias")
@@ -163,7 +165,10 @@ def test_layernorm_strided_rows(dev):
   sel = x.view(n, L, D)[:, -1]
   assert_close(y, torch.nn.functional.layer_norm(sel, (D,), scale, bias, eps=1e-6), 1e-5, 1e-5, "strided ln")
   dy = rnd((n, D), dev, 4)
-  dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=n, D=D, row_stride=L, row_offset=L - 1)
+  dxsum = torch.zeros(D, device=dev)
+  dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=n, D=D, row_stride=L, row_offset=L - 1,
+                         dx_colsum=dxsum)
+  assert_close(dxsum, dx.double().sum(0), 1e-4, 1e-4, "strided ln dx colsum")
   xr = x.clone().requires_grad_(True)
   torch.nn.functional.layer_norm(xr.view(n, L, D)[:, -1], (D,), scale, bias, eps=1e-6).backward(dy)
   assert_close(dx, xr.grad, 1e-4, 1e-5, "strided ln bwd")

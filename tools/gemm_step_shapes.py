@@ -53,6 +53,8 @@ def main():
       if hasattr(lib, "bv_gemm_skew"):
         lib.bv_gemm_skew(0)
         ms0 = timeit(lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, **kw))
+        lib.bv_gemm_skew(2)
+        ms = timeit(lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, **kw))
         lib.bv_gemm_skew(1)
         name = f"{name} [noskew {ms0*1e3:.1f}]"
       s += ms
