@@ -145,6 +145,7 @@ def main():
   ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample", type=int, default=16)
+  ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
   args = ap.parse_args()
 
   from big_vision_amd import _lib, dp
@@ -166,6 +167,7 @@ def main():
                            temperature_init=10.0, bias_init=-10.0)
   total_steps = max(20_000, args.steps + args.warmup)
   config = make_config(total_steps)
+  config.microbatch = args.microbatch
   image, text = synthetic_batch(n, dev, seed=1 + comm.rank)
   state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,
                                      total_steps=total_steps, device=dev)
@@ -184,6 +186,7 @@ def main():
   t0 = time.perf_counter()
   for _ in range(args.steps):
     state, meas = update_fn(state, None, batch)
+  host_dt = time.perf_counter() - t0   # host enqueue time (diagnostic: host- vs GPU-bound)
   torch.cuda.synchronize()
   comm.barrier()
   dt = time.perf_counter() - t0
@@ -206,11 +209,14 @@ def main():
       "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
       "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
                              "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
-                 "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": MICRO,
-                 "recompute": (f"{max(0, n // MICRO - update_fn.state_cache['keep_n'])} of {n // MICRO} micro-batches "
-                               "re-run their forward in pass 2 (activations of the others stay in HBM)")
-                              if n > MICRO else "none",
-                 "parallelism": f"dp{world}", "final_loss": loss},
+                 "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
+                 "recompute": (f"{max(0, n // args.microbatch - update_fn.state_cache['keep_n'])} of "
+                               f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
+                               f"(the others keep {'light' if update_fn.state_cache['light'] else 'full'} "
+                               "activation contexts in HBM)")
+                              if n > args.microbatch else "none",
+                 "parallelism": f"dp{world}", "final_loss": loss,
+                 "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps},
   }
   if not args.no_roofline:
     launches, ms, flops = obs.summary()

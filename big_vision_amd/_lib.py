@@ -25,6 +25,8 @@ PROTOTYPES = {
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
                      c_int, P, P, c_long, c_int, P, c_float, c_int, P],
     "bv_gemm_fast_path": [c_int],
+    "bv_gemm_tune": [c_int, c_int, c_int],
+    "bv_gemm_pre_issue": [c_int],
     "bv_set_workspace": [P, c_long],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
@@ -53,7 +55,7 @@ PROTOTYPES = {
                      c_float, c_float, c_float, P, P],
 }
 
-EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC = range(6)
+EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT = range(7)
 
 _lib = None
 

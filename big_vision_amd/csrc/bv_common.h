@@ -61,12 +61,21 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));   // sigmoid(2u)
   return x * sg;
 }
-// d/dx [x sigmoid(2u)] = s + x s (1 - s) 2 u',  u' = sqrt(2/pi) (1 + 3*0.044715 x^2)
-__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+// value g = x sigmoid(2u) and derivative d/dx g = s + x s (1 - s) 2 u',
+// u' = sqrt(2/pi) (1 + 3*0.044715 x^2), in one pass (shared exp/rcp).  The explicit fmaf /
+// products pin the rounding so that every caller (with or without the value) gets the same bits.
+__device__ __forceinline__ void gelu_tanh_val_grad_f(float x, float& g, float& dg) {
   const float c = 0.7978845608028654f;
   const float x2 = x * x;
-  const float z = (-2.0f * 1.4426950408889634f * c) * x * (1.0f + 0.044715f * x2);
+  const float z = (-2.0f * 1.4426950408889634f * c) * x * __builtin_fmaf(0.044715f, x2, 1.0f);
   const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
-  return sg + x * sg * (1.0f - sg) * (2.0f * c) * (1.0f + 3.0f * 0.044715f * x2);
+  g = x * sg;
+  const float up = (2.0f * c) * __builtin_fmaf(3.0f * 0.044715f, x2, 1.0f);
+  dg = __builtin_fmaf(g * (1.0f - sg), up, sg);
+}
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  float g, dg;
+  gelu_tanh_val_grad_f(x, g, dg);
+  return dg;
 }
 #endif

@@ -61,6 +61,11 @@ struct G256Params {
   float alpha;
   float* slab;         // split-K partial slabs (TN), or nullptr
   int skew_cycles;     // > 0: spread the workgroups' start over this many cycles (see kernel)
+  int skew_mode;       // 0: one phase per XCD; 1: one phase per workgroup (idx-major, so the
+                       //    workgroups that own one tile fewer start last)
+  int nt;              // bit 0: nontemporal (streaming) stores of C / C2; bit 1: nontemporal aux loads
+  int pre_issue;       // 1: issue the next tile's K-tile 1/2 loads ahead of the epilogue stores
+  long* dbg;           // probes only: [bid*4 + {0,1,2,3}] = shader-clock / 100 MHz REFCLK stamps at start / end
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -89,6 +94,18 @@ __device__ __forceinline__ s16x4 lds_read_tr64(uint32_t addr) {
 
 __device__ __forceinline__ void glds16(const bf16* src, char* dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst_wave_base, 16, 0, 0);
+}
+
+// 16-byte global stores / loads with an optional streaming (nontemporal) hint: the outputs of
+// the big projections (hundreds of MB) are never re-read before they fall out of the 4 MiB
+// L2, so allocating them there only evicts the weight panel every workgroup of the XCD shares.
+__device__ __forceinline__ void st16(void* ptr, u32x4 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ptr));
+  else *reinterpret_cast<u32x4*>(ptr) = v;
+}
+__device__ __forceinline__ u32x4 ld16(const void* ptr, bool nt) {
+  if (nt) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+  return *reinterpret_cast<const u32x4*>(ptr);
 }
 
 // PROBE != 0 variants exist only for tools/probes/gemm256_probe.hip (bottleneck
@@ -137,14 +154,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
   if (nmy == 0) return;
   const int nk_all = p.K >> 6;
+  if (PROBE != 0 && p.dbg && tid == 0) {
+    p.dbg[bid * 4 + 0] = __builtin_amdgcn_s_memtime();
+    p.dbg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+  // PROBE 9: fine-grained s_memtime stamps of wave 0 (blocks 0 and 1): one per K-tile end, one
+  // at the epilogue start and one at its end.
+  int stamp_n = 0;
+  auto stamp = [&]() {
+    if (PROBE == 9 && p.dbg && tid == 0 && bid < 2 && stamp_n < 1000)
+      p.dbg[1024 + bid * 1024 + stamp_n++] = __builtin_amdgcn_s_memtime();
+  };
   // All workgroups of a launch run identical tiles, so left alone they stay in lockstep
   // and hit their epilogues together: a chip-wide store burst during which nobody
   // computes (the next tile's first counted vmcnt wait also retires the older stores).
   // For launches of many rounds the host asks for a start skew of one tile period spread
   // over the workgroups of each XCD; the phases persist, the store traffic becomes steady.
   if (p.skew_cycles > 0) {
-    const int n = (int)(((long)p.skew_cycles * xcd / 8) >> 13);   // s_sleep 127 ~ 8128 cycles
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    const int rank = p.skew_mode ? idx * 8 + xcd : xcd * (G >> 3);
+    const int n = (int)(((long)p.skew_cycles * rank / G) >> 10);   // s_sleep 16 ~ 1024 cycles
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
   }
 
   auto load_item = [&](Cursor& c) {
@@ -360,6 +389,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 
   int gk = 0;  // K-tiles consumed so far (ring position)
   int bs = 0;  // B ring slot of the current K-tile
+  // Stores of one tile's epilogue per wave (they sit in the same in-order VMEM queue as the
+  // DMA): with `pre` set, the loads K-tile 0 of the next tile would issue were issued BEFORE
+  // the stores (into the ring slots the finished tile freed), and K-tile 0's counted wait
+  // leaves the stores outstanding (vmcnt(4 + NSTORE)) instead of draining them.
+  constexpr int NSTORE = KM ? ((OUTF32 || EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_BWD_EMIT) ? 32 : 16) : 32;
+  bool pre = false;
   for (int jt = 0; jt < nmy; ++jt) {
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
     const int nkc = cur.nk;
@@ -369,27 +404,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       const int bs1 = (bs == 2) ? 0 : bs + 1;          // slot of K-tile gk+1
       const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of K-tile gk+2
       const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
+      const bool doA = moreA && !pre, doB = moreB && !pre;
       // -------- phase 0: quadrant (0,0)
       readA(sa, 0);
       readB(sb, 0);
-      if (moreA) issueA(ca, (gk + 1) & 1, 0);
+      if (doA) issueA(ca, (gk + 1) & 1, 0);
       BV_MID();
       BV_MFMA_QUAD(0, 0);
       BV_END();
       // -------- phase 1: quadrant (0,1)
       readB(sb, 1);
-      if (moreA) issueA(ca, (gk + 1) & 1, 1);
+      if (doA) issueA(ca, (gk + 1) & 1, 1);
       BV_MID();
       BV_MFMA_QUAD(0, 2);
       BV_END();
       // -------- phase 2: quadrant (1,1)
       readA(sa, 1);
-      if (moreB) issueB(cb, bs2, 0);
+      if (doB) issueB(cb, bs2, 0);
       BV_MID();
       BV_MFMA_QUAD(4, 2);
       BV_END();
       // -------- phase 3: quadrant (1,0); retire K-tile gk+1's loads for the next iteration
-      if (moreB) {
+      if (pre) {
+        // in-order queue: [A(k+1) x4] [B(k+2) x4 if moreB] [NSTORE stores]; retire through A(k+1)
+        if (moreB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NSTORE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+        pre = false;
+      } else if (moreB) {
         issueB(cb, bs2, 1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
@@ -402,10 +443,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       if (moreB) advance(cb);
       bs = bs1;
       ++gk;
+      stamp();
       probe_skip_reads = true;
       probe_no_dma = true;
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();   // re-align both wave groups for the epilogue
+    stamp();
+    // Every wave has finished reading the last K-tile: its ring slots are free.  Issue the next
+    // tile's K-tile 1 (A) / K-tile 2 (B) now, ahead of the epilogue's stores.
+    if ((KM || p.slab) && EPI != BV_EPI_GELU_BWD && EPI != BV_EPI_GELU_BWD_EMIT && p.pre_issue) {
+      const bool mA = ca.j < nmy, mB = cb.j < nmy;
+      if (mA || mB) {
+        const int b1 = (bs == 2) ? 0 : bs + 1, b2 = (b1 == 2) ? 0 : b1 + 1;
+        if (mA) { issueA(ca, (gk + 1) & 1, 0); issueA(ca, (gk + 1) & 1, 1); }
+        if (mB) { issueB(cb, b2, 0); issueB(cb, b2, 1); }
+        pre = true;
+      }
+    }
     const int m0 = cur.m0, n0 = cur.n0, tile = cur.tile, split = cur.split;
 
   // ---- epilogue
@@ -433,30 +487,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       }
     }
     const int mrow0 = m0 + wr * 128 + lr;
+    const bool nts = (p.nt & 1) || PROBE == 6, ntl = p.nt & 2;
+    // row fragments per batch of auxiliary loads (GELU': 2, the variant is at the VGPR limit)
+    constexpr bool GBWD = EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT;
+    constexpr int IB = GBWD ? 2 : 4;
 #pragma unroll
-    for (int ib = 0; ib < 8; ib += 4) {
-      float4 ax[4][4];
-      uint4 hx[4][2];
+    for (int ib = 0; ib < 8; ib += IB) {
+      float4 ax[IB][4];
+      uint4 hx[IB][2];
       if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
+        for (int ii = 0; ii < IB; ++ii) {
           const int m = mrow0 + (ib + ii) * 16;
           const long arow = (EPI == BV_EPI_POS) ? (long)(m % p.aux_rows) : (long)m;
           const float* x = reinterpret_cast<const float*>(p.aux) + arow * p.ldaux;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ax[ii][j] = *reinterpret_cast<const float4*>(x + nc[j]);
+          for (int j = 0; j < 4; ++j) ax[ii][j] = __builtin_bit_cast(float4, ld16(x + nc[j], ntl));
         }
-      } else if constexpr (EPI == BV_EPI_GELU_BWD) {
+      } else if constexpr (GBWD) {
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
+        for (int ii = 0; ii < IB; ++ii) {
           const int m = mrow0 + (ib + ii) * 16;
           const bf16* h = reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux;
-          hx[ii][0] = *reinterpret_cast<const uint4*>(h + nc[0]);
-          hx[ii][1] = *reinterpret_cast<const uint4*>(h + nc[2]);
+          hx[ii][0] = __builtin_bit_cast(uint4, ld16(h + nc[0], ntl));
+          hx[ii][1] = __builtin_bit_cast(uint4, ld16(h + nc[2], ntl));
         }
       }
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
+      for (int ii = 0; ii < IB; ++ii) {
         const int i = ib + ii;
         const int m = mrow0 + i * 16;
         float v[16];
@@ -480,14 +538,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
               v[hh * 8 + e * 2 + 1] *= gelu_tanh_grad_f(bfhi(w[e]));
             }
           }
+        } else if constexpr (EPI == BV_EPI_GELU_BWD_EMIT) {
+          // same, and C2 = gelu(aux): the activation is recomputed here (from the same bf16
+          // pre-activation the forward applied it to) instead of being kept from the forward.
+          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
+            uint32_t gw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float g0, d0, g1, d1;
+              gelu_tanh_val_grad_f(bflo(w[e]), g0, d0);
+              gelu_tanh_val_grad_f(bfhi(w[e]), g1, d1);
+              v[hh * 8 + e * 2 + 0] *= d0;
+              v[hh * 8 + e * 2 + 1] *= d1;
+              gw[e] = pack_bf2(g0, g1);
+            }
+            st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
+          }
         }
         if constexpr (OUTF32) {
           float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<float4*>(c + nc[j]) = make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3]);
+            st16(c + nc[j], __builtin_bit_cast(u32x4, make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3])), nts);
         } else {
           bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc;
+          if (PROBE == 7)   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back)
+            c = reinterpret_cast<bf16*>(p.C) + ((long)bid * 128 + ((m - m0) & 127)) * 256 - n0;
           if (PROBE == 5) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
 #pragma unroll
             for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(v[e]));
@@ -500,18 +579,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
             o.y = pack_bf2(v[hh * 8 + 2], v[hh * 8 + 3]);
             o.z = pack_bf2(v[hh * 8 + 4], v[hh * 8 + 5]);
             o.w = pack_bf2(v[hh * 8 + 6], v[hh * 8 + 7]);
-            *reinterpret_cast<uint4*>(c + nc[hh * 2]) = o;
+            st16(c + nc[hh * 2], __builtin_bit_cast(u32x4, o), nts);
           }
           if constexpr (EPI == BV_EPI_GELU) {
             bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-              uint4 o;
-              o.x = pack_bf2(gelu_tanh_f(v[hh * 8 + 0]), gelu_tanh_f(v[hh * 8 + 1]));
-              o.y = pack_bf2(gelu_tanh_f(v[hh * 8 + 2]), gelu_tanh_f(v[hh * 8 + 3]));
-              o.z = pack_bf2(gelu_tanh_f(v[hh * 8 + 4]), gelu_tanh_f(v[hh * 8 + 5]));
-              o.w = pack_bf2(gelu_tanh_f(v[hh * 8 + 6]), gelu_tanh_f(v[hh * 8 + 7]));
-              *reinterpret_cast<uint4*>(c2 + nc[hh * 2]) = o;
+              // g = gelu(h) of the bf16-ROUNDED pre-activation h that is stored (and that the
+              // backward differentiates / can recompute g from): forward and backward agree.
+              uint32_t gw[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const uint32_t hw = pack_bf2(v[hh * 8 + e * 2], v[hh * 8 + e * 2 + 1]);
+                gw[e] = pack_bf2(gelu_tanh_f(bflo(hw)), gelu_tanh_f(bfhi(hw)));
+              }
+              st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
             }
           }
         }
@@ -548,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       }
     }
   }
+    stamp();
     // ---- next work item: clear the accumulators, move the math cursor
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -559,6 +642,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #undef BV_MFMA_QUAD
 #undef BV_MID
 #undef BV_END
+  if (PROBE != 0 && p.dbg && tid == 0) {
+    p.dbg[bid * 4 + 2] = __builtin_amdgcn_s_memtime();
+    p.dbg[bid * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // C[m][n..n+3] += alpha * sum_s slab[s][tile][...]  (deterministic split-K combine).
@@ -596,6 +683,21 @@ extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
   const int old = g_skew;
   if (enable >= 0) g_skew = enable;
   return old;
+}
+// Tuning knobs of the k-major kernel (tools/gemm_step_shapes.py A/Bs them):
+//   nt: bit 0 streaming stores, bit 1 streaming aux loads;  skew_mode / skew_pct: start skew of
+//   the workgroups as a percentage of one tile period (0 = off).  Negative = leave unchanged.
+static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0;
+extern "C" int bv_gemm_pre_issue(int enable) {   // diagnostics: A/B the pre-epilogue load issue
+  const int old = g_pre;
+  if (enable >= 0) g_pre = enable;
+  return old;
+}
+extern "C" int bv_gemm_tune(int nt, int skew_mode, int skew_pct) {
+  if (nt >= 0) g_nt = nt;
+  if (skew_mode >= 0) g_skew_mode = skew_mode;
+  if (skew_pct >= 0) g_skew_pct = skew_pct;
+  return BV_OK;
 }
 static void* g_ws = nullptr;
 static long g_ws_bytes = 0;
@@ -659,6 +761,14 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   // start skew (see kernel): one tile period (~3600 cycles per K-tile + epilogue) when every
   // workgroup has >= 8 tiles, so the skewed tail costs < 1/8 of the launch.
   p.skew_cycles = (km && g_skew > 1 && nwork >= 8 * 256) ? nk * 3600 + 3000 : 0;
+  p.skew_mode = 0;
+  if (km && g_skew_pct > 0 && nwork > 256) {
+    p.skew_cycles = (int)((long)(nk * 3600 + 12000) * g_skew_pct / 100);
+    p.skew_mode = g_skew_mode;
+  }
+  p.nt = g_nt;
+  p.pre_issue = g_pre;
+  p.dbg = nullptr;
   dim3 grid(nwork < 256 ? nwork : 256), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
   if (!km) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
@@ -666,6 +776,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   else if (epilogue == BV_EPI_POS) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_POS, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_BWD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD, false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_GELU_BWD_EMIT) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD_EMIT, false>), grid, block, 0, s, p);
   else if (out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, false>), grid, block, 0, s, p);
   if (use_slab)

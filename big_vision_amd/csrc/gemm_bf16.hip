@@ -228,13 +228,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         const float4 x = *reinterpret_cast<const float4*>(
             reinterpret_cast<const float*>(p.aux) + (long)(m % p.aux_rows) * p.ldaux + n);
         v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
-      } else if (epi == BV_EPI_GELU_BWD) {
+      } else if (epi == BV_EPI_GELU_BWD || epi == BV_EPI_GELU_BWD_EMIT) {
         const uint2 h = *reinterpret_cast<const uint2*>(
             reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + n);
-        v[0] *= gelu_tanh_grad_f(bflo(h.x));
-        v[1] *= gelu_tanh_grad_f(bfhi(h.x));
-        v[2] *= gelu_tanh_grad_f(bflo(h.y));
-        v[3] *= gelu_tanh_grad_f(bfhi(h.y));
+        float g[4], d[4];
+        gelu_tanh_val_grad_f(bflo(h.x), g[0], d[0]);
+        gelu_tanh_val_grad_f(bfhi(h.x), g[1], d[1]);
+        gelu_tanh_val_grad_f(bflo(h.y), g[2], d[2]);
+        gelu_tanh_val_grad_f(bfhi(h.y), g[3], d[3]);
+        if (epi == BV_EPI_GELU_BWD_EMIT) {
+          uint2 go;
+          go.x = pack_bf2(g[0], g[1]);
+          go.y = pack_bf2(g[2], g[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + n) = go;
+        }
+        v[0] *= d[0]; v[1] *= d[1]; v[2] *= d[2]; v[3] *= d[3];
       }
       if (p.out_f32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) =
@@ -244,10 +252,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         o.x = pack_bf2(v[0], v[1]);
         o.y = pack_bf2(v[2], v[3]);
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
-        if (epi == BV_EPI_GELU) {
+        if (epi == BV_EPI_GELU) {   // gelu of the bf16-rounded pre-activation that is stored
           uint2 g;
-          g.x = pack_bf2(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]));
-          g.y = pack_bf2(gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+          g.x = pack_bf2(gelu_tanh_f(bflo(o.x)), gelu_tanh_f(bfhi(o.x)));
+          g.y = pack_bf2(gelu_tanh_f(bflo(o.y)), gelu_tanh_f(bfhi(o.y)));
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + n) = g;
         }
       }
@@ -283,12 +291,14 @@ extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda,
              "bv_gemm_bf16: B contiguous dim / ldb must be multiples of 8 (N=%d K=%d ldb=%ld)", N, K, ldb);
   BV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0),
              "bv_gemm_bf16: operand pointers must be 16-byte aligned");
-  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_ATOMIC, "bv_gemm_bf16: bad epilogue %d", epilogue);
+  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_GELU_BWD_EMIT, "bv_gemm_bf16: bad epilogue %d", epilogue);
   BV_REQUIRE(ldc % 4 == 0, "bv_gemm_bf16: ldc=%ld must be a multiple of 4", ldc);
-  if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_GELU_BWD)
+  if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_GELU_BWD ||
+      epilogue == BV_EPI_GELU_BWD_EMIT)
     BV_REQUIRE(aux != nullptr && ldaux % 4 == 0, "bv_gemm_bf16: epilogue %d needs aux (ldaux %% 4 == 0)", epilogue);
   if (epilogue == BV_EPI_POS) BV_REQUIRE(aux_rows > 0, "bv_gemm_bf16: POS epilogue needs aux_rows > 0");
-  if (epilogue == BV_EPI_GELU) BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: GELU epilogue needs bf16 C and C2");
+  if (epilogue == BV_EPI_GELU || epilogue == BV_EPI_GELU_BWD_EMIT)
+    BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: epilogue %d needs bf16 C and C2", epilogue);
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");

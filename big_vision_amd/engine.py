@@ -188,19 +188,27 @@ class MLP:
     self.w2 = _W(store, f"{prefix}/Dense_1/kernel"); self.b2 = _W(store, f"{prefix}/Dense_1/bias")
     self.M = M
 
-  def fwd(self, y_bf, resid):
-    """resid + fc2(gelu(fc1(y))) ; returns (out f32, h_pre bf16, g bf16)."""
+  def fwd(self, y_bf, resid, keep_g=True):
+    """resid + fc2(gelu(fc1(y))) ; returns (out f32, h_pre bf16, g bf16 or None)."""
     g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
     h = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
     out = linear_fwd(g, self.w2, self.b2, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=resid)
-    return out, h, g
+    return out, h, (g if keep_g else None)
 
   def bwd(self, dout_f32, dout_bf, y_bf, h, g, bias2_done=False):
     """Returns dy (bf16) = gradient w.r.t. the MLP input y.  bias2_done: the Dense_1 bias
     gradient (column sums of dout) was already accumulated by the LayerNorm-backward kernel
-    that produced dout (bv_layernorm_bwd dx_colsum)."""
-    linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
-    dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h)
+    that produced dout (bv_layernorm_bwd dx_colsum).  g = None ("light" context): the
+    activation gelu(h) was not kept; the dX GEMM that needs gelu'(h) anyway re-emits it
+    (BV_EPI_GELU_BWD_EMIT, bit-identical to the forward's g)."""
+    if g is None:
+      g = torch.empty_like(h)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g)
+      linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
+      del g
+    else:
+      linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h)
     linear_bwd_w(y_bf, dh, self.w1, self.b1)
     return linear_bwd_x(dh, self.w1)
 
@@ -220,14 +228,19 @@ class Block:
     self.bo = _W(store, f"{A}/out/bias")
     self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
 
-  def fwd(self, x, n, L):
+  def fwd(self, x, n, L, light=False):
+    """light: the saved context drops what the backward can re-derive cheaply - the two
+    LayerNorm outputs (re-normalised from x / x1) and gelu(h) (re-emitted by the fc2 dX
+    GEMM) - one third of the block's activation bytes."""
     T, D, H = n * L, self.D, self.H
     y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
     o, lse = ops.attn_fwd(qkv, n, L, H)
     x1 = linear_fwd(o, self.wo, self.bo, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=x)
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
-    x2, h, g = self.mlp.fwd(y1, x1)
+    x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light)
+    if light:
+      y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
   def bwd(self, saved, dx2, dx2_bf, n, L, b2_done=False, next_b2=None):
@@ -236,13 +249,19 @@ class Block:
     LayerNorm_0 backward that produces that block's dx2 (bias grads = column sums of dx)."""
     x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g = saved
     T, D, H = n * L, self.D, self.H
+    if y1 is None:   # light context: same kernel, same input -> the forward's y1 bit for bit
+      y1 = self.ln1.fwd(x1, T, D)[0]
     dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g, bias2_done=b2_done)
+    del y1
     dx1_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
     dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad)
     linear_bwd_w(o, dx1_bf, self.wo, None)      # out-proj bias grad = colsum(dx1): fused above
     d_o = linear_bwd_x(dx1_bf, self.wo)
     dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+    if y0 is None:
+      y0 = self.ln0.fwd(x, T, D)[0]
     linear_bwd_w(y0, dqkv, self.wqkv, self.bqkv)
+    del y0
     dy0 = linear_bwd_x(dqkv, self.wqkv)
     dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
     dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf, dx_colsum=next_b2)
@@ -262,7 +281,7 @@ class Encoder:
     saved = []
     for i, blk in enumerate(self.blocks):
       x_in = x
-      x, s = blk.fwd(x, n, L)
+      x, s = blk.fwd(x, n, L, light=(save == "light"))
       if save:
         saved.append(s)
       if out is not None:

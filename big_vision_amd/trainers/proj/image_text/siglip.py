@@ -83,7 +83,7 @@ def make_update_fn(model, config, comm=None):
   comm = comm or dp.Comm()
   assert "mixup" not in config, "Mixup is not supported for SigLIP."
   micro = int(config.get("microbatch", 0) or 0)
-  state_cache = {"keep_n": 1}
+  state_cache = {"keep_n": 0, "light": None, "per_ctx": {}}
 
   def update_fn(train_state, rng, batch):
     del rng  # dropout is 0 on this path; kept for signature parity
@@ -104,36 +104,59 @@ def make_update_fn(model, config, comm=None):
       # Pass 1: embeddings of all micro-batches.  The sigmoid loss couples the whole batch,
       # so every tower backward has to wait for all embeddings.  The activations of as many
       # micro-batches as fit in HBM (288 GB on MI355X) are KEPT; only the rest is recomputed
-      # in pass 2 (a pure memory/compute trade: results are identical either way).
+      # in pass 2 (a pure memory/compute trade: results are identical either way).  When the
+      # full contexts do not all fit, "light" contexts are kept instead (engine.Block.fwd:
+      # LayerNorm outputs and gelu(h) are re-derived by the backward, 1/3 fewer bytes).
       starts = list(range(0, n, micro))
+      dev = images.device
       keep_cfg = config.get("microbatch_keep", "auto")
-      keep_n = len(starts) if keep_cfg == "all" else (0 if keep_cfg in (0, "none") else None)
-      if isinstance(keep_cfg, int) and keep_cfg > 0:
-        keep_n = keep_cfg
+      keep_max = len(starts) if keep_cfg in ("all", "auto") else (0 if keep_cfg in (0, "none") else int(keep_cfg))
+      light_cfg = config.get("microbatch_light", "auto")
+      total_mem = torch.cuda.mem_get_info(dev)[1]
+      margin = int(0.06 * total_mem)   # pass-2 transients + allocator slack
+
+      def headroom():
+        free, _ = torch.cuda.mem_get_info(dev)
+        return free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+
+      def fits(per_ctx, count):
+        return headroom() - margin >= count * (per_ctx + per_ctx // 32)
+
+      if state_cache["light"] is None:
+        state_cache["light"] = bool(light_cfg) if light_cfg != "auto" else None
       zi, zt, kept = [], [], {}
       for k, s in enumerate(starts):
-        keep = (keep_n is None and k == 0) or (keep_n is not None and len(kept) < keep_n)
-        if keep_n is None and k > 0:
-          keep = len(kept) < state_cache["keep_n"]
-        before = torch.cuda.memory_allocated(images.device)
-        a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=keep)
+        mode = "light" if state_cache["light"] else True
+        per_ctx = state_cache["per_ctx"].get(mode)
+        keep = len(kept) < keep_max and (per_ctx is None or keep_cfg == "all" or fits(per_ctx, 1))
+        before = torch.cuda.memory_allocated(dev)
+        a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=(mode if keep else False))
+        if keep and per_ctx is None:
+          per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
+          if state_cache["light"] is None:
+            # first step, "auto": stay with full contexts only if all of them fit
+            state_cache["light"] = keep_max > 1 and not fits(per_ctx, min(keep_max, len(starts)) - 1)
+            if state_cache["light"]:
+              del c
+              mode = "light"
+              before = torch.cuda.memory_allocated(dev)
+              a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=mode)
+              state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
         if keep:
           kept[s] = c
-          if keep_n is None and k == 0:
-            per_ctx = max(1, torch.cuda.memory_allocated(images.device) - before)
-            free, total = torch.cuda.mem_get_info(images.device)
-            reserved_slack = torch.cuda.memory_reserved(images.device) - torch.cuda.memory_allocated(images.device)
-            budget = max(0, free + reserved_slack - int(0.12 * total))   # leave 12 % of HBM untouched
-            state_cache["keep_n"] = 1 + int(budget // (per_ctx + per_ctx // 8))
+        del c
         zi.append(a); zt.append(b)
+      state_cache["keep_n"] = len(kept)
       zimg, ztxt = torch.cat(zi), torch.cat(zt)
       stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
       # Pass 2: back-propagate every micro-batch's slice of the embedding gradients (grads
-      # accumulate in the flat buffer); recompute the forward where it was not kept.
+      # accumulate in the flat buffer); recompute the forward where it was not kept (those are
+      # the LAST micro-batches: by then the kept contexts have been consumed and freed).
       for s in starts:
         ctx = kept.pop(s, None)
         if ctx is None:
-          _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro], save=True)
+          _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro],
+                                save=("light" if state_cache["light"] else True))
         ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
                None if txt_frozen else dztxt[s:s + micro].contiguous())
         del ctx

@@ -55,9 +55,13 @@ int bv_version(void);
 #define BV_EPI_NONE 0
 #define BV_EPI_RESIDUAL 1 /* C(f32) += aux(f32)[m,n]           (x + f(x), vit.py:101,110)   */
 #define BV_EPI_POS 2      /* C(f32) += aux(f32)[m % aux_rows,n] (posemb add, vit.py:220-221) */
-#define BV_EPI_GELU 3     /* C(bf16)=pre-activation, C2(bf16)=gelu_tanh(pre) (vit.py:75)    */
+#define BV_EPI_GELU 3     /* C(bf16)=pre-activation h, C2(bf16)=gelu_tanh(h) (vit.py:75); the
+                             activation is applied to the bf16-rounded h that is stored     */
 #define BV_EPI_GELU_BWD 4 /* C *= gelu_tanh'(aux(bf16)[m,n])   (backward of vit.py:75)      */
 #define BV_EPI_ATOMIC 5   /* C(f32) += result via fp32 atomics; split-K over K              */
+#define BV_EPI_GELU_BWD_EMIT 6 /* GELU_BWD, and C2(bf16) = gelu_tanh(aux): the activation is
+                             recomputed by the backward instead of being kept (bit-identical
+                             to what BV_EPI_GELU wrote)                                      */
 int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
@@ -76,6 +80,16 @@ int bv_set_workspace(void* ptr, long bytes);
  * general 128x128x64 kernel) and bv_attn_fwd/bwd use the LDS-resident kernels.
  * enable = 0/1 sets the switch, -1 only queries; returns the old value. */
 int bv_gemm_fast_path(int enable);
+
+/* Tuning knobs of the 256x256 k-major kernel (diagnostics / A-B benchmarking; negative =
+ * leave unchanged): nt bit 0 = streaming (nontemporal) stores of C/C2, bit 1 = streaming
+ * loads of aux; skew_mode 0/1 = start phase per XCD / per workgroup, skew_pct = spread of
+ * the workgroups' start as a percentage of one tile period (0 = off). */
+int bv_gemm_tune(int nt, int skew_mode, int skew_pct);
+/* 1 (default): the persistent 256x256 kernel issues the next tile's K-tile 1/2 loads ahead of
+ * the epilogue's stores (same in-order VMEM queue) and leaves the stores outstanding at the
+ * next tile's first counted wait.  enable = 0/1 sets, -1 queries; returns the old value. */
+int bv_gemm_pre_issue(int enable);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,

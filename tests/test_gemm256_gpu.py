@@ -87,6 +87,14 @@ def test_nt_epilogues(dev, fast):
   ref = (x.float() @ w.float().T) * hf.grad
   out = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=hh, **kw)
   close(out, ref, 1e-2, 2e-2, "gelu bwd")
+  # GELU_BWD_EMIT: same dX, and C2 = gelu(aux) with the bits the forward epilogue produces
+  g2 = torch.empty((M, N), device=dev, dtype=BF16)
+  out2 = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=hh, out2=g2, **kw)
+  close(out2, ref, 1e-2, 2e-2, "gelu bwd (emit)")
+  close(g2, torch.nn.functional.gelu(hh.float(), approximate="tanh"), 1e-2, 1e-2, "emitted gelu")
+  g3 = torch.empty((M, N), device=dev, dtype=BF16)
+  ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g3, **kw)
+  assert torch.equal(g3, g), "gelu(h) re-emitted by the backward differs from the forward's"
   y = ops.gemm(x, w, out_dtype=BF16, alpha=0.5, **kw)
   close(y, 0.5 * (x.float() @ w.float().T), 1e-2, 1e-2, "alpha")
 

@@ -96,6 +96,14 @@ def test_gemm_epilogues(dev):
   out = ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16,
                  epilogue=ops.EPI_GELU_BWD, aux=hh)
   assert_close(out, ref, 1e-2, 2e-2, "gelu bwd")
+  g2 = torch.empty((M, N), device=dev, dtype=BF16)
+  out2 = ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16,
+                  epilogue=ops.EPI_GELU_BWD_EMIT, aux=hh, out2=g2)
+  assert_close(out2, ref, 1e-2, 2e-2, "gelu bwd (emit)")
+  assert_close(g2, torch.nn.functional.gelu(hh.float(), approximate="tanh"), 1e-2, 1e-2, "emitted gelu")
+  g3 = torch.empty((M, N), device=dev, dtype=BF16)
+  ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g3)
+  assert torch.equal(g3, g), "gelu(h) re-emitted by the backward differs from the forward's"
 
 
 def test_gemm_rejects_bad_args(dev):

@@ -124,10 +124,14 @@ def test_b16_siglip_step_small_batch(dev):
   _run_case(dev, image_cfg, text_cfg, E=768, n=4, res=224, seq=64, vocab=32_000)
 
 
-@pytest.mark.parametrize("keep", [0, 1, "all", "auto"])
-def test_microbatched_step_equals_full_batch(dev, keep):
-  """Two-pass micro-batching (config.microbatch / microbatch_keep) is a pure memory/compute
-  trade: loss and gradients must match the single-pass step on the same batch."""
+@pytest.mark.parametrize("keep,light", [(0, False), (1, False), ("all", False), ("auto", "auto"),
+                                        ("all", True), (2, True)])
+def test_microbatched_step_equals_full_batch(dev, keep, light):
+  """Two-pass micro-batching (config.microbatch / microbatch_keep / microbatch_light) is a
+  pure memory/compute trade: loss and gradients must match the single-pass step on the same
+  batch; "light" contexts (LayerNorm outputs and gelu(h) re-derived by the backward) feed the
+  backward the same bits as full contexts, so the gradients agree to fp32 accumulation-order
+  noise (LayerNorm scale/bias and bias gradients are summed with fp32 atomics)."""
   import bv_oracle as O
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
@@ -149,8 +153,14 @@ def test_microbatched_step_equals_full_batch(dev, keep):
     return meas["training_loss"].item(), grads
 
   loss_full, g_full = run()
-  loss_mb, g_mb = run(microbatch=2, microbatch_keep=keep)
+  loss_mb, g_mb = run(microbatch=2, microbatch_keep=keep, microbatch_light=light)
   assert abs(loss_full - loss_mb) <= 1e-5 * abs(loss_full)
   gn = math.sqrt(sum((v ** 2).sum().item() for v in g_full.values()))
   for k, v in g_full.items():
     assert (v - g_mb[k]).norm().item() <= 2e-3 * max(v.norm().item(), 1e-3 * gn), k
+  if light is True:
+    loss_ref, g_ref = run(microbatch=2, microbatch_keep=keep, microbatch_light=False)
+    assert loss_ref == loss_mb
+    for k, v in g_ref.items():
+      assert (v - g_mb[k]).norm().item() <= 1e-5 * max(v.norm().item(), 1e-3 * gn), \
+          f"light context changed {k}"

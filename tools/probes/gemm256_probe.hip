@@ -27,6 +27,15 @@ static float run(G256Params p, int grid, int iters) {
   return ms / iters;
 }
 
+static long* g_dbg = nullptr;
+// average shader clock over the last launch (block 0): d(s_memtime) / d(s_memrealtime @100 MHz)
+static void report_clock(const char* what) {
+  long h[4];
+  hipMemcpy(h, g_dbg, sizeof(h), hipMemcpyDeviceToHost);
+  const double cyc = (double)(h[2] - h[0]), ref = (double)(h[3] - h[1]);
+  printf("      [%s] block 0: %.0f shader cycles in %.1f us -> %.0f MHz\n", what, cyc, ref / 100.0, cyc / ref * 100.0);
+}
+
 static void fill(void* d, size_t n_bf16) {
   std::vector<unsigned short> h(n_bf16);
   unsigned s = 12345;
@@ -48,6 +57,7 @@ int main() {
   printf("malloc: %d %d %d %d  %p %p %p %p\n", e1, e2, e3, e4, x, y, w, c); fflush(stdout);
   fill(x, (size_t)T * 3072); fill(y, (size_t)T * 3072); fill(w, (size_t)3072 * 3072);
   hipMemset(c, 0, (size_t)T * 3072 * 4);
+  hipMalloc(&g_dbg, 4096 * sizeof(long)); hipMemset(g_dbg, 0, 4096 * sizeof(long));
   for (auto& s : shapes) {
     const double fl = 2.0 * T * s.in * s.out;
     {  // TN: dW[in][out] = X^T dY, split-K atomics
@@ -77,8 +87,36 @@ int main() {
       p.splits = 1;
       const int grid = p.ntiles < 256 ? p.ntiles : 256;
       float t0 = run<true, 0>(p, grid, 5), t1 = run<true, 1>(p, grid, 5), t3 = run<true, 3>(p, grid, 5), t4 = run<true, 5>(p, grid, 5);
-      printf("NT %-4s grid %4d: full %.3f ms %6.0f TF | noLDSread %.3f | noDMA %.3f | noStores %.3f\n", s.name, grid,
-             t0, fl / t0 / 1e9, t1, t3, t4);
+      {
+        float t7 = run<true, 7>(p, grid, 5);
+        printf("NT %-4s stores into an L2-resident 64 KiB per block: %.3f ms %6.0f TF (full %.3f, noStores %.3f)\n", s.name, t7, fl / t7 / 1e9, t0, t4);
+      }
+      p.dbg = g_dbg;
+      float t6 = run<true, 6>(p, grid, 5);
+      printf("   nontemporal stores: %.3f ms %6.0f TF\n", t6, fl / t6 / 1e9);
+      report_clock("nt stores");
+      run<true, 8>(p, grid, 5); report_clock("full");
+      if (s.in == 768) {
+        run<true, 9>(p, grid, 1);
+        std::vector<long> st(3072);
+        hipMemcpy(st.data(), g_dbg, 3072 * sizeof(long), hipMemcpyDeviceToHost);
+        const int nk = s.in / 64, per = nk + 2;
+        for (int b = 0; b < 2; ++b) {
+          const long* q = st.data() + 1024 + b * 1024;
+          printf("      [stamps block %d] per tile: K-tile durations | epilogue | (cycles)\n", b);
+          long prev = st[b * 4 + 0];
+          for (int t = 0; t < 6; ++t) {
+            printf("        tile %d (start +%ld):", t, q[t * per] - st[b * 4 + 0]);
+            for (int i = 0; i < per; ++i) { printf(" %ld", q[t * per + i] - prev); prev = q[t * per + i]; }
+            printf("\n");
+          }
+        }
+      }
+      run<true, 5>(p, grid, 5); report_clock("no stores");
+      run<true, 3>(p, grid, 5); report_clock("no DMA");
+      run<true, 1>(p, grid, 5); report_clock("no LDS reads");
+      p.dbg = nullptr;
+      p.skew_cycles = 0; p.skew_mode = 0;
     }
   }
   return 0;
