@@ -24,6 +24,8 @@ PROTOTYPES = {
     "bv_version": [],
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
                      c_int, P, P, c_long, c_int, P, c_float, c_int, P],
+    "bv_gemm_bf16_colsum": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
+                            c_int, P, P, c_long, c_int, P, c_float, c_int, P, P],
     "bv_gemm_fast_path": [c_int],
     "bv_gemm_tune": [c_int, c_int, c_int],
     "bv_gemm_pre_issue": [c_int],

@@ -84,24 +84,62 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
   }
 }
 
+// dtable[ids[r]] += dx[r].  Token ids repeat heavily (sticky EOS / padding: pp/ops_text.py:143-155
+// makes about half of all positions the same id), so plain per-row atomics serialise on a few
+// table rows.  Each workgroup takes EB_ROWS consecutive rows, links the rows that share an id
+// into chains (LDS), sums every chain in registers and issues ONE atomic add per distinct id,
+// column and workgroup.
+constexpr int EB_ROWS = 64;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ ids,
                                                         const float* __restrict__ dx,
                                                         float* __restrict__ dtable, long rows,
                                                         int D, int vocab) {
-  const int lane = threadIdx.x & 63;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long nw = (long)gridDim.x * 4;
-  for (long r = wave; r < rows; r += nw) {
-    int id = ids[r];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    float* dst = dtable + (long)id * D;
-    const float* src = dx + r * D;
-    for (int c = lane * 4; c < D; c += 256) {
-      const float4 a = *reinterpret_cast<const float4*>(src + c);
-      unsafeAtomicAdd(dst + c + 0, a.x);
-      unsafeAtomicAdd(dst + c + 1, a.y);
-      unsafeAtomicAdd(dst + c + 2, a.z);
-      unsafeAtomicAdd(dst + c + 3, a.w);
+  __shared__ int sid[EB_ROWS];
+  __shared__ int nxt[EB_ROWS];    // next row of the chunk with the same id (-1: end of chain)
+  __shared__ int head[EB_ROWS];   // 1: first row of its chain
+  const int tid = threadIdx.x;
+  const long r0 = (long)blockIdx.x * EB_ROWS;
+  const int nr = (int)min((long)EB_ROWS, rows - r0);
+  if (tid < EB_ROWS) {
+    int id = tid < nr ? ids[r0 + tid] : -1;
+    if (tid < nr) id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    sid[tid] = id;
+    nxt[tid] = -1;
+  }
+  __syncthreads();
+  if (tid < nr) {
+    const int me = sid[tid];
+    int prev = -1;
+    for (int j = tid - 1; j >= 0; --j)
+      if (sid[j] == me) { prev = j; break; }
+    head[tid] = prev < 0;
+    if (prev >= 0) nxt[prev] = tid;   // unique writer: a row has at most one successor
+  }
+  __syncthreads();
+  const float* base = dx + r0 * D;
+  for (int c = tid * 4; c < D; c += 1024) {
+    for (int r = 0; r < nr; ++r) {
+      if (!head[r]) continue;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int q = r;
+      while (q >= 0) {   // up to 4 independent row loads in flight per step
+        const int q1 = nxt[q], q2 = q1 >= 0 ? nxt[q1] : -1, q3 = q2 >= 0 ? nxt[q2] : -1;
+        const float4 a0 = *reinterpret_cast<const float4*>(base + (long)q * D + c);
+        float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1, a3 = a1;
+        if (q1 >= 0) a1 = *reinterpret_cast<const float4*>(base + (long)q1 * D + c);
+        if (q2 >= 0) a2 = *reinterpret_cast<const float4*>(base + (long)q2 * D + c);
+        if (q3 >= 0) a3 = *reinterpret_cast<const float4*>(base + (long)q3 * D + c);
+        acc.x += (a0.x + a1.x) + (a2.x + a3.x);
+        acc.y += (a0.y + a1.y) + (a2.y + a3.y);
+        acc.z += (a0.z + a1.z) + (a2.z + a3.z);
+        acc.w += (a0.w + a1.w) + (a2.w + a3.w);
+        q = q3 >= 0 ? nxt[q3] : -1;
+      }
+      float* dst = dtable + (long)sid[r] * D + c;
+      unsafeAtomicAdd(dst + 0, acc.x);
+      unsafeAtomicAdd(dst + 1, acc.y);
+      unsafeAtomicAdd(dst + 2, acc.z);
+      unsafeAtomicAdd(dst + 3, acc.w);
     }
   }
 }
@@ -336,7 +374,7 @@ extern "C" int bv_embed_fwd(const int* ids, const float* table, const float* pos
 extern "C" int bv_embed_bwd(const int* ids, const float* dx, float* dtable, int rows, int D, int vocab,
                             void* stream) {
   BV_REQUIRE(rows > 0 && D % 4 == 0 && vocab > 0, "bv_embed_bwd: bad shape rows=%d D=%d", rows, D);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((rows + EB_ROWS - 1) / EB_ROWS), dim3(256), 0, (hipStream_t)stream,
                      ids, dx, dtable, (long)rows, D, vocab);
   return bv_check_launch("bv_embed_bwd");
 }

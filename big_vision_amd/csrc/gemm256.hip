@@ -49,6 +49,7 @@ struct G256Params {
   void* C2;
   const float* bias;
   const void* aux;
+  float* colsum;       // GELU_BWD epilogues: colsum[n] += sum_m C[m][n] (the Dense_0 bias gradient)
   long lda, ldb, ldc, ldaux;
   int M, N, K;
   int aux_rows;
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   auto stamp = [&]() {
     if (PROBE == 9 && p.dbg && tid == 0 && bid < 2 && stamp_n < 1000)
       p.dbg[1024 + bid * 1024 + stamp_n++] = __builtin_amdgcn_s_memtime();
+  };
+  auto tstamp = [&](int jt) {
+    if (PROBE == 10 && p.dbg && tid == 0 && (bid & 7) == 0 && jt < 30)
+      p.dbg[1024 + (bid >> 3) * 32 + jt] = __builtin_amdgcn_s_memrealtime();
   };
   // All workgroups of a launch run identical tiles, so left alone they stay in lockstep
   // and hit their epilogues together: a chip-wide store burst during which nobody
@@ -476,9 +481,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       nc[j] = n0 + wc * 64 + (OUTF32 ? j * 16 + lg * 4 : (j >> 1) * 32 + lg * 8 + (j & 1) * 4);
-    float bv[16];
+    float bv[16], cs[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = 0.f;
+    for (int e = 0; e < 16; ++e) bv[e] = cs[e] = 0.f;
     if (p.bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -558,6 +563,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
             st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
           }
         }
+        if constexpr (GBWD) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) cs[e] += v[e];
+        }
         if constexpr (OUTF32) {
           float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc;
 #pragma unroll
@@ -599,6 +608,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
         }
       }
     }
+    if constexpr (GBWD) {
+      // column sums of this wave's 128 x 64 block of dX (fp32, before the bf16 rounding): reduce
+      // the 16 row lanes with DPP, one atomic per column and wave.
+      if (p.colsum) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float sum = cs[e];
+          sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+          sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+          sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x141, 0xF, 0xF, true));  // row_half_mirror
+          sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x140, 0xF, 0xF, true));  // row_mirror
+          if (lr == 0) unsafeAtomicAdd(p.colsum + nc[e >> 2] + (e & 3), sum);
+        }
+      }
+    }
   } else {
     // TN (dW): lane holds C[m][n .. n+3], m = m0 + wr*128 + i*16 + lr, n = n0 + wc*64 + j*16 + lg*4.
     if (p.slab) {
@@ -631,6 +655,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     }
   }
     stamp();
+    tstamp(jt);
     // ---- next work item: clear the accumulators, move the math cursor
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -712,7 +737,7 @@ extern "C" int bv_set_workspace(void* ptr, long bytes) {
 int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                   float alpha, int split_k, void* stream) {
+                   float alpha, int split_k, float* colsum, void* stream) {
   if (a_kmajor != b_kmajor) return 0;
   if ((M & 255) || (N & 255) || (K & 63)) return 0;
   const bool km = a_kmajor != 0;
@@ -727,7 +752,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
 
   G256Params p;
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.C2 = C2;
-  p.bias = bias; p.aux = aux;
+  p.bias = bias; p.aux = aux; p.colsum = colsum;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
   p.M = M; p.N = N; p.K = K; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
   p.epi = epilogue; p.out_f32 = out_f32; p.alpha = alpha;

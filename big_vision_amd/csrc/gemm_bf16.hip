@@ -33,6 +33,7 @@ struct GemmParams {
   void* C2;
   const float* bias;
   const void* aux;
+  float* colsum;       // optional: colsum[n] += sum_m C[m][n] (fp32, before the output rounding)
   long lda, ldb, ldc, ldaux;
   int M, N, K;
   int aux_rows;
@@ -244,6 +245,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         }
         v[0] *= d[0]; v[1] *= d[1]; v[2] *= d[2]; v[3] *= d[3];
       }
+      if (p.colsum) {   // small / ragged problems only: one atomic per element
+#pragma unroll
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(p.colsum + n + r, v[r]);
+      }
       if (p.out_f32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) =
             make_float4(v[0], v[1], v[2], v[3]);
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                   float alpha, int split_k, void* stream);
+                   float alpha, int split_k, float* colsum, void* stream);
 static int g_fast_path = 1;
 int bv_fast_path_enabled() { return g_fast_path; }
 extern "C" int bv_gemm_fast_path(int enable) {
@@ -279,10 +284,23 @@ extern "C" int bv_gemm_fast_path(int enable) {
 }
 
 // See include/bvhip.h for the contract.
+extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
+                                   long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
+                                   int epilogue, const float* bias, const void* aux, long ldaux,
+                                   int aux_rows, void* C2, float alpha, int split_k, float* colsum,
+                                   void* stream);
 extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
                             long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
                             int epilogue, const float* bias, const void* aux, long ldaux,
                             int aux_rows, void* C2, float alpha, int split_k, void* stream) {
+  return bv_gemm_bf16_colsum(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K, epilogue, bias,
+                             aux, ldaux, aux_rows, C2, alpha, split_k, nullptr, stream);
+}
+extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
+                                   long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
+                                   int epilogue, const float* bias, const void* aux, long ldaux,
+                                   int aux_rows, void* C2, float alpha, int split_k, float* colsum,
+                                   void* stream) {
   BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
   BV_REQUIRE(N % 8 == 0, "bv_gemm_bf16: N=%d must be a multiple of 8", N);
   BV_REQUIRE(a_kmajor ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0),
@@ -302,14 +320,17 @@ extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda,
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
+  if (colsum)
+    BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT,
+               "bv_gemm_bf16_colsum: column sums are fused into the GELU_BWD epilogues only (got %d)", epilogue);
 
   if (g_fast_path && bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K,
-                                     epilogue, bias, aux, ldaux, aux_rows, C2, alpha, split_k, stream))
+                                     epilogue, bias, aux, ldaux, aux_rows, C2, alpha, split_k, colsum, stream))
     return bv_check_launch("bv_gemm_bf16(256x256)");
 
   GemmParams p;
   p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C; p.C2 = C2;
-  p.bias = bias; p.aux = aux;
+  p.bias = bias; p.aux = aux; p.colsum = colsum;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
   p.M = M; p.N = N; p.K = K; p.aux_rows = aux_rows > 0 ? aux_rows : 1;
   p.epi = epilogue; p.out_f32 = out_f32; p.alpha = alpha;

@@ -201,15 +201,16 @@ class MLP:
     that produced dout (bv_layernorm_bwd dx_colsum).  g = None ("light" context): the
     activation gelu(h) was not kept; the dX GEMM that needs gelu'(h) anyway re-emits it
     (BV_EPI_GELU_BWD_EMIT, bit-identical to the forward's g)."""
+    # The Dense_0 bias gradient (column sums of dh) is reduced inside the same epilogue.
     if g is None:
       g = torch.empty_like(h)
-      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g, colsum=self.b1.grad)
       linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
       del g
     else:
       linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
-      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h)
-    linear_bwd_w(y_bf, dh, self.w1, self.b1)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h, colsum=self.b1.grad)
+    linear_bwd_w(y_bf, dh, self.w1, None)
     return linear_bwd_x(dh, self.w1)
 
 

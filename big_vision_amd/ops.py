@@ -50,8 +50,10 @@ def _ensure_workspace(device):
 
 # ------------------------------------------------------------------- GEMMs --
 def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=None, N=None, K=None,
-         epilogue=EPI_NONE, bias=None, aux=None, aux_rows=0, out2=None, alpha=1.0, split_k=0):
+         epilogue=EPI_NONE, bias=None, aux=None, aux_rows=0, out2=None, alpha=1.0, split_k=0,
+         colsum=None):
   """C[M,N] = A(MxK) B(KxN) with bf16 inputs; see bv_gemm_bf16 in include/bvhip.h.
+  colsum (fp32 [N], GELU_BWD epilogues): += column sums of C (bv_gemm_bf16_colsum).
 
   a: [M,K] if a_kmajor else [K,M];  b: [N,K] if b_kmajor else [K,N].
   """
@@ -74,6 +76,12 @@ def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=Non
     _chk(bias, F32, "gemm.bias")
   if epilogue == EPI_ATOMIC:
     _ensure_workspace(a.device)
+  if colsum is not None:
+    _chk(colsum, F32, "gemm.colsum")
+    _lib.call("bv_gemm_bf16_colsum", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
+              int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
+              float(alpha), split_k, _p(colsum), _stream())
+    return out
   _lib.call("bv_gemm_bf16", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
             int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
             float(alpha), split_k, _stream())

@@ -67,6 +67,15 @@ int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                  float alpha, int split_k /*0 = auto*/, void* stream);
 
+/* bv_gemm_bf16 with a fused column reduction: colsum[n] += sum_m C[m][n], taken from the fp32
+ * results before the output rounding (fp32 atomics).  Supported with the GELU_BWD epilogues:
+ * the column sums of dH are the gradient of the MlpBlock Dense_0 bias (vit.py:72), which
+ * saves a separate pass over the [tokens, mlp_dim] tensor.  colsum = NULL: plain bv_gemm_bf16. */
+int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
+                        void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
+                        const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
+                        float alpha, int split_k, float* colsum, void* stream);
+
 /* Caller-provided scratch (device memory, >= 64 MiB recommended) for split-K
  * partial tiles of the weight-gradient GEMMs (EPI_ATOMIC): with a workspace the
  * partials are written with plain coalesced stores and combined by a second

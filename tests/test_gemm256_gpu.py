@@ -95,6 +95,12 @@ def test_nt_epilogues(dev, fast):
   g3 = torch.empty((M, N), device=dev, dtype=BF16)
   ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g3, **kw)
   assert torch.equal(g3, g), "gelu(h) re-emitted by the backward differs from the forward's"
+  # fused column sums (Dense_0 bias gradient) of both GELU_BWD epilogues, accumulated in place
+  for epi, extra in ((ops.EPI_GELU_BWD, {}), (ops.EPI_GELU_BWD_EMIT, dict(out2=g2))):
+    cs = torch.ones((N,), device=dev, dtype=F32)
+    o3 = ops.gemm(x, w, out_dtype=BF16, epilogue=epi, aux=hh, colsum=cs, **extra, **kw)
+    assert torch.equal(o3, out), "colsum changed the GEMM result"
+    close(cs, 1.0 + ref.sum(0), 1e-3, 1e-3 * ref.abs().sum(0).max().item(), "fused colsum")
   y = ops.gemm(x, w, out_dtype=BF16, alpha=0.5, **kw)
   close(y, 0.5 * (x.float() @ w.float().T), 1e-2, 1e-2, "alpha")
 

@@ -104,6 +104,9 @@ def test_gemm_epilogues(dev):
   g3 = torch.empty((M, N), device=dev, dtype=BF16)
   ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g3)
   assert torch.equal(g3, g), "gelu(h) re-emitted by the backward differs from the forward's"
+  cs = torch.ones((N,), device=dev, dtype=F32)
+  ops.gemm(dg_in, w2, a_kmajor=True, b_kmajor=True, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=hh, colsum=cs)
+  assert_close(cs, 1.0 + ref.sum(0), 1e-3, 1e-3 * ref.abs().sum(0).max().item(), "fused colsum")
 
 
 def test_gemm_rejects_bad_args(dev):
@@ -283,6 +286,18 @@ def test_embed(dev):
   ops.embed_bwd(ids.view(-1), dx, dt)
   ref_dt = torch.zeros((V, D), device=dev, dtype=torch.float64).index_add_(0, ids.long().view(-1), dx.double())
   assert_close(dt, ref_dt, 1e-5, 1e-5, "embed bwd")
+  # several workgroup chunks, ragged tail, D > one pass of the workgroup, out-of-range ids clamp
+  n, L, D, V = 7, 37, 1536, 23
+  ids = torch.randint(0, V, (n, L), generator=g, dtype=torch.int32)
+  ids[:, 20:] = 1
+  ids[0, 0] = -5; ids[1, 1] = V + 3
+  ids = ids.to(dev)
+  dx = rnd((n * L, D), dev, 4)
+  dt = torch.zeros((V, D), device=dev)
+  ops.embed_bwd(ids.view(-1), dx, dt)
+  idc = ids.long().view(-1).clamp(0, V - 1)
+  ref_dt = torch.zeros((V, D), device=dev, dtype=torch.float64).index_add_(0, idc, dx.double())
+  assert_close(dt, ref_dt, 1e-5, 1e-4, "embed bwd (chunks)")
 
 
 def test_reductions_and_casts(dev):

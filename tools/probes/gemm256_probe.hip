@@ -87,9 +87,23 @@ int main() {
       p.splits = 1;
       const int grid = p.ntiles < 256 ? p.ntiles : 256;
       float t0 = run<true, 0>(p, grid, 5), t1 = run<true, 1>(p, grid, 5), t3 = run<true, 3>(p, grid, 5), t4 = run<true, 5>(p, grid, 5);
-      {
-        float t7 = run<true, 7>(p, grid, 5);
-        printf("NT %-4s stores into an L2-resident 64 KiB per block: %.3f ms %6.0f TF (full %.3f, noStores %.3f)\n", s.name, t7, fl / t7 / 1e9, t0, t4);
+      if (s.in == 768 && s.out == 2304) {
+        const int period = (s.in / 64) * 2700 + 11000;
+        for (int pc = 0; pc <= 100; pc += 50) {
+          p.dbg = g_dbg; p.skew_mode = 1; p.skew_cycles = period * pc / 100; p.pre_issue = 0;
+          hipMemset(g_dbg, 0, 4096 * sizeof(long));
+          float tt = run<true, 10>(p, grid, 1);
+          std::vector<long> st(4096);
+          hipMemcpy(st.data(), g_dbg, 4096 * sizeof(long), hipMemcpyDeviceToHost);
+          printf("   skew %d%% (%.3f ms): tile-end times (us since block 0 tile 0 end) of XCD-0 blocks idx 0,8,16,24,31\n", pc, tt);
+          const long base = st[1024];
+          for (int idx : {0, 8, 16, 24, 31}) {
+            printf("     idx %2d:", idx);
+            for (int j = 0; j < 14; ++j) printf(" %6.1f", (st[1024 + idx * 32 + j] - base) / 100.0);
+            printf("\n");
+          }
+        }
+        p.skew_cycles = 0; p.dbg = nullptr;
       }
       p.dbg = g_dbg;
       float t6 = run<true, 6>(p, grid, 5);
