@@ -35,7 +35,7 @@ PROTOTYPES = {
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
-    "bv_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_patchify": [P, P, c_int, c_int, c_int, c_int, P],

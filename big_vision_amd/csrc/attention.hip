@@ -520,8 +520,9 @@ int launch_bwd(const void* qkv, const void* d_o, const float* lse, const float* 
 // fallback selected by bv_gemm_fast_path(0).
 int bv_attn2_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
 int bv_attn2_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                 void* dqkv, int n, int L, int H, void* stream);
+                 void* dqkv, float* dbias, int n, int L, int H, void* stream);
 int bv_fast_path_enabled();
+extern "C" int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int cols, void* stream);
 
 extern "C" int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_fwd: bad shape n=%d L=%d H=%d", n, L, H);
@@ -536,20 +537,27 @@ extern "C" int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, i
 }
 
 extern "C" int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse,
-                           float* delta, void* dqkv, int n, int L, int H, void* stream) {
+                           float* delta, void* dqkv, float* dbias_rows, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_bwd: L=%d > 576 not supported", L);
-  if (bv_fast_path_enabled()) return bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, n, L, H, stream);
+  if (bv_fast_path_enabled()) return bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, dbias_rows, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * L * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                      (const bf16*)o, (const bf16*)d_o, delta, n, L, H);
   int rc = bv_check_launch("bv_attn_bwd(delta)");
   if (rc) return rc;
-  if (L <= 64) return launch_bwd<4>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  if (L <= 224) return launch_bwd<14>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  if (L <= 448) return launch_bwd<28>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  return launch_bwd<36>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  if (L <= 64) rc = launch_bwd<4>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  else if (L <= 224) rc = launch_bwd<14>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  else if (L <= 448) rc = launch_bwd<28>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  else rc = launch_bwd<36>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  if (rc || !dbias_rows) return rc;
+  // general path: per-sample column sums with the stand-alone reduction
+  (void)hipMemsetAsync(dbias_rows, 0, sizeof(float) * (size_t)n * 3 * H * 64, s);
+  for (int i = 0; i < n && !rc; ++i)
+    rc = bv_colsum((const bf16*)dqkv + (long)i * L * 3 * H * 64, 0, 3L * H * 64, dbias_rows + (long)i * 3 * H * 64, L,
+                   3 * H * 64, stream);
+  return rc;
 }
 
 extern "C" int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int L, int H,

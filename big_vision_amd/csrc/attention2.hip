@@ -113,6 +113,15 @@ __device__ __forceinline__ float xsum4(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// sum over the 16 lanes of a DPP row (lanes with the same lane>>4); every lane gets the total
+__device__ __forceinline__ float rowsum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // ------------------------------------------------------------------ forward --
 template <int KF, int QF>
 __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16* __restrict__ qkv,
@@ -219,38 +228,15 @@ __global__ __launch_bounds__(256, 2) void attn2_fwd_kernel(const bf16* __restric
   }
 }
 
-// -------------------------------------------------------------------- delta --
-__global__ __launch_bounds__(256) void attn2_delta_kernel(const bf16* __restrict__ o,
-                                                          const bf16* __restrict__ d_o,
-                                                          float* __restrict__ delta, int n, int L,
-                                                          int H) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // (t, h)
-  const long total = (long)n * L * H;
-  if (idx >= total) return;
-  const long t = idx / H;
-  const int h = (int)(idx - t * H);
-  const uint4* po = reinterpret_cast<const uint4*>(o + idx * DH);
-  const uint4* pd = reinterpret_cast<const uint4*>(d_o + idx * DH);
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint4 a = po[c], b = pd[c];
-    acc += bflo(a.x) * bflo(b.x) + bfhi(a.x) * bfhi(b.x) + bflo(a.y) * bflo(b.y) +
-           bfhi(a.y) * bfhi(b.y) + bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) +
-           bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
-  }
-  const long i = t / L;
-  const int l = (int)(t - i * L);
-  delta[(i * H + h) * L + l] = acc;
-}
-
 // ------------------------------------------------------------- backward: dQ --
 template <int KF, int QF>
 __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __restrict__ qkv,
+                                                              const bf16* __restrict__ o,
                                                               const bf16* __restrict__ d_o,
                                                               const float* __restrict__ lse,
-                                                              const float* __restrict__ delta,
-                                                              bf16* __restrict__ dqkv, int L, int H,
+                                                              float* __restrict__ delta,
+                                                              bf16* __restrict__ dqkv,
+                                                              float* __restrict__ dbias, int L, int H,
                                                               float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
@@ -263,9 +249,13 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __rest
   const bf16* kb_ = qb_ + (long)H * DH;
   const bf16* vb_ = qb_ + 2L * H * DH;
   const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+  const bf16* ob_ = o + (long)i * L * ldo + h * DH;
   t64_stage2<KF * 16>(Kt, kb_, ld, Vt, vb_, ld, L, tid);
   __syncthreads();
   const float c = scale * LOG2E;
+  f32x4 cq[4];   // per-lane partial column sums of dQ (query-bias gradient), rows >= L contribute 0
+#pragma unroll
+  for (int d = 0; d < 4; ++d) cq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int blk = wave; blk * QF * 16 < L; blk += 4) {
     bf16x8 q[QF][2], g[QF][2];
@@ -278,11 +268,16 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __rest
       g[u][0] = gfrag(dob_, ldo, qrow, L, lg * 8);
       g[u][1] = gfrag(dob_, ldo, qrow, L, 32 + lg * 8);
       lse2[u] = INFINITY;
-      del[u] = 0.f;
-      if (qrow < L) {
-        lse2[u] = lse[((long)i * H + h) * L + qrow] * LOG2E;
-        del[u] = delta[((long)i * H + h) * L + qrow];
-      }
+      if (qrow < L) lse2[u] = lse[((long)i * H + h) * L + qrow] * LOG2E;
+      // delta = rowsum(dO o O) of this query row, computed here from the dO fragments the lane
+      // holds anyway (4 lanes x 16 columns per row) and published for the dK,dV pass.
+      const bf16x8 o0 = gfrag(ob_, ldo, qrow, L, lg * 8), o1 = gfrag(ob_, ldo, qrow, L, 32 + lg * 8);
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        dsum += (float)g[u][0][e] * (float)o0[e] + (float)g[u][1][e] * (float)o1[e];
+      del[u] = xsum4(dsum);
+      if (lg == 0 && qrow < L) delta[((long)i * H + h) * L + qrow] = del[u];
     }
     f32x4 dq[QF][4];
 #pragma unroll
@@ -325,6 +320,8 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __rest
 #pragma unroll
     for (int u = 0; u < QF; ++u) {
       const int qrow = (blk * QF + u) * 16 + lr;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) cq[d] += dq[u][d];   // padded query rows are exactly 0
       if (qrow < L) {
         bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
 #pragma unroll
@@ -337,6 +334,22 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dq_kernel(const bf16* __rest
       }
     }
   }
+  if (dbias) {
+    // per-(sample, head) column sums of dQ (fp32, before the bf16 rounding) -> dbias[i][0][h][:];
+    // the 4 waves are combined through LDS (the K tile is dead), the host sums over samples.
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][64]
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = rowsum16(cq[d][r]) * scale;
+        if (lr == 0) red[wave * 64 + d * 16 + lg * 4 + r] = t;
+      }
+    __syncthreads();
+    if (tid < 64)
+      dbias[((long)i * 3 * H + h) * DH + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
 }
 
 // --------------------------------------------------------- backward: dK, dV --
@@ -346,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(const bf16* __res
                                                                const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse,
                                                                const float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv, int L, int H,
+                                                               bf16* __restrict__ dqkv,
+                                                               float* __restrict__ dbias, int L, int H,
                                                                float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
@@ -369,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(const bf16* __res
   }
   __syncthreads();
   const float c = scale * LOG2E;
+  f32x4 ck[4], cv[4];   // per-lane partial column sums of dK / dV (key / value bias gradients)
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    ck[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   for (int blk = wave; blk * KB * 16 < L; blk += 4) {
     bf16x8 k[KB][2], v[KB][2];
@@ -434,11 +454,13 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(const bf16* __res
 #pragma unroll
     for (int e = 0; e < KB; ++e) {
       const int krow = (blk * KB + e) * 16 + lr;
-      if (krow < L) {
+      if (krow < L) {   // (padded key rows hold garbage: P = exp2(-lse) != 0 there)
         bf16* rowk = dqkv + ((long)i * L + krow) * ld + (long)H * DH + h * DH;
         bf16* rowv = rowk + (long)H * DH;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
+          ck[d] += dk[e][d];
+          cv[d] += dv[e][d];
           uint2 a, b;
           a.x = pack_bf2(dk[e][d][0] * scale, dk[e][d][1] * scale);
           a.y = pack_bf2(dk[e][d][2] * scale, dk[e][d][3] * scale);
@@ -448,6 +470,26 @@ __global__ __launch_bounds__(256, 2) void attn2_bwd_dkv_kernel(const bf16* __res
           *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
         }
       }
+    }
+  }
+  if (dbias) {   // dbias[i][1][h][:] (key) and dbias[i][2][h][:] (value), see the dQ kernel
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][64]
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tk = rowsum16(ck[d][r]) * scale, tv = rowsum16(cv[d][r]);
+        if (lr == 0) {
+          red[wave * 128 + d * 16 + lg * 4 + r] = tk;
+          red[wave * 128 + 64 + d * 16 + lg * 4 + r] = tv;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, d = tid & 63;
+      dbias[((long)i * 3 * H + (long)(1 + which) * H + h) * DH + d] =
+          red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
     }
   }
 }
@@ -468,18 +510,18 @@ int launch_fwd2(const void* qkv, void* o, float* lse, int n, int L, int H, hipSt
   return bv_check_launch("bv_attn_fwd");
 }
 template <int KF, int QF>
-int launch_bwd2(const void* qkv, const void* d_o, const float* lse, const float* delta, void* dqkv,
-                int n, int L, int H, hipStream_t s) {
+int launch_bwd2(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                float* dbias, int n, int L, int H, hipStream_t s) {
   const size_t sh1 = (size_t)KF * 4096;
   set_lds(attn2_bwd_dq_kernel<KF, QF>, sh1);
   hipLaunchKernelGGL((attn2_bwd_dq_kernel<KF, QF>), dim3(n * H), dim3(256), sh1, s, (const bf16*)qkv,
-                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, L, H, 0.125f);
+                     (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, L, H, 0.125f);
   int rc = bv_check_launch("bv_attn_bwd(dq)");
   if (rc) return rc;
   const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8;
   set_lds(attn2_bwd_dkv_kernel<KF, QF>, sh2);
   hipLaunchKernelGGL((attn2_bwd_dkv_kernel<KF, QF>), dim3(n * H), dim3(256), sh2, s, (const bf16*)qkv,
-                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, L, H, 0.125f);
+                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, L, H, 0.125f);
   return bv_check_launch("bv_attn_bwd(dkv)");
 }
 
@@ -495,15 +537,11 @@ int bv_attn2_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void
 }
 
 int bv_attn2_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                 void* dqkv, int n, int L, int H, void* stream) {
+                 void* dqkv, float* dbias, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)n * L * H;
-  hipLaunchKernelGGL(attn2_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                     (const bf16*)o, (const bf16*)d_o, delta, n, L, H);
-  int rc = bv_check_launch("bv_attn_bwd(delta)");
-  if (rc) return rc;
-  if (L <= 64) return launch_bwd2<4, 1>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  if (L <= 224) return launch_bwd2<14, 2>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  if (L <= 448) return launch_bwd2<28, 1>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
-  return launch_bwd2<36, 1>(qkv, d_o, lse, delta, dqkv, n, L, H, s);
+  // delta = rowsum(dO o O) is produced by the dQ pass (no separate pass over O and dO)
+  if (L <= 64) return launch_bwd2<4, 1>(qkv, o, d_o, lse, delta, dqkv, dbias, n, L, H, s);
+  if (L <= 224) return launch_bwd2<14, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, n, L, H, s);
+  if (L <= 448) return launch_bwd2<28, 1>(qkv, o, d_o, lse, delta, dqkv, dbias, n, L, H, s);
+  return launch_bwd2<36, 1>(qkv, o, d_o, lse, delta, dqkv, dbias, n, L, H, s);
 }

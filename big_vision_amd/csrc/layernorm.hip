@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <bool DY_F32>
+// NV = float4 per lane and row (D <= 256 * NV): the per-column partials live in registers, so
+// the ViT widths (768 -> 3, 1024 -> 4) get their own instantiation (3x fewer VGPRs than the
+// generic NV = 8, more rows in flight per CU).
+template <bool DY_F32, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ scale,
@@ -88,9 +91,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   const int wave_global = blockIdx.x * 4 + wave;
   const int nwaves = gridDim.x * 4;
   const float inv_d = 1.0f / (float)D;
-  float4 ps[MAXV], pb[MAXV], po[MAXV];
+  float4 ps[NV], pb[NV], po[NV];
 #pragma unroll
-  for (int it = 0; it < MAXV; ++it) {
+  for (int it = 0; it < NV; ++it) {
     ps[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     pb[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     po[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -99,10 +102,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     const long xrow = (long)r * row_stride + row_offset;
     const float* xr = x + xrow * D;
     const float mean = mean_i[r], rstd = rstd_i[r];
-    float4 g[MAXV], xh[MAXV];
+    float4 g[NV], xh[NV], dr[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = lane * 4 + it * 256;
       if (c < D) {
         float4 d;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
         const float4 xv = *reinterpret_cast<const float4*>(xr + c);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        dr[it] = dres ? *reinterpret_cast<const float4*>(dres + xrow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         xh[it] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
                              (xv.w - mean) * rstd);
         g[it] = make_float4(d.x * sc.x, d.y * sc.y, d.z * sc.z, d.w * sc.w);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     s1 = wave_sum(s1) * inv_d;
     s2 = wave_sum(s2) * inv_d;
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
+    for (int it = 0; it < NV; ++it) {
       const int c = lane * 4 + it * 256;
       if (c < D) {
         float4 o;
@@ -135,10 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         o.y = rstd * (g[it].y - s1 - xh[it].y * s2);
         o.z = rstd * (g[it].z - s1 - xh[it].z * s2);
         o.w = rstd * (g[it].w - s1 - xh[it].w * s2);
-        if (dres) {
-          const float4 dr = *reinterpret_cast<const float4*>(dres + xrow * D + c);
-          o.x += dr.x; o.y += dr.y; o.z += dr.z; o.w += dr.w;
-        }
+        o.x += dr[it].x; o.y += dr[it].y; o.z += dr[it].z; o.w += dr[it].w;
         *reinterpret_cast<float4*>(dx + xrow * D + c) = o;
         po[it].x += o.x; po[it].y += o.y; po[it].z += o.z; po[it].w += o.w;
         if (dx_bf) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   float* rb = red + 4 * D;       // [4][D]
   float* ro = red + 8 * D;       // [4][D]
 #pragma unroll
-  for (int it = 0; it < MAXV; ++it) {
+  for (int it = 0; it < NV; ++it) {
     const int c = lane * 4 + it * 256;
     if (c < D) {
       *reinterpret_cast<float4*>(rs + wave * D + c) = ps[it];
@@ -197,16 +198,20 @@ extern "C" int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, c
   BV_REQUIRE(D % 4 == 0 && D <= 256 * MAXV, "bv_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
   BV_REQUIRE(row_stride >= 1 && row_offset >= 0 && row_offset < row_stride, "bv_layernorm_bwd: bad row_stride/offset");
   BV_REQUIRE(mean && rstd && dx, "bv_layernorm_bwd: mean/rstd/dx required");
+  const int nv = D <= 768 ? 3 : (D <= 1024 ? 4 : MAXV);
   int grid = (rows + 3) / 4;
-  if (grid > 512) grid = 512;
+  const int max_grid = nv <= 4 ? 1024 : 512;   // workgroups resident per CU: 4 / 2
+  if (grid > max_grid) grid = max_grid;
   const size_t shmem = sizeof(float) * 12 * D;
-  if (dy_is_f32)
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x,
-                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D, row_stride,
-                       row_offset);
-  else
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x,
-                       scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D, row_stride,
-                       row_offset);
+#define BV_LN_BWD(F32, NV)                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<F32, NV>), dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x, \
+                     scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D,     \
+                     row_stride, row_offset)
+  if (dy_is_f32) {
+    if (nv == 3) BV_LN_BWD(true, 3); else if (nv == 4) BV_LN_BWD(true, 4); else BV_LN_BWD(true, MAXV);
+  } else {
+    if (nv == 3) BV_LN_BWD(false, 3); else if (nv == 4) BV_LN_BWD(false, 4); else BV_LN_BWD(false, MAXV);
+  }
+#undef BV_LN_BWD
   return bv_check_launch("bv_layernorm_bwd");
 }

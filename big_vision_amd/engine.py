@@ -258,10 +258,10 @@ class Block:
     dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad)
     linear_bwd_w(o, dx1_bf, self.wo, None)      # out-proj bias grad = colsum(dx1): fused above
     d_o = linear_bwd_x(dx1_bf, self.wo)
-    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=self.bqkv.grad)   # q/k/v bias grads fused
     if y0 is None:
       y0 = self.ln0.fwd(x, T, D)[0]
-    linear_bwd_w(y0, dqkv, self.wqkv, self.bqkv)
+    linear_bwd_w(y0, dqkv, self.wqkv, None)
     del y0
     dy0 = linear_bwd_x(dqkv, self.wqkv)
     dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)

@@ -135,13 +135,21 @@ def attn_fwd(qkv, n, L, H):
   return o, lse
 
 
-def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None):
+def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None):
+  """dbias (fp32, 3*H*64 elements): += column sums of dqkv (the q/k/v bias gradients)."""
   _chk(qkv, BF16, "attn.qkv"); _chk(o, BF16, "attn.o"); _chk(d_o, BF16, "attn.do")
   assert d_o.is_contiguous() and o.is_contiguous()
   if dqkv is None:
     dqkv = torch.empty_like(qkv)
+  if dbias is not None:
+    _chk(dbias, F32, "attn.dbias")
+    assert dbias.is_contiguous() and dbias.numel() == 3 * H * 64
   delta = torch.empty((n, H, L), device=qkv.device, dtype=F32)
-  _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), n, L, H, _stream())
+  rows = torch.empty((n, 3 * H * 64), device=qkv.device, dtype=F32) if dbias is not None else None
+  _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(rows), n, L, H,
+            _stream())
+  if dbias is not None:
+    colsum(rows, dbias)   # per-sample sums (written by the kernels) -> bias gradient
   return dqkv
 
 

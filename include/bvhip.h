@@ -137,9 +137,12 @@ int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float*
  * log-sum-exp, saved for the backward).  Dh must be 64; L <= 576. */
 int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
 /* dqkv (same layout as qkv) from do ([n*L][H][64] bf16); delta is fp32 scratch
- * [n][H][L] (rowsum(dO*O), computed here). */
+ * [n][H][L] (rowsum(dO*O), computed here).  dbias_rows (optional, fp32 [n][3][H][64]) receives
+ * the per-sample column sums of dqkv, reduced inside the kernels from the fp32 results; summed
+ * over n (bv_colsum) they are the gradient of the query/key/value projection biases
+ * (vit.py:93-98) - no separate pass over dqkv. */
 int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                void* dqkv, int n, int L, int H, void* stream);
+                void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
 
 /* Single-query attention of the MAP head (models/vit.py:176-178): q [n][H][64]
  * bf16, kv packed [n*L][2][H][64] bf16 -> o [n][H][64] bf16, probabilities p

@@ -221,6 +221,12 @@ def _attention_case(dev, n, L, H):
   g = qr.grad
   err = (dqkv.double() - g).abs().max().item()
   assert_close(dqkv, g, 3e-2, 3e-2 * g.abs().max().item(), f"dqkv (max err {err:.3e})")
+  # fused q/k/v bias gradient: column sums of dqkv, accumulated in place
+  db = torch.full((3 * H * 64,), 0.5, device=dev)
+  dqkv2 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
+  assert torch.equal(dqkv2, dqkv)
+  cs = g.sum(0)
+  assert_close(db, 0.5 + cs, 2e-2, 2e-2 * g.abs().sum(0).max().item(), "fused qkv bias grad")
 
 
 def test_attention_peaked_softmax(dev):
