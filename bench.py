@@ -61,16 +61,38 @@ class GemmObserver:
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
-    return (e0, e1, 2.0 * args[9] * args[10] * args[11])
+    M, N, K, epi, out_f32 = args[9], args[10], args[11], args[12], args[8]
+    # algorithmic HBM bytes of the launch: A + B read once, C written once, plus the epilogue's
+    # auxiliary operand (fp32 residual / bf16 pre-activation) and second output (GELU / EMIT)
+    nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4.0 if out_f32 else 2.0)
+    nbytes += {1: 4.0, 4: 2.0, 6: 2.0}.get(epi, 0.0) * M * N      # aux
+    nbytes += {3: 2.0, 6: 2.0}.get(epi, 0.0) * M * N              # C2
+    return (e0, e1, 2.0 * M * N * K, nbytes)
 
   def end(self, tok):
     tok[1].record()
     self.recs.append(tok)
 
   def summary(self):
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.recs)
-    flops = sum(f for _, _, f in self.recs)
-    return len(self.recs), ms, flops
+    ms = sum(r[0].elapsed_time(r[1]) for r in self.recs)
+    flops = sum(r[2] for r in self.recs)
+    nbytes = sum(r[3] for r in self.recs)
+    return len(self.recs), ms, flops, nbytes
+
+
+def pmc_traffic(world, micro):
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
+  THIS command (profiles/r01_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
+  be read from inside the process).  None when the profile does not match the configuration."""
+  path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+  try:
+    with open(path) as f:
+      d = json.load(f)
+    if d.get("n_gpus", 1) != world or d.get("microbatch") != micro:
+      return None, None
+    return d["kernels"][DOMINANT_KERNEL]["hbm_bytes"], os.path.relpath(path, ROOT)
+  except (OSError, KeyError, ValueError):
+    return None, None
 
 
 def make_config(total_steps):
@@ -219,11 +241,15 @@ def main():
                  "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps},
   }
   if not args.no_roofline:
-    launches, ms, flops = obs.summary()
+    launches, ms, flops, nbytes = obs.summary()
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(world, args.microbatch)
     line["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach,
                         "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": nbytes / max(1, launches),
                         "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
                         "share_of_step_time": ms / (1e3 * dt)}
   if world == 1 and not args.no_cpu_baseline:

@@ -74,6 +74,52 @@ class Comm:
       dist.barrier(group=self.group)
 
 
+class GradSync:
+  """Overlaps the gradient all-reduce with the backward pass.
+
+  The backward finishes parameter gradients tower by tower, last layer first (the reference
+  leaves this overlap to XLA's scheduler, _deprecated_contrastive.py:343).  `launch(lo, hi)`
+  is called on the compute stream once elements [lo, hi) of the flat gradient buffer are
+  final: the range is summed over ranks on a side stream (RCCL kernels run next to the
+  remaining backward GEMMs); `finish()` reduces whatever was not launched and makes the
+  compute stream wait for the side stream.  Every rank issues the same ranges in the same
+  order.  CPU tensors (gloo tests) are reduced synchronously."""
+
+  def __init__(self, comm: Comm, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
+    self.comm, self.flat, self.bucket_bytes = comm, flat, bucket_bytes
+    self.done = []   # disjoint [lo, hi) already handed to the collective
+    self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and comm.size > 1) else None
+
+  def launch(self, lo: int, hi: int):
+    lo, hi = max(0, int(lo)), min(int(hi), self.flat.numel())
+    if self.comm.size == 1 or hi <= lo:
+      return
+    for a, b in self.done:
+      assert hi <= a or lo >= b, f"gradient range [{lo},{hi}) overlaps an already reduced range [{a},{b})"
+    self.done.append((lo, hi))
+    if self.stream is None:
+      self.comm.all_reduce_sum_(self.flat[lo:hi], self.bucket_bytes)
+      return
+    ready = torch.cuda.Event()
+    ready.record()                         # on the compute stream: the range is final after this point
+    with torch.cuda.stream(self.stream):
+      self.stream.wait_event(ready)
+      self.comm.all_reduce_sum_(self.flat[lo:hi], self.bucket_bytes)
+
+  def finish(self):
+    """Reduces the complement of the launched ranges, then joins the side stream."""
+    if self.comm.size == 1:
+      return
+    pos = 0
+    for a, b in sorted(self.done) + [(self.flat.numel(), self.flat.numel())]:
+      if a > pos:
+        self.comm.all_reduce_sum_(self.flat[pos:a], self.bucket_bytes)
+      pos = max(pos, b)
+    if self.stream is not None:
+      torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+    self.done = []
+
+
 def init_from_env(backend: str | None = None) -> Comm:
   """Initialises torch.distributed from torchrun-style env vars (if present)."""
   world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -297,12 +297,17 @@ class Encoder:
     encoder's incoming dx (encoder_norm backward) accumulates its column sums there."""
     return self.blocks[-1].mlp.b2.grad if self.blocks else None
 
-  def bwd(self, saved, dx, dx_bf, n, L, b2_done=False):
+  def bwd(self, saved, dx, dx_bf, n, L, b2_done=False, on_block=None):
+    """on_block(i): called after block i's backward is enqueued; the gradients of blocks >= i
+    are final at that point (block i's Dense_1 bias was accumulated earlier, by the kernel
+    that produced its incoming dx; block i's backward also finishes block i-1's Dense_1 bias)."""
     last = len(self.blocks) - 1
     for i in range(last, -1, -1):
       nb2 = self.blocks[i - 1].mlp.b2.grad if i > 0 else None
       dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L, b2_done=(b2_done if i == last else True),
                                      next_b2=nb2)
+      if on_block is not None:
+        on_block(i)
     return dx, dx_bf
 
 

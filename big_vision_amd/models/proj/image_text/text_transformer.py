@@ -75,7 +75,7 @@ class TextExec:
       ctx["head_in"] = zb
     return x, out, (ctx if save else None)
 
-  def bwd(self, ctx, dx):
+  def bwd(self, ctx, dx, on_block=None):
     m = self.m
     D = m.width
     n, L = ctx["n"], ctx["L"]
@@ -99,7 +99,7 @@ class TextExec:
     else:
       dy = self.map.bwd(ctx["map"], dz, n, L)
       dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
-    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True)
+    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True, on_block=on_block)
     if self.table.grad is not None:
       ops.embed_bwd(ctx["ids"].view(-1), dx0, self.table.grad)
     if self.pos.grad is not None:

@@ -54,14 +54,34 @@ class TwoTowersExec:
       out["b"] = self.b.f32
     return zimg, ztxt, out, (ctx if save else None)
 
-  def bwd(self, ctx, dzimg, dztxt):
-    """dzimg / dztxt: gradients w.r.t. the NORMALISED embeddings (None = tower skipped)."""
+  def bwd(self, ctx, dzimg, dztxt, sync=None):
+    """dzimg / dztxt: gradients w.r.t. the NORMALISED embeddings (None = tower skipped).
+    sync (dp.GradSync, last backward of a step on N > 1 ranks): gradient ranges are handed to
+    the all-reduce as soon as they are final - the whole text tower once its backward is
+    enqueued, the upper half of the image tower (blocks depth/2.., encoder_norm, MAP head)
+    half-way through the image backward - so RCCL overlaps the remaining GEMMs."""
+    store = self.store
     if dztxt is not None and "txt" in ctx:
       c, z, norm = ctx["txt"]
       self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt))
+      if sync is not None:
+        r = store.grad_range(lambda n: n.startswith("txt/"))
+        if r is not None:
+          sync.launch(*r)
     if dzimg is not None and "img" in ctx:
       c, z, norm = ctx["img"]
-      self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg))
+      on_block = None
+      half = getattr(self.m.image_tower, "depth", 0) // 2
+      if sync is not None and half > 0:
+        def upper(n, half=half):
+          if not n.startswith("img/") or n.startswith(("img/embedding", "img/pos_embedding", "img/cls")):
+            return False
+          k = n.split("encoderblock_")
+          return len(k) == 1 or int(k[1].split("/")[0]) >= half
+        rng = store.grad_range(upper)
+        if rng is not None:
+          on_block = lambda i, rng=rng, half=half: sync.launch(*rng) if i == half else None
+      self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg), on_block=on_block)
 
 
 class Model:

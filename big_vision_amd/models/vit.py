@@ -147,7 +147,7 @@ class VitExec:
     return x, out, (ctx if save else None)
 
   # ------------------------------------------------------------- backward --
-  def bwd(self, ctx, dx):
+  def bwd(self, ctx, dx, on_block=None):
     m = self.m
     D = m.width
     n, L, L0 = ctx["n"], ctx["L"], ctx["L0"]
@@ -171,7 +171,7 @@ class VitExec:
       dxL_bf.zero_()
       self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=0,
                         dx_colsum=self.enc.last_b2_grad())
-    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True)
+    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True, on_block=on_block)
     if m.pool_type == "tok":
       if self.cls.grad is not None:
         ops.colsum(dx0.view(n, L * D)[:, :D], self.cls.grad.view(-1))

@@ -128,6 +128,19 @@ class ParamStore:
       raise KeyError(f"{name} is frozen: it has no entry in buffer '{buf}'")
     return b[e.offset:e.offset + e.numel].view(e.shape)
 
+  def grad_range(self, pred) -> Optional[Tuple[int, int]]:
+    """[lo, hi) of the flat gradient buffer covered by the trainable entries whose name satisfies
+    `pred`, or None if they are not one contiguous run (or there are none)."""
+    hit = [e for n, e in self.entries.items() if n not in self.frozen and pred(n)]
+    if not hit:
+      return None
+    lo = min(e.offset for e in hit)
+    hi = max(e.offset + (e.numel + ALIGN - 1) // ALIGN * ALIGN for e in hit)
+    for n, e in self.entries.items():
+      if n not in self.frozen and not pred(n) and lo <= e.offset < hi:
+        return None
+    return lo, min(hi, self.trainable_count)
+
   def has_grad(self, name: str) -> bool:
     return name not in self.frozen
 

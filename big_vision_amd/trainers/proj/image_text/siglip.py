@@ -98,6 +98,8 @@ def make_update_fn(model, config, comm=None):
     txt_frozen = all(e in store.frozen for e in store.entries if e.startswith("txt/"))
     t_param = store.t("t")
     b_param = store.t("b") if "b" in store.entries else None
+    # N > 1: the gradient all-reduce overlaps the (last) backward, see dp.GradSync
+    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and config.get("overlap_grad_sync", True)) else None
 
     if micro and n > micro:
       assert n % micro == 0, f"per-device batch {n} not divisible by microbatch {micro}"
@@ -158,12 +160,13 @@ def make_update_fn(model, config, comm=None):
           _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro],
                                 save=("light" if state_cache["light"] else True))
         ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
-               None if txt_frozen else dztxt[s:s + micro].contiguous())
+               None if txt_frozen else dztxt[s:s + micro].contiguous(),
+               sync=(sync if s == starts[-1] else None))   # gradients are final in the LAST backward only
         del ctx
     else:
       zimg, ztxt, _, ctx = ex.fwd(images, labels, save=True)
       stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
-      ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt)
+      ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt, sync=sync)
 
     # dL/dt', dL/db (scalars computed by the loss kernel) into the flat grad buffer.
     gt = store.g("t")
@@ -173,7 +176,10 @@ def make_update_fn(model, config, comm=None):
       store.g("b").add_(stats[2].to(F32))
 
     # DP: sum partial gradients and the loss shares (pmean of the reference).
-    comm.all_reduce_sum_(store.grad)
+    if sync is not None:
+      sync.finish()
+    else:
+      comm.all_reduce_sum_(store.grad)
     loss = stats[:1].clone()
     comm.all_reduce_scalars_(loss)
 

@@ -81,6 +81,18 @@ def _worker(rank, world, port, n, E, out):
   lb = O.sigmoid_loss_per_device(zimg * w, shards, rank, t, b).view(1).clone()
   comm.all_reduce_scalars_(lb)
   assert abs(lb.item() / world - ref.item()) < 1e-12
+  # ---- GradSync: ranges handed over early + the complement in finish() == one all-reduce
+  base = torch.arange(1000, dtype=torch.float64)
+  buf = base * (rank + 1)
+  sync = dp.GradSync(comm, buf, bucket_bytes=256)
+  sync.launch(100, 300)
+  sync.launch(600, 900)
+  sync.finish()
+  assert torch.equal(buf, base * sum(r + 1 for r in range(world))), "GradSync must sum every element exactly once"
+  buf2 = base * (rank + 1)
+  sync.launch(0, 1000); sync.finish()      # (state was reset by finish)
+  buf2_sync = dp.GradSync(comm, buf2); buf2_sync.finish()
+  assert torch.equal(buf2, base * sum(r + 1 for r in range(world)))
   comm.barrier()
   out.put((rank, loss.item()))
   dist.destroy_process_group()

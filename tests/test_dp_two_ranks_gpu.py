@@ -1,0 +1,110 @@
+"""The N > 1 trainer path on ONE GPU: two rank processes share cuda:0 and talk over `gloo`
+(RCCL refuses two ranks on one device; the collectives' semantics are the same).  Each rank runs
+the product `update_fn` on its half of the batch - all_gather of ztxt, sharded sigmoid loss with
+the positive diagonal at rank*n, reduce_scatter of dztxt, overlapped gradient all-reduce
+(dp.GradSync on a side stream) - and the result must match the single-process step on the
+whole batch (trainers/proj/image_text/siglip.py:271-323 under a 2-device mesh)."""
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+IMAGE_CFG = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+TEXT_CFG = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+
+
+def _config(**kw):
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  c = ConfigDict()
+  c.lr, c.wd = 1e-3, 1e-2
+  c.schedule = dict(decay_type="cosine", warmup_steps=2)
+  c.optax_name = "scale_by_adam"
+  c.grad_clip_norm = 1.0
+  c.total_steps = 10
+  for k, v in kw.items():
+    c[k] = v
+  return c
+
+
+def _step(comm, image, text, **kw):
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  from big_vision_amd import utils as u
+  model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, 128), temperature_init=10.0,
+                           bias_init=-10.0)
+  config = _config(**kw)
+  state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, comm=comm,
+                                     total_steps=config.total_steps)
+  state, meas = siglip.make_update_fn(model, config, comm=comm)(state, None, {"image": image, "labels": text})
+  torch.cuda.synchronize()
+  store = state["params"].store
+  grads = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
+  params = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
+  return meas["training_loss"].item(), meas["l2_grads"].item(), grads, params
+
+
+def _worker(rank, world, port, out, kw):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK="0")
+  import bv_oracle as O
+  from big_vision_amd import dp
+  torch.cuda.set_device(0)
+  comm = dp.init_from_env(backend="gloo")
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  n = 8 // world
+  dev = torch.device("cuda:0")
+  loss, gn, grads, params = _step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev), **kw)
+  digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
+  # numpy arrays are pickled by value (torch tensors would travel as shared-memory handles that
+  # die with this process)
+  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest))
+  comm.barrier()
+  torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2)])
+def test_two_ranks_match_single_process(dev, kw):
+  import torch.multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  import bv_oracle as O
+  from big_vision_amd import dp
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev))
+  ctx = mp.get_context("spawn")
+  out = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, out, kw)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = {}
+  for _ in range(2):
+    r = out.get(timeout=300)
+    res[r[0]] = r[1:]
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
+  loss2, gn2, g2, p2 = res[0]
+  assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(loss1), "ranks disagree on the global loss"
+  assert abs(loss2 - loss1) <= 1e-4 * abs(loss1), (loss1, loss2)
+  assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
+  gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
+  for k, v in g1.items():
+    assert (v - torch.from_numpy(g2[k])).norm().item() <= 2e-2 * max(v.norm().item(), 1e-2 * gnorm), k
+  assert res[0][3] == res[1][3], "replicated parameters diverged between the ranks after the update"

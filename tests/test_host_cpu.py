@@ -141,3 +141,25 @@ def test_configdict_surface():
   assert c.model.image.variant == "B/16" and c["model"]["out_dim"] == (None, 768)
   assert c.get("missing", 7) == 7 and "lr" in c
   assert c.to_dict()["model"]["image"] == {"variant": "B/16"}
+
+
+def test_grad_ranges_for_overlapped_all_reduce():
+  """dp.GradSync hands contiguous runs of the flat gradient buffer to RCCL while the backward
+  still runs: the text tower and the upper half of the image tower must be contiguous runs
+  that do not overlap, and frozen entries must not be part of any run."""
+  from big_vision_amd.models.proj.image_text import two_towers
+  m = two_towers.Model(image=dict(width=128, depth=4, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map"),
+                       text=dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=50),
+                       out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0)
+  store = m.make_store((2, 32, 32, 3), (2, 8), device="cpu")
+  txt = store.grad_range(lambda n: n.startswith("txt/"))
+  up = store.grad_range(lambda n: n.startswith("img/MAPHead") or "encoder_norm" in n and n.startswith("img/")
+                        or any(f"img/Transformer/encoderblock_{i}/" in n for i in (2, 3)))
+  assert txt is not None and up is not None
+  assert up[1] <= txt[0] and txt[1] <= store.trainable_count
+  for name, e in store.entries.items():
+    inside = txt[0] <= e.offset < txt[1]
+    assert inside == name.startswith("txt/"), name
+  # a non-contiguous selection is refused
+  assert store.grad_range(lambda n: n in ("img/embedding/kernel", "t")) is None
+  assert store.grad_range(lambda n: False) is None
