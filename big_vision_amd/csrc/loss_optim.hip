@@ -187,64 +187,74 @@ struct AdamArgs {
   float sched[BV_MAX_SCHED];
 };
 
-__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-  __shared__ float sh[4];
-  const bv_adam_seg hp = a.segs[a.chunk_seg[blockIdx.x]];
-  const float sched = a.sched[hp.sched_idx & (BV_MAX_SCHED - 1)];
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, long nchunks) {
+  __shared__ double shd[2][256];
   float clip = 1.f;
   if (a.clip_norm > 0.f) {
     const float gn = (float)sqrt(*a.gsq);
     clip = gn > a.clip_norm ? a.clip_norm / gn : 1.f;
   }
-  const long i = (long)blockIdx.x * 1024 + threadIdx.x * 4;
-  const float4 p4 = *reinterpret_cast<const float4*>(a.p + i);
-  const float4 g4 = *reinterpret_cast<const float4*>(a.g + i);
-  const float4 v4 = *reinterpret_cast<const float4*>(a.nu + i);
-  float m[4];
-  if (a.mu_bf16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(a.mu) + i);
-    m[0] = bflo(u.x); m[1] = bfhi(u.x); m[2] = bflo(u.y); m[3] = bfhi(u.y);
-  } else {
-    const float4 m4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mu) + i);
-    m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
-  }
-  float p[4] = {p4.x, p4.y, p4.z, p4.w};
-  const float g[4] = {g4.x * clip, g4.y * clip, g4.z * clip, g4.w * clip};
-  float v[4] = {v4.x, v4.y, v4.z, v4.w};
-  float sp = 0.f, su = 0.f;
+  // Grid-stride over the 1024-element chunks: the two norm statistics are accumulated per
+  // thread over all its chunks and leave the workgroup as ONE pair of fp64 atomics (a
+  // workgroup per chunk put ~400 k atomics on the same two addresses and ran at 1.2 TB/s).
+  double sp = 0.0, su = 0.0;   // per-thread over all its chunks (fp32 within a chunk)
+  for (long c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    float cp = 0.f, cu = 0.f;
+    const bv_adam_seg hp = a.segs[a.chunk_seg[c]];
+    const float sched = a.sched[hp.sched_idx & (BV_MAX_SCHED - 1)];
+    const long i = c * 1024 + threadIdx.x * 4;
+    const float4 p4 = *reinterpret_cast<const float4*>(a.p + i);
+    const float4 g4 = *reinterpret_cast<const float4*>(a.g + i);
+    const float4 v4 = *reinterpret_cast<const float4*>(a.nu + i);
+    float m[4];
+    if (a.mu_bf16) {
+      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(a.mu) + i);
+      m[0] = bflo(u.x); m[1] = bfhi(u.x); m[2] = bflo(u.y); m[3] = bfhi(u.y);
+    } else {
+      const float4 m4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mu) + i);
+      m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
+    }
+    float p[4] = {p4.x, p4.y, p4.z, p4.w};
+    const float g[4] = {g4.x * clip, g4.y * clip, g4.z * clip, g4.w * clip};
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    m[e] = a.b1 * m[e] + (1.f - a.b1) * g[e];
-    v[e] = a.b2 * v[e] + (1.f - a.b2) * g[e] * g[e];
-    float u = (m[e] / a.bc1) / (sqrtf(v[e] / a.bc2) + a.eps);
-    u = hp.lr_eff * u + hp.wd_eff * p[e];
-    u *= sched;
-    p[e] -= u;
-    sp += p[e] * p[e];
-    su += u * u;
-  }
-  *reinterpret_cast<float4*>(a.p + i) = make_float4(p[0], p[1], p[2], p[3]);
-  *reinterpret_cast<float4*>(a.nu + i) = make_float4(v[0], v[1], v[2], v[3]);
-  if (a.mu_bf16) {
-    uint2 u;
-    u.x = pack_bf2(m[0], m[1]);
-    u.y = pack_bf2(m[2], m[3]);
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(a.mu) + i) = u;
-  } else {
-    *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.mu) + i) = make_float4(m[0], m[1], m[2], m[3]);
-  }
-  if (a.shadow) {
-    uint2 u;
-    u.x = pack_bf2(p[0], p[1]);
-    u.y = pack_bf2(p[2], p[3]);
-    *reinterpret_cast<uint2*>(a.shadow + i) = u;
+    for (int e = 0; e < 4; ++e) {
+      m[e] = a.b1 * m[e] + (1.f - a.b1) * g[e];
+      v[e] = a.b2 * v[e] + (1.f - a.b2) * g[e] * g[e];
+      float u = (m[e] / a.bc1) / (sqrtf(v[e] / a.bc2) + a.eps);
+      u = hp.lr_eff * u + hp.wd_eff * p[e];
+      u *= sched;
+      p[e] -= u;
+      cp += p[e] * p[e];
+      cu += u * u;
+    }
+    sp += (double)cp;
+    su += (double)cu;
+    *reinterpret_cast<float4*>(a.p + i) = make_float4(p[0], p[1], p[2], p[3]);
+    *reinterpret_cast<float4*>(a.nu + i) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.mu_bf16) {
+      uint2 u;
+      u.x = pack_bf2(m[0], m[1]);
+      u.y = pack_bf2(m[2], m[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(a.mu) + i) = u;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.mu) + i) = make_float4(m[0], m[1], m[2], m[3]);
+    }
+    if (a.shadow) {
+      uint2 u;
+      u.x = pack_bf2(p[0], p[1]);
+      u.y = pack_bf2(p[2], p[3]);
+      *reinterpret_cast<uint2*>(a.shadow + i) = u;
+    }
   }
   if (a.stats) {
-    const float tp = block_sum_256(sp, sh);
-    const float tu = block_sum_256(su, sh);
-    if (threadIdx.x == 0) {
-      atomicAdd(a.stats + 0, (double)tp);
-      atomicAdd(a.stats + 1, (double)tu);
+    shd[0][threadIdx.x] = sp;
+    shd[1][threadIdx.x] = su;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      double t = 0.0;
+      for (int k = 0; k < 256; ++k) t += shd[threadIdx.x][k];
+      atomicAdd(a.stats + threadIdx.x, t);
     }
   }
 }
@@ -303,6 +313,8 @@ extern "C" int bv_adam_step(float* params, const float* grads, void* mu, int mu_
   a.segs = segs; a.chunk_seg = chunk_seg; a.gsq = gsq; a.stats = stats;
   a.clip_norm = clip_norm; a.b1 = b1; a.b2 = b2; a.eps = eps; a.bc1 = bc1; a.bc2 = bc2;
   a.mu_bf16 = mu_bf16;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(count / 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  const long nchunks = count / 1024;
+  const unsigned grid = (unsigned)(nchunks < 4096 ? nchunks : 4096);   // 16 workgroups per CU
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, nchunks);
   return bv_check_launch("bv_adam_step");
 }
