@@ -51,7 +51,11 @@ PROTOTYPES = {
     "bv_l2norm_fwd": [P, P, P, c_int, c_int, c_float, P],
     "bv_l2norm_bwd": [P, P, P, P, c_int, c_int, c_float, P],
     "bv_siglip_loss": [P, P, P, P, c_int, c_int, c_int, c_int, P],
-    "bv_softmax_xent": [P, P, P, P, c_int, c_int, P],
+    "bv_softmax_xent": [P, P, P, P, c_int, c_int, c_int, P],
+    "bv_sigmoid_xent": [P, P, P, P, c_int, c_int, c_int, P],
+    "bv_tanh_fwd": [P, P, c_long, P],
+    "bv_tanh_bwd": [P, P, P, c_long, P],
+    "bv_mixup": [P, P, c_float, c_int, c_long, P],
     "bv_sqnorm": [P, c_long, P, P],
     "bv_adam_step": [P, P, P, c_int, P, P, P, P, c_long, P, c_int, P, c_float, c_float, c_float,
                      c_float, c_float, c_float, P, P],

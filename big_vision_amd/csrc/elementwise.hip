@@ -331,6 +331,24 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long count) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+__global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x, float* __restrict__ out, float a,
+                                                    int n, long row_elems) {
+  const long total = (long)n * row_elems;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / row_elems;
+    const long j = r == 0 ? i + (long)(n - 1) * row_elems : i - row_elems;   // row r-1 (mod n): jnp.roll(x, 1, 0)
+    out[i] = a * x[i] + (1.f - a) * x[j];
+  }
+}
+
 }  // namespace
 
 // bf16 transpose: dst[cols][rows] = src[rows][cols]^T (row strides lds / ldd
@@ -404,6 +422,26 @@ extern "C" int bv_cast_bf16(const float* x, void* y, long count, void* stream) {
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(count / 8 + 1, 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, x, (bf16*)y, count);
   return bv_check_launch("bv_cast_bf16");
+}
+
+// pre_logits tanh (models/vit.py:259-262) and its backward dx = dy (1 - y^2)
+extern "C" int bv_tanh_fwd(const float* x, float* y, long count, void* stream) {
+  BV_REQUIRE(count > 0, "bv_tanh_fwd: empty");
+  hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, count);
+  return bv_check_launch("bv_tanh_fwd");
+}
+extern "C" int bv_tanh_bwd(const float* y, const float* dy, float* dx, long count, void* stream) {
+  BV_REQUIRE(count > 0, "bv_tanh_bwd: empty");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(count, 256, 4096)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, count);
+  return bv_check_launch("bv_tanh_bwd");
+}
+
+// utils.py:1146-1154 (get_mixup): out[i] = a x[i] + (1 - a) x[i - 1 mod n] over rows of row_elems floats
+extern "C" int bv_mixup(const float* x, float* out, float a, int n, long row_elems, void* stream) {
+  BV_REQUIRE(n > 0 && row_elems > 0 && x != out, "bv_mixup: bad arguments (in-place is not supported)");
+  hipLaunchKernelGGL(mixup_kernel, dim3(grid_for((long)n * row_elems, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     x, out, a, n, row_elems);
+  return bv_check_launch("bv_mixup");
 }
 
 // models/vit.py:223-225

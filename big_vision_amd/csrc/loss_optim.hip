@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void siglip_loss_kernel(float* __restrict__ ra
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
                                                            const float* __restrict__ labels,
                                                            double* __restrict__ loss_sum,
-                                                           float* __restrict__ dlogits, int n, int C) {
+                                                           float* __restrict__ dlogits, int n, int C,
+                                                           float inv_n) {
   __shared__ float sh[4];
   const int r = blockIdx.x;
   const float* lr = logits + (long)r * C;
@@ -82,14 +83,39 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restri
   syl = block_sum_256(syl, sh);
   const float lse = logf(se);
   // -sum_c y (l - mx - lse) = -(syl - sy*lse)
-  if (threadIdx.x == 0) atomicAdd(loss_sum, (double)(-(syl - sy * lse)) / (double)n);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (double)(-(syl - sy * lse)) * (double)inv_n);
   if (dlogits) {
-    const float inv_n = 1.0f / (float)n;
     for (int c = threadIdx.x; c < C; c += 256) {
       const float p = __expf(lr[c] - mx - lse);
       dlogits[(long)r * C + c] = (p * sy - yr[c]) * inv_n;
     }
   }
+}
+
+// ------------------------------------------------------------ sigmoid xent --
+// utils.py:236-243: nll_i = -sum_c [y log sigmoid(l) + (1 - y) log sigmoid(-l)], mean over i.
+// log sigmoid(x) = min(x, 0) - log1p(exp(-|x|)) (stable); d nll / d l = sigmoid(l) - y.
+// One workgroup per row.
+__global__ __launch_bounds__(256) void sigmoid_xent_kernel(const float* __restrict__ logits,
+                                                           const float* __restrict__ labels,
+                                                           double* __restrict__ loss_sum,
+                                                           float* __restrict__ dlogits, int n, int C,
+                                                           float inv_n) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  const float* lr = logits + (long)r * C;
+  const float* yr = labels + (long)r * C;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float l = lr[c], y = yr[c];
+    const float sp = log1pf(__expf(-fabsf(l)));          // softplus(-|l|)
+    const float log_p = fminf(l, 0.f) - sp;               // log sigmoid(l)
+    const float log_np = fminf(-l, 0.f) - sp;             // log sigmoid(-l)
+    acc -= y * log_p + (1.f - y) * log_np;
+    if (dlogits) dlogits[(long)r * C + c] = (1.f / (1.f + __expf(-l)) - y) * inv_n;
+  }
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, (double)acc * (double)inv_n);
 }
 
 // ----------------------------------------------------------- strided sgemm --
@@ -273,11 +299,19 @@ extern "C" int bv_siglip_loss(float* raw, const float* t_param, const float* b_p
 }
 
 extern "C" int bv_softmax_xent(const float* logits, const float* labels, double* loss_sum,
-                               float* dlogits, int n, int C, void* stream) {
-  BV_REQUIRE(n > 0 && C > 0, "bv_softmax_xent: bad shape");
+                               float* dlogits, int n, int C, int n_global, void* stream) {
+  BV_REQUIRE(n > 0 && C > 0 && n_global >= n, "bv_softmax_xent: bad shape n=%d C=%d n_global=%d", n, C, n_global);
   hipLaunchKernelGGL(softmax_xent_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels,
-                     loss_sum, dlogits, n, C);
+                     loss_sum, dlogits, n, C, 1.0f / (float)n_global);
   return bv_check_launch("bv_softmax_xent");
+}
+
+extern "C" int bv_sigmoid_xent(const float* logits, const float* labels, double* loss_sum,
+                               float* dlogits, int n, int C, int n_global, void* stream) {
+  BV_REQUIRE(n > 0 && C > 0 && n_global >= n, "bv_sigmoid_xent: bad shape n=%d C=%d n_global=%d", n, C, n_global);
+  hipLaunchKernelGGL(sigmoid_xent_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     loss_sum, dlogits, n, C, 1.0f / (float)n_global);
+  return bv_check_launch("bv_sigmoid_xent");
 }
 
 extern "C" int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,

@@ -82,8 +82,8 @@ class VitExec:
     self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M)
     self.map = E.MAPHead(store, f"{prefix}MAPHead_0", D, H, M) if m.pool_type == "map" else None
     self.pre = None
-    if m.rep_size:
-      raise NotImplementedError("rep_size (pre_logits tanh) is served by big_vision_amd.train only")
+    if m.rep_size:   # pre_logits = tanh(Dense(x)), vit.py:259-262
+      self.pre = (E._W(store, f"{prefix}pre_logits/kernel"), E._W(store, f"{prefix}pre_logits/bias"))
     self.head = None
     if m.num_classes:
       self.head = (E._W(store, f"{prefix}head/kernel"), E._W(store, f"{prefix}head/bias"))
@@ -137,6 +137,10 @@ class VitExec:
     else:
       raise ValueError(f"Unknown pool type: '{m.pool_type}'")
     out["head_input"] = z
+    if self.pre is not None:
+      zb0 = ops.cast_bf16(z)
+      z = ops.tanh_fwd(E.linear_fwd(zb0, self.pre[0], self.pre[1], out_dtype=F32))
+      ctx["pre"] = (zb0, z)
     out["pre_logits"] = z
     x = z
     if self.head is not None:
@@ -157,6 +161,12 @@ class VitExec:
       dzb = ops.cast_bf16(dz)
       E.linear_bwd_w(ctx["head_in"], dzb, self.head[0], self.head[1], dy_for_bias=dz)
       dz = E.linear_bwd_x(dzb, self.head[0], out_dtype=F32)
+    if self.pre is not None:
+      zb0, y = ctx["pre"]
+      dpl = ops.tanh_bwd(y, dz.contiguous())
+      dplb = ops.cast_bf16(dpl)
+      E.linear_bwd_w(zb0, dplb, self.pre[0], self.pre[1], dy_for_bias=dpl)
+      dz = E.linear_bwd_x(dplb, self.pre[0], out_dtype=F32)
     mean, rstd = ctx["norm"]
     xL = ctx["xL"]
     dxL_bf = torch.empty((T, D), device=xL.device, dtype=BF16)

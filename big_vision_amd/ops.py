@@ -276,12 +276,43 @@ def siglip_loss_(raw, t_param, b_param, stats, row_offset, B_global):
             B_global, _stream())
 
 
-def softmax_xent(logits, labels, loss_sum, want_grad=True):
-  _chk(logits, F32, "softmax_xent.logits"); _chk(labels, F32, "softmax_xent.labels")
+def softmax_xent(logits, labels, loss_sum, want_grad=True, n_global=None, name="bv_softmax_xent"):
+  """loss_sum (f64[1]) += mean-over-n_global softmax cross-entropy; returns dlogits (or None)."""
+  _chk(logits, F32, "xent.logits"); _chk(labels, F32, "xent.labels")
+  assert logits.is_contiguous() and labels.is_contiguous() and loss_sum.dtype == torch.float64
   n, C = logits.shape
   dl = torch.empty_like(logits) if want_grad else None
-  _lib.call("bv_softmax_xent", _p(logits), _p(labels), _p(loss_sum), _p(dl), n, C, _stream())
+  _lib.call(name, _p(logits), _p(labels), _p(loss_sum), _p(dl), n, C, int(n_global or n), _stream())
   return dl
+
+
+def sigmoid_xent(logits, labels, loss_sum, want_grad=True, n_global=None):
+  return softmax_xent(logits, labels, loss_sum, want_grad, n_global, name="bv_sigmoid_xent")
+
+
+def tanh_fwd(x):
+  _chk(x, F32, "tanh.x")
+  assert x.is_contiguous()
+  y = torch.empty_like(x)
+  _lib.call("bv_tanh_fwd", _p(x), _p(y), x.numel(), _stream())
+  return y
+
+
+def tanh_bwd(y, dy):
+  _chk(y, F32, "tanh.y"); _chk(dy, F32, "tanh.dy")
+  assert y.is_contiguous() and dy.is_contiguous()
+  dx = torch.empty_like(y)
+  _lib.call("bv_tanh_bwd", _p(y), _p(dy), _p(dx), y.numel(), _stream())
+  return dx
+
+
+def mixup(x, a):
+  """a x + (1 - a) roll(x, 1, axis 0) (utils.py:1146-1154)."""
+  _chk(x, F32, "mixup.x")
+  assert x.is_contiguous()
+  out = torch.empty_like(x)
+  _lib.call("bv_mixup", _p(x), _p(out), float(a), x.shape[0], x.numel() // x.shape[0], _stream())
+  return out
 
 
 def sqnorm_(x, out):

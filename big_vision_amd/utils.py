@@ -222,3 +222,29 @@ def save_params_npz(fname, tree):
   names_and_vals, _ = tree_flatten_with_names(tree)
   np.savez(fname, **{n: np.asarray(v.detach().cpu() if hasattr(v, "detach") else v)
                      for n, v in names_and_vals})
+
+
+# ------------------------------------------------------------------ mixup ----
+def get_mixup_coefficient(rng, step, p):
+  """a ~ Beta(p, p), a := max(a, 1 - a) (utils.py:1148-1150).  The reference draws it from
+  jax.random with the step-folded key; here a host torch.Generator seeded from (rng, step)
+  plays that role (same distribution, not the same bits - tests pass `mixup_a` explicitly)."""
+  import torch
+  from big_vision_amd.models.vit import _seed_of
+  g = torch.Generator().manual_seed((_seed_of(rng if rng is not None else 0) * 1000003 + int(step)) % (2 ** 63 - 1))
+  # Beta(p, p) = first coordinate of Dirichlet(p, p); the only sampler that takes a Generator
+  a = float(torch._sample_dirichlet(torch.tensor([float(p), float(p)]), generator=g)[0].item())
+  return max(a, 1.0 - a)
+
+
+def get_mixup(rng, p, step=0):
+  """Mirror of utils.get_mixup (utils.py:1146-1154): returns `_mixup(*things)` which gives back
+  (rng, mixed things); every thing is a [n, ...] fp32 GPU tensor, mixed with its roll by one
+  along dim 0 (bv_mixup kernel)."""
+  from big_vision_amd import ops
+  a = get_mixup_coefficient(rng, step, p)
+
+  def _mixup(*things):
+    return (rng, *[ops.mixup(t.contiguous(), a) for t in things])
+  _mixup.a = a
+  return _mixup

@@ -205,10 +205,26 @@ int bv_l2norm_bwd(const float* z, const float* norm, const float* dzn, float* dz
 int bv_siglip_loss(float* raw, const float* t_param, const float* b_param, double* stats, int n,
                    int B, int row_offset, int B_global, void* stream);
 
-/* softmax cross-entropy with soft labels, utils.py:276-281 (config 1):
- * loss_sum[0] += sum_i -sum_c y*log_softmax(logits) / n ; dlogits = (softmax*sum(y) - y)/n */
+/* Classification losses of big_vision/train.py:295-300 (BASELINE config 1), soft labels
+ * [n, C] fp32.  n = rows of this call, n_global = rows of the whole (data-parallel) batch: the
+ * mean is over n_global, so per-rank results are partial sums (all-reduce SUM).
+ * softmax_xent (utils.py:276-281): loss_sum[0] += sum_i -sum_c y log_softmax(l) / n_global,
+ *   dlogits = (softmax * sum_c(y) - y) / n_global.
+ * sigmoid_xent (utils.py:236-243): loss_sum[0] += sum_i -sum_c [y log sig(l) + (1-y) log sig(-l)]
+ *   / n_global, dlogits = (sigmoid(l) - y) / n_global.  dlogits may be NULL (forward only). */
 int bv_softmax_xent(const float* logits, const float* labels, double* loss_sum, float* dlogits,
-                    int n, int C, void* stream);
+                    int n, int C, int n_global, void* stream);
+int bv_sigmoid_xent(const float* logits, const float* labels, double* loss_sum, float* dlogits,
+                    int n, int C, int n_global, void* stream);
+
+/* pre_logits = tanh(Dense(x)) of the classification head (models/vit.py:259-262) and its
+ * backward dx = dy (1 - y^2); fp32, elementwise. */
+int bv_tanh_fwd(const float* x, float* y, long count, void* stream);
+int bv_tanh_bwd(const float* y, const float* dy, float* dx, long count, void* stream);
+
+/* Mixup (utils.py:1146-1154): out[i] = a x[i] + (1 - a) x[(i - 1) mod n] over n rows of
+ * row_elems floats (jnp.roll(x, shift=1, axis=0)); used for images and soft labels alike. */
+int bv_mixup(const float* x, float* out, float a, int n, long row_elems, void* stream);
 
 /* -------------------------------------------------------------- Optimizer --
  * sqnorm_out[0] += sum x^2 (double accumulator) — global grad norm for

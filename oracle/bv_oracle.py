@@ -333,6 +333,25 @@ def softmax_xent(logits, labels):
   return (-(labels * torch.log_softmax(logits, dim=-1)).sum(-1)).mean()
 
 
+def sigmoid_xent(logits, labels):
+  """utils.py:236-243 (stable log-sigmoid form)."""
+  log_p = log_sigmoid(logits)
+  log_not_p = log_sigmoid(-logits)
+  return (-(labels * log_p + (1.0 - labels) * log_not_p).sum(-1)).mean()
+
+
+def classification_step_loss(params, image, labels, *, model_cfg, num_classes, loss="sigmoid_xent",
+                             mixup_a=None):
+  """Loss of the classification trainer (big_vision/train.py:281-300): optional mixup with a
+  GIVEN coefficient a (utils.py:1146-1154; the reference draws it from jax.random.beta), then
+  getattr(u, config.loss)(logits, labels) on the ViT logits.  Returns (loss, logits)."""
+  if mixup_a is not None:
+    image, labels = mixup(mixup_a, image, labels)
+  logits, _ = vit_forward(params, image, num_classes=num_classes, **model_cfg)
+  fn = {"sigmoid_xent": sigmoid_xent, "softmax_xent": softmax_xent}[loss]
+  return fn(logits, labels), logits
+
+
 def mixup(a, *things):
   """utils.py:1146-1154 with a given mixing coefficient a (already max(a,1-a))."""
   return tuple(a * t + (1 - a) * torch.roll(t, shifts=1, dims=0) for t in things)

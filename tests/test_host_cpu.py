@@ -1,6 +1,9 @@
 """Host-side logic that needs no GPU: Flax-compatible parameter naming / layout,
 regex masks, durations and schedules (the reference's known answers,
 big_vision/utils_test.py:228-281), config-driven freezing, ConfigDict."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -163,3 +166,59 @@ def test_grad_ranges_for_overlapped_all_reduce():
   # a non-contiguous selection is refused
   assert store.grad_range(lambda n: n in ("img/embedding/kernel", "t")) is None
   assert store.grad_range(lambda n: False) is None
+
+
+def test_parse_arg_contract():
+  """Docstring examples of big_vision/configs/common.py:29-60."""
+  from big_vision_amd.configs import common as bvcc
+  spec = dict(res=(224, int), runlocal=False, schedule="short")
+  a = bvcc.parse_arg("runlocal,schedule=long,res=128", **spec)
+  assert (a.res, a.runlocal, a.schedule) == (128, True, "long")
+  assert bvcc.parse_arg("res=128", **spec).res == 128
+  assert bvcc.parse_arg("runlocal", **spec).runlocal is True
+  assert bvcc.parse_arg("runlocal=False", **spec).runlocal is False
+  assert bvcc.parse_arg("128", **spec).res == 128          # first spec entry may be passed unnamed
+  assert bvcc.parse_arg(None, **spec).res == 224
+  with pytest.raises(ValueError):
+    bvcc.parse_arg("nope=1", **spec)
+  lazy = bvcc.parse_arg("nope=1,x=2.5,y=abc,z=true", lazy=True, **spec)
+  assert (lazy.nope, lazy.x, lazy.y, lazy.z) == (1, 2.5, "abc", True)
+  assert bvcc.arg(res=256, foo="bar") == {"config_arg": "res=256,foo=bar", "res": 256, "foo": "bar"}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/big_vision/configs"), reason="needs the reference checkout")
+def test_reference_config_files_load_unchanged():
+  """`existing configs load unchanged` (BASELINE north star): the two in-repo configs of the hot
+  path are executed as they are and drive our model registry."""
+  from big_vision_amd.configs.loader import load_config
+  from big_vision_amd import train
+  c = load_config("/root/reference/big_vision/configs/vit_s16_i1k.py")
+  assert c.model_name == "vit" and c.loss == "softmax_xent" and c.mixup.p == 0.2
+  _, model = train.get_model(c)
+  assert (model.width, model.depth, model.mlp_dim, model.num_heads, model.num_classes) == (384, 12, 1536, 6, 1000)
+  assert model.rep_size is True and model.pool_type == "gap" and model.posemb == "sincos2d"
+  names = {e.name for e in model.entries("", (14, 14))}
+  assert "pre_logits/kernel" in names and "head/kernel" in names and "pos_embedding" not in names
+  lit = load_config("/root/reference/big_vision/configs/proj/image_text/siglip_lit_coco.py",
+                    reference_root="/root/reference")
+  assert lit.model_name == "proj.image_text.two_towers" and lit.model.bias_init == -2.71
+  assert lit.model.image.pool_type == "tok" and tuple(lit.model.out_dim) == (None, 768)
+  assert lit.schedule[0] == ("img/.*", None)               # frozen image tower (LiT)
+  assert "big_vision.configs.common" not in sys.modules      # the loader cleans up its aliases
+
+
+def test_oracle_sigmoid_xent_and_mixup():
+  import bv_oracle as O
+  logits = torch.tensor([[100.0, -100.0, 0.3]], dtype=torch.float64)
+  labels = torch.tensor([[1.0, 0.0, 0.25]], dtype=torch.float64)
+  naive = -(labels * torch.log(torch.sigmoid(logits)) + (1 - labels) * torch.log(torch.sigmoid(-logits))).sum(-1).mean()
+  assert abs(O.sigmoid_xent(logits, labels).item() - naive.item()) < 1e-12
+  assert torch.isfinite(O.sigmoid_xent(torch.tensor([[800.0, -800.0]]), torch.tensor([[0.0, 1.0]])))
+  x = torch.arange(6.0).view(3, 2)
+  (m,) = O.mixup(0.75, x)
+  assert torch.equal(m, 0.75 * x + 0.25 * x[[2, 0, 1]])     # roll(x, shift=1, axis=0)
+  from big_vision_amd import utils as u
+  for s in range(20):
+    a = u.get_mixup_coefficient(0, s, 0.2)
+    assert 0.5 <= a <= 1.0
+  assert u.get_mixup_coefficient(0, 3, 0.2) == u.get_mixup_coefficient(0, 3, 0.2)

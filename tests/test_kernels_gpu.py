@@ -397,6 +397,46 @@ def test_softmax_xent(dev):
   dl = ops.softmax_xent(logits, labels, acc)
   assert_close(acc.cpu()[0], ref.detach(), 1e-5, 1e-6, "xent")
   assert_close(dl.cpu(), lr.grad, 1e-4, 1e-7, "dlogits")
+  # data-parallel normaliser: a rank holding n of n_global rows contributes n/n_global of the mean
+  acc2 = torch.zeros(1, device=dev, dtype=torch.float64)
+  dl2 = ops.softmax_xent(logits, labels, acc2, n_global=4 * n)
+  assert_close(acc2.cpu()[0], ref.detach() / 4, 1e-5, 1e-6, "xent n_global")
+  assert_close(dl2.cpu(), lr.grad / 4, 1e-4, 1e-7, "dlogits n_global")
+
+
+def test_sigmoid_xent(dev):
+  """utils.py:236-243, incl. saturated logits (the stable log-sigmoid form) and forward-only."""
+  import bv_oracle as O
+  from big_vision_amd import ops
+  n, C = 5, 777
+  logits = rnd((n, C), dev, 4, 6.0)
+  logits[0, :4] = torch.tensor([80.0, -80.0, 1e-3, 30.0], device=dev)  # (not exactly 0: the oracle's min/abs form has a kink there)
+  labels = torch.rand((n, C), device=dev)
+  lr = logits.double().cpu().requires_grad_(True)
+  ref = O.sigmoid_xent(lr, labels.double().cpu())
+  ref.backward()
+  acc = torch.zeros(1, device=dev, dtype=torch.float64)
+  dl = ops.sigmoid_xent(logits, labels, acc)
+  assert_close(acc.cpu()[0], ref.detach(), 1e-5, 1e-5, "sigmoid xent")
+  assert_close(dl.cpu(), lr.grad, 1e-4, 1e-7, "sigmoid dlogits")
+  acc2 = torch.zeros(1, device=dev, dtype=torch.float64)
+  assert ops.sigmoid_xent(logits, labels, acc2, want_grad=False) is None
+  assert_close(acc2.cpu()[0], ref.detach(), 1e-5, 1e-5, "sigmoid xent fwd-only")
+
+
+def test_tanh_and_mixup(dev):
+  import bv_oracle as O
+  from big_vision_amd import ops
+  x = rnd((7, 384), dev, 5, 2.0)
+  y = ops.tanh_fwd(x)
+  assert_close(y, torch.tanh(x.double()), 1e-6, 1e-6, "tanh")
+  dy = rnd((7, 384), dev, 6)
+  assert_close(ops.tanh_bwd(y, dy), dy.double() * (1 - torch.tanh(x.double()) ** 2), 1e-5, 1e-6, "tanh bwd")
+  img = rnd((5, 8, 8, 3), dev, 7)
+  ref = O.mixup(0.7, img.double().cpu())[0]
+  assert_close(ops.mixup(img, 0.7).cpu(), ref, 1e-6, 1e-6, "mixup (roll by one along the batch)")
+  one = rnd((1, 12), dev, 8)
+  assert_close(ops.mixup(one, 0.3), one, 1e-6, 1e-6, "mixup n=1")
 
 
 # ------------------------------------------------------------- optimizer -----
