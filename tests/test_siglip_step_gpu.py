@@ -124,6 +124,17 @@ def test_b16_siglip_step_small_batch(dev):
   _run_case(dev, image_cfg, text_cfg, E=768, n=4, res=224, seq=64, vocab=32_000)
 
 
+def test_l16_336_siglip_step_small_batch(dev):
+  """BASELINE configs[3] shapes: ViT-L/16 at 336 px (441 tokens, width 1024, 16 heads) + text-L,
+  E = 1024, at n = 2: the long-sequence attention kernels (L > 224), the width-1024 LayerNorm
+  instantiation and ragged GEMM shapes (882 tokens) against the fp64 oracle.  Depth is cut from
+  24 to 4 blocks per tower to keep the CPU oracle at ~20 s (the full-depth model passed with the
+  same tolerances in 134 s; every block has the same shapes)."""
+  image_cfg = dict(variant="L/16", pool_type="map", depth=4)
+  text_cfg = dict(variant="L", depth=4)
+  _run_case(dev, image_cfg, text_cfg, E=1024, n=2, res=336, seq=64, vocab=32_000)
+
+
 @pytest.mark.parametrize("keep,light", [(0, False), (1, False), ("all", False), ("auto", "auto"),
                                         ("all", True), (2, True)])
 def test_microbatched_step_equals_full_batch(dev, keep, light):
