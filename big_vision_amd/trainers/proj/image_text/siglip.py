@@ -191,6 +191,16 @@ def make_update_fn(model, config, comm=None):
   return update_fn
 
 
+def make_predict_fn(model):
+  """`predict_fn(train_state, batch)` handed to the evaluators (siglip.py:388-392): either of
+  batch["image"] / batch["labels"] may be missing."""
+  def predict_fn(train_state, batch):
+    zimg, ztxt, out = model.apply({"params": train_state["params"]}, batch.get("image", None),
+                                  batch.get("labels", None), collect=False)
+    return zimg, ztxt, out
+  return predict_fn
+
+
 def check_finite(measurements):
   """NaN/Inf abort of siglip.py:468-470 (synchronises)."""
   for k, v in measurements.items():
