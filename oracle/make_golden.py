@@ -151,6 +151,49 @@ def main():
   out["hf_ztxt"] = res.text_embeds.numpy()
   out["hf_logits"] = res.logits_per_image.numpy()
   out["hf_loss"] = res.loss.numpy()
+  # HF's autograd gradients of its loss w.r.t. a selection of parameters, mapped back to the Flax
+  # names / layouts: pins the BACKWARD of the oracle (and through it the hand-written HIP
+  # backward) to an independent implementation.
+  hf.zero_grad()
+  res = hf(input_ids=text.long(),
+           pixel_values=torch.from_numpy(out["image"]).to(dt).permute(0, 3, 1, 2).contiguous(),
+           return_loss=True)
+  res.loss.backward()
+  g = {n: p_.grad for n, p_ in hf.named_parameters()}
+  D, H = c["width"], c["num_heads"]
+  L0 = "vision_model.encoder.layers.0"
+  T1 = "text_model.encoder.layers.1"
+  sel = {
+      "img/embedding/kernel": g["vision_model.embeddings.patch_embedding.weight"].permute(2, 3, 1, 0),
+      "img/embedding/bias": g["vision_model.embeddings.patch_embedding.bias"],
+      "img/pos_embedding": g["vision_model.embeddings.position_embedding.weight"][None],
+      "img/Transformer/encoderblock_0/LayerNorm_0/scale": g[L0 + ".layer_norm1.weight"],
+      "img/Transformer/encoderblock_0/MultiHeadDotProductAttention_0/query/kernel":
+          g[L0 + ".self_attn.q_proj.weight"].T.reshape(D, H, D // H),
+      "img/Transformer/encoderblock_0/MultiHeadDotProductAttention_0/key/bias":
+          g[L0 + ".self_attn.k_proj.bias"].reshape(H, D // H),
+      "img/Transformer/encoderblock_0/MultiHeadDotProductAttention_0/out/kernel":
+          g[L0 + ".self_attn.out_proj.weight"].T.reshape(H, D // H, D),
+      "img/Transformer/encoderblock_0/MlpBlock_0/Dense_0/kernel": g[L0 + ".mlp.fc1.weight"].T,
+      "img/Transformer/encoderblock_0/MlpBlock_0/Dense_1/bias": g[L0 + ".mlp.fc2.bias"],
+      "img/Transformer/encoder_norm/bias": g["vision_model.post_layernorm.bias"],
+      "img/MAPHead_0/probe": g["vision_model.head.probe"],
+      "img/MAPHead_0/MultiHeadDotProductAttention_0/value/kernel":
+          g["vision_model.head.attention.in_proj_weight"][2 * D:].T.reshape(D, H, D // H),
+      "img/MAPHead_0/MlpBlock_0/Dense_1/kernel": g["vision_model.head.mlp.fc2.weight"].T,
+      "txt/Embed_0/embedding": g["text_model.embeddings.token_embedding.weight"],
+      "txt/pos_embedding": g["text_model.embeddings.position_embedding.weight"][None],
+      "txt/Encoder_0/encoderblock_1/MultiHeadDotProductAttention_0/value/kernel":
+          g[T1 + ".self_attn.v_proj.weight"].T.reshape(D, H, D // H),
+      "txt/Encoder_0/encoderblock_1/MlpBlock_0/Dense_0/bias": g[T1 + ".mlp.fc1.bias"],
+      "txt/Encoder_0/encoder_norm/scale": g["text_model.final_layer_norm.weight"],
+      "txt/head/kernel": g["text_model.head.weight"].T,
+      "txt/head/bias": g["text_model.head.bias"],
+      "t": g["logit_scale"],
+      "b": g["logit_bias"],
+  }
+  for n, v in sel.items():
+    out["hfgrad:" + n] = v.detach().contiguous().numpy()
   dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
                      "siglip_hf_tiny.npz")
   np.savez_compressed(dst, **out)
