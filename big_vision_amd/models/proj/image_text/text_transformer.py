@@ -136,10 +136,14 @@ class _Model:
                Entry(f"{prefix}head/bias", (self.num_classes,), E.init_zeros)]
     return ents
 
+  def scan_prefixes(self, prefix=""):
+    """Encoders presented with stacked blocks (scan=True)."""
+    return (f"{prefix}Encoder_0",) if self.scan else ()
+
   def init(self, rng, text, **kw):
     del kw
     dev = text.device if torch.is_tensor(text) and text.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    store = ParamStore(self.entries("", text.shape[1]), dev)
+    store = ParamStore(self.entries("", text.shape[1]), dev, scan_prefixes=self.scan_prefixes())
     store.init_random(vit._seed_of(rng))
     store.refresh_shadow()
     return {"params": store.tree()}
@@ -158,7 +162,8 @@ class _Model:
     else:
       key = ("adhoc", id(params))
       if key not in self._execs:
-        store = ParamStore(self.entries("", text.shape[1]), torch.device("cuda", torch.cuda.current_device()))
+        store = ParamStore(self.entries("", text.shape[1]), torch.device("cuda", torch.cuda.current_device()),
+                           scan_prefixes=self.scan_prefixes())
         store.load_tree(params)
         self._execs[key] = store
       store, prefix = self._execs[key], ""
@@ -179,7 +184,10 @@ def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=in
   params = utils.tree_map(lambda x: x, params)
   extra_posemb = params["Encoder_0"].pop("pos_embedding", 0)
   params["pos_embedding"] = params["pos_embedding"] + extra_posemb
-  if "encoderblock" in params["Encoder_0"]:
-    tmp = vit.scan_to_pyloop({"Transformer": params["Encoder_0"]})
-    params["Encoder_0"] = tmp["Transformer"]
+  want_scan = bool(init_params) and "encoderblock" in init_params.get("Encoder_0", {})
+  have_scan = "encoderblock" in params["Encoder_0"]
+  if have_scan and not want_scan:
+    params["Encoder_0"] = vit.scan_to_pyloop({"Transformer": params["Encoder_0"]})["Transformer"]
+  elif want_scan and not have_scan:
+    params["Encoder_0"] = vit.pyloop_to_scan({"Transformer": params["Encoder_0"]})["Transformer"]
   return common.merge_params(params, init_params, dont_load)

@@ -106,9 +106,16 @@ class Model:
       ents.append(Entry(f"{prefix}b", (1,), E.init_const(self.bias_init)))
     return ents
 
+  def scan_prefixes(self, prefix=""):
+    sp = getattr(self.image_tower, "scan_prefixes", lambda p: ())(f"{prefix}img/")
+    return tuple(sp) + tuple(getattr(self.text_tower, "scan_prefixes", lambda p: ())(f"{prefix}txt/"))
+
   def leaf_names(self, image_shape, text_shape):
+    """Leaf names as presented (stacked `encoderblock` for towers built with scan=True)."""
+    from big_vision_amd.params import external_leaf_names
     hw = self.image_tower.grid(tuple(image_shape))
-    return sorted(l for e in self.entries("", hw, text_shape[1]) for l, _ in e.flax_leaves())
+    return external_leaf_names([l for e in self.entries("", hw, text_shape[1]) for l, _ in e.flax_leaves()],
+                               self.scan_prefixes())
 
   def make_store(self, image_shape, text_shape, device=None, frozen_leaves=()):
     """Allocates the flat parameter store for both towers (+ t, b).
@@ -118,15 +125,17 @@ class Model:
     device = device or torch.device("cuda", torch.cuda.current_device())
     hw = self.image_tower.grid(tuple(image_shape))
     ents = self.entries("", hw, text_shape[1])
+    from big_vision_amd.params import scan_name
     frozen_leaves = set(frozen_leaves)
+    sp = self.scan_prefixes()
     frozen = set()
     for e in ents:
-      hits = [leaf in frozen_leaves for leaf, _ in e.flax_leaves()]
+      hits = [scan_name(leaf, sp)[0] in frozen_leaves for leaf, _ in e.flax_leaves()]
       if any(hits) and not all(hits):
         raise NotImplementedError(f"fused tensor {e.name} is only partially frozen")
       if all(hits):
         frozen.add(e.name)
-    return ParamStore(ents, device, frozen=frozen)
+    return ParamStore(ents, device, frozen=frozen, scan_prefixes=sp)
 
   def init(self, rng, image, text=None, **kw):
     del kw

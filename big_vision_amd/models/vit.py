@@ -243,11 +243,15 @@ class _Model:
   def grid(self, image_shape):
     return (image_shape[1] // self.patch_size[0], image_shape[2] // self.patch_size[1])
 
+  def scan_prefixes(self, prefix=""):
+    """Encoders presented with stacked blocks (scan=True, vit.py:129-148)."""
+    return (f"{prefix}Transformer",) if self.scan else ()
+
   def init(self, rng, image, **kw):
     del kw
     shape = tuple(image.shape)
     dev = image.device if torch.is_tensor(image) and image.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    store = ParamStore(self.entries("", self.grid(shape)), dev)
+    store = ParamStore(self.entries("", self.grid(shape)), dev, scan_prefixes=self.scan_prefixes())
     store.init_random(_seed_of(rng))
     store.refresh_shadow()
     return {"params": store.tree()}
@@ -264,7 +268,7 @@ class _Model:
     key = ("adhoc", id(params))
     if key not in self._execs:
       dev = torch.device("cuda", torch.cuda.current_device())
-      store = ParamStore(self.entries("", hw), dev)
+      store = ParamStore(self.entries("", hw), dev, scan_prefixes=self.scan_prefixes())
       store.load_tree(params)
       self._execs[key] = store
     return self._execs[key], ""
@@ -346,9 +350,14 @@ def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=in
   init_file = VANITY_NAMES.get(init_file, init_file)
   restored_params = utils.load_params(init_file)
   restored_params = fix_old_checkpoints(restored_params)
-  # The accelerated encoder always uses the python-loop layout.
-  if "encoderblock" in restored_params["Transformer"]:
+  # Bring the checkpoint to the layout the model presents (vit.py:416-424): stacked blocks for
+  # scan=True models, encoderblock_{i} otherwise.
+  want_scan = bool(init_params) and "encoderblock" in init_params.get("Transformer", {})
+  have_scan = "encoderblock" in restored_params["Transformer"]
+  if have_scan and not want_scan:
     restored_params = scan_to_pyloop(restored_params)
+  elif want_scan and not have_scan:
+    restored_params = pyloop_to_scan(restored_params)
   del model_cfg
   restored_params = common.merge_params(restored_params, init_params, dont_load)
   if init_params and "pos_embedding" in init_params:

@@ -84,7 +84,7 @@ class Optimizer:
       for n in names:
         sched_idx_of_leaf[n] = len(self.schedule_fns) - 1
     assert len(self.schedule_fns) <= MAX_SCHED, "too many schedule groups"
-    frozen_entries = {store.leaf_index[n][0] for n in frozen}
+    frozen_entries = {e for n in frozen for e in store.entries_of(n)}
     if frozen_entries != set(store.frozen):
       raise ValueError("The parameter store was not laid out for this config.schedule: "
                        f"frozen in config {sorted(frozen_entries)[:4]}... vs store {sorted(store.frozen)[:4]}...")
@@ -128,7 +128,7 @@ class Optimizer:
     for e in store.entries.values():
       if e.name in store.frozen:
         continue
-      lv = [leaf for leaf, _ in e.flax_leaves()]
+      lv = [store.ext_of[leaf] for leaf, _ in e.flax_leaves()]   # names as presented (stacked if scanned)
       hp = {(lr_mult[l], wd[l], sched_idx_of_leaf[l]) for l in lv}
       if len(hp) != 1:
         raise NotImplementedError(f"fused tensor {e.name} has mixed optimizer hyper-parameters {hp}")

@@ -44,6 +44,23 @@ class Entry:
     return list(self.views.items())
 
 
+_BLOCK = re.compile(r"^(?P<pre>.*/)encoderblock_(?P<i>\d+)/(?P<rest>.+)$")
+
+
+def scan_name(name: str, scan_prefixes: Sequence[str]):
+  """`<enc>/encoderblock_<i>/<rest>` -> (`<enc>/encoderblock/<rest>`, i) for the encoders
+  listed in `scan_prefixes` (models built with scan=True: the reference stacks the blocks of
+  nn.scan on a leading `depth` axis, vit.py:129-148,363-405); (name, None) otherwise."""
+  m = _BLOCK.match(name)
+  if m and m.group("pre").rstrip("/") in scan_prefixes:
+    return f"{m.group('pre')}encoderblock/{m.group('rest')}", int(m.group("i"))
+  return name, None
+
+
+def external_leaf_names(leaves: Sequence[str], scan_prefixes: Sequence[str]) -> List[str]:
+  return sorted({scan_name(n, scan_prefixes)[0] for n in leaves})
+
+
 class ParamTree(dict):
   """Nested dict of parameter views that remembers the store it came from."""
   store = None
@@ -80,10 +97,17 @@ def flatten_tree(tree, prefix="") -> Dict[str, object]:
 
 
 class ParamStore:
-  def __init__(self, entries: List[Entry], device, frozen: Optional[Sequence[str]] = None):
+  def __init__(self, entries: List[Entry], device, frozen: Optional[Sequence[str]] = None,
+               scan_prefixes: Sequence[str] = ()):
     """`frozen`: storage-entry names placed at the END of the flat buffers so
-    the optimizer state / kernels only cover the trainable prefix."""
+    the optimizer state / kernels only cover the trainable prefix.
+    `scan_prefixes`: encoders (e.g. "img/Transformer") whose blocks are PRESENTED stacked,
+    `<enc>/encoderblock/<leaf>` with a leading depth axis, like a reference model built with
+    scan=True.  Storage and kernels are unchanged (one tensor per block); the stacked leaves
+    are strided views over the same flat buffers (all blocks of an encoder have the same
+    layout, so leaf i sits at offset0 + i * block_stride)."""
     self.device = torch.device(device)
+    self.scan_prefixes = tuple(scan_prefixes)
     frozen = set(frozen or ())
     self.entries: Dict[str, Entry] = {}
     order = [e for e in entries if e.name not in frozen] + [e for e in entries if e.name in frozen]
@@ -106,6 +130,14 @@ class ParamStore:
     for e in order:
       for leaf, sl in e.flax_leaves():
         self.leaf_index[leaf] = (e.name, sl)
+    # external (presentation) names: identical to the internal ones unless an encoder is scanned
+    self.ext_of: Dict[str, str] = {}
+    self.ext_index: Dict[str, List[str]] = {}
+    for leaf in self.leaf_index:
+      ext, i = scan_name(leaf, self.scan_prefixes)
+      self.ext_of[leaf] = ext
+      self.ext_index.setdefault(ext, []).append((i if i is not None else 0, leaf))
+    self.ext_index = {k: [l for _, l in sorted(v)] for k, v in self.ext_index.items()}
     self._shadow_dirty = True
     self.shadow_version = 0   # bumped whenever the bf16 shadow changes (cast / optimizer step)
 
@@ -148,19 +180,40 @@ class ParamStore:
     """Grad view of a storage tensor, or None if it is frozen."""
     return self.t(name, "grad") if name not in self.frozen else None
 
-  def leaf(self, leaf_name: str, buf: str = "master") -> torch.Tensor:
+  def _leaf_internal(self, leaf_name: str, buf: str) -> torch.Tensor:
     sname, sl = self.leaf_index[leaf_name]
     t = self.t(sname, buf)
     return t if sl is None else t.select(sl[0], sl[1])
 
+  def leaf(self, leaf_name: str, buf: str = "master") -> torch.Tensor:
+    """View of one (external) Flax leaf in buffer `buf`; scanned encoders give the stacked
+    `[depth, ...]` view.  Internal per-block names are accepted too."""
+    group = self.ext_index.get(leaf_name)
+    if group is None or (len(group) == 1 and group[0] == leaf_name):
+      return self._leaf_internal(leaf_name, buf)
+    views = [self._leaf_internal(l, buf) for l in group]
+    v0 = views[0]
+    if len(views) == 1:
+      return v0.unsqueeze(0)
+    step = views[1].storage_offset() - v0.storage_offset()
+    for k, v in enumerate(views):
+      if (tuple(v.shape), v.stride(), v.storage_offset()) != (tuple(v0.shape), v0.stride(), v0.storage_offset() + k * step):
+        raise RuntimeError(f"blocks of {leaf_name} are not laid out uniformly; cannot present them stacked")
+    return torch.as_strided(self._buf(buf), (len(views),) + tuple(v0.shape), (step,) + tuple(v0.stride()),
+                            v0.storage_offset())
+
   def leaf_names(self) -> List[str]:
-    return sorted(self.leaf_index.keys())
+    """External leaf names (what checkpoints and config regexes address)."""
+    return sorted(self.ext_index.keys())
+
+  def entries_of(self, leaf_name: str) -> List[str]:
+    """Storage entries behind an external leaf (depth of them for a stacked leaf)."""
+    return [self.leaf_index[l][0] for l in self.ext_index[leaf_name]]
 
   def tree(self, buf: str = "master") -> ParamTree:
     flat = {}
     for n in self.leaf_names():
-      sname, _ = self.leaf_index[n]
-      if buf == "grad" and sname in self.frozen:
+      if buf == "grad" and any(e in self.frozen for e in self.entries_of(n)):
         continue
       flat[n] = self.leaf(n, buf)
     return _nest(flat, self, buf)
@@ -171,19 +224,23 @@ class ParamStore:
     gen = torch.Generator().manual_seed(int(seed))
     for e in self.entries.values():
       for leaf, sl in e.flax_leaves():
-        dst = self.leaf(leaf)
+        dst = self._leaf_internal(leaf, "master")
         val = e.init(gen, tuple(dst.shape))
         dst.copy_(val.to(torch.float32).to(self.device))
     self._shadow_dirty = True
 
   def load_tree(self, tree, strict: bool = True):
     flat = flatten_tree(tree)
-    missing = [n for n in self.leaf_index if n not in flat]
-    extra = [n for n in flat if n not in self.leaf_index]
+    # accept the presented layout (stacked for scanned encoders) and the per-block one
+    known = set(self.ext_index) | set(self.leaf_index)
+    covered = {l for n in flat if n in self.ext_index for l in self.ext_index[n]} | \
+              {n for n in flat if n in self.leaf_index}
+    missing = [n for n in self.leaf_index if n not in covered]
+    extra = [n for n in flat if n not in known]
     if strict and (missing or extra):
       raise ValueError(f"Parameter tree mismatch. Missing: {missing[:8]} Unexpected: {extra[:8]}")
     for n, v in flat.items():
-      if n not in self.leaf_index:
+      if n not in known:
         continue
       dst = self.leaf(n)
       v = torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v)

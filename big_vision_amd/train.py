@@ -55,17 +55,19 @@ def make_train_state(model, config, image_shape, *, rng=0, comm=None, total_step
   comm = comm or dp.Comm()
   device = device or torch.device("cuda", torch.cuda.current_device())
   hw = model.grid(tuple(image_shape))
+  from big_vision_amd.params import external_leaf_names, scan_name
   ents = model.entries("", hw)
-  leaves = [leaf for e in ents for leaf, _ in e.flax_leaves()]
+  sp = model.scan_prefixes()
+  leaves = external_leaf_names([leaf for e in ents for leaf, _ in e.flax_leaves()], sp)
   frozen_leaves = bv_optax.frozen_leaves(config, leaves)
   frozen = set()
   for e in ents:
-    hits = [leaf in frozen_leaves for leaf, _ in e.flax_leaves()]
+    hits = [scan_name(leaf, sp)[0] in frozen_leaves for leaf, _ in e.flax_leaves()]
     if any(hits) and not all(hits):
       raise NotImplementedError(f"fused tensor {e.name} is only partially frozen")
     if all(hits):
       frozen.add(e.name)
-  store = ParamStore(ents, device, frozen=frozen)
+  store = ParamStore(ents, device, frozen=frozen, scan_prefixes=sp)
   store.init_random(_seed_of(rng))
   store.refresh_shadow()
   store.want_grads = True

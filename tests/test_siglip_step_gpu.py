@@ -15,6 +15,8 @@ oracle restatement of the reference step (oracle/bv_oracle.py).  Tolerances
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -178,3 +180,44 @@ def test_microbatched_step_equals_full_batch(dev, keep, light):
     for k, v in g_ref.items():
       assert (v - g_mb[k]).norm().item() <= 1e-5 * max(v.norm().item(), 1e-3 * gn), \
           f"light context changed {k}"
+
+
+def test_scan_layout_model_steps_like_the_pyloop_model(dev):
+  """scan=True only changes how parameters are PRESENTED (stacked `encoderblock` leaves, strided
+  views of the same storage): same seed -> same loss, and the stacked gradient leaves are the
+  per-block gradients stacked."""
+  import bv_oracle as O
+  from big_vision_amd.models import vit
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  from big_vision_amd import utils as u
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+
+  def run(scan):
+    model = two_towers.Model(image=dict(image_cfg, scan=scan), text=dict(text_cfg, scan=scan), out_dim=(None, 128),
+                             temperature_init=10.0, bias_init=-10.0)
+    config = _cfg()
+    state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0,
+                                       total_steps=config.total_steps)
+    state, meas = siglip.make_update_fn(model, config)(state, None, batch)
+    g = u.tree_map(lambda v: v.detach().cpu().clone().numpy(), dict(state["params"].store.tree("grad")))
+    p = u.tree_map(lambda v: v.detach().cpu().clone().numpy(), dict(state["params"]))
+    return meas["training_loss"].item(), g, p
+
+  loss_a, g_a, p_a = run(False)
+  loss_b, g_b, p_b = run(True)
+  assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)
+  for tree_a, tree_b in ((g_a, g_b), (p_a, p_b)):
+    want = dict(tree_a)
+    want["img"] = vit.pyloop_to_scan(tree_a["img"])
+    want["txt"] = dict(tree_a["txt"])
+    want["txt"]["Encoder_0"] = vit.pyloop_to_scan({"Transformer": tree_a["txt"]["Encoder_0"]})["Transformer"]
+    fa, fb = dict(u.tree_flatten_with_names(want)[0]), dict(u.tree_flatten_with_names(tree_b)[0])
+    assert fa.keys() == fb.keys()
+    gn = math.sqrt(sum(float((v ** 2).sum()) for v in fa.values()))
+    for k in fa:
+      assert fa[k].shape == fb[k].shape, k
+      assert float(np.linalg.norm(fa[k] - fb[k])) <= 1e-5 * max(float(np.linalg.norm(fa[k])), 1e-3 * gn), k
