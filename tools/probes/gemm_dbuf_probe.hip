@@ -319,6 +319,253 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
   }
 }
 
+// =====================================================================================
+// v2 (NOT YET RUN ON A GPU): same idea, shaped for the load LATENCY that v1 exposed.  With
+// K-tiles of ~1300 cycles a 3-stage ring gives the loads one K-tile of lead, less than the
+// latency of the HBM-streamed operand (A = activations: every row panel is a first touch).
+// Tile 128 (M) x 256 (N): the streamed operand is only a third of the bytes of a stage, so it
+// gets a FOUR-stage ring (16 KiB stages, loads 3 K-tiles ahead, >= 2 K-tiles of lead) while the
+// L2-resident weights keep three 32 KiB stages (2 ahead): 64 + 96 = 160 KiB.  8 waves as
+// 2(M) x 4(N), wave tile 64 x 64, two accumulator sets, trickled epilogue as in v1.
+constexpr int D2_NA = 4, D2_NB = 3;
+constexpr int D2_A_BYTES = D2_NA * HALF;                    // 65536
+constexpr int D2_SMEM = D2_A_BYTES + D2_NB * 2 * HALF;      // 163840
+
+template <int PROBE = 0>
+__global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // tiles_n = N/256, ntiles = (M/128)*(N/256)
+  __shared__ __attribute__((aligned(1024))) char smem[D2_SMEM];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2;             // 64-row block of the tile AND ping-pong group
+  const int wn = wave & 3;              // 64-column block
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int bid = blockIdx.x, G = gridDim.x;
+  const int nwork = p.ntiles;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q8 = nwork >> 3, r8 = nwork & 7;
+  const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cl = q8 + (xcd < r8 ? 1 : 0);
+  const int bpx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+  const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
+  if (nmy == 0) return;
+  const int nk = p.K >> 6;
+
+  auto load_item = [&](DbCursor& c) {
+    const int w = cs + idx + c.j * bpx;
+    const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
+    c.m0 = tm * 128; c.n0 = tn * 256;
+    c.nk = nk;
+    c.offA = (long)c.m0 * p.lda;
+    c.offB = (long)c.n0 * p.ldb;
+  };
+  auto advance = [&](DbCursor& c) {
+    if (++c.t == c.nk) {
+      c.t = 0;
+      ++c.j;
+      if (c.j < nmy) load_item(c);
+    }
+  };
+
+  const int r = wave * 8 + (lane >> 3);
+  const int pos = lane & 7;
+  const int ch = pos ^ kswz(r);
+  const bf16* srcA = p.A + (long)r * p.lda + ch * 8;
+  const bf16* srcB = p.B + (long)r * p.ldb + ch * 8;
+  const long gA = 64 * p.lda, gB = 64 * p.ldb, hB = 128 * p.ldb;
+  const int wave_off = wave * 1024;
+  auto issueA = [&](const DbCursor& c, int slot) {   // 2 DMA instructions per thread
+    char* d = smem + slot * HALF + wave_off;
+    const bf16* s = srcA + c.offA + (long)c.t * 64;
+    glds16(s, d);
+    glds16(s + gA, d + 8192);
+  };
+  auto issueB = [&](const DbCursor& c, int slot) {   // 4 DMA instructions per thread
+    char* d = smem + D2_A_BYTES + slot * 2 * HALF + wave_off;
+    const bf16* s = srcB + c.offB + (long)c.t * 64;
+    glds16(s, d);
+    glds16(s + gB, d + 8192);
+    glds16(s + hB, d + HALF);
+    glds16(s + hB + gB, d + HALF + 8192);
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int brow = (lr >> 2) * 8 + (lr & 3);
+  const uint32_t ra0 = lds0 + (wm * 64 + lr) * 128 + ((lg ^ kswz(lr)) << 4);
+  const uint32_t ra1 = ra0 ^ 64;
+  const uint32_t rb0 = lds0 + D2_A_BYTES + (wn >> 1) * HALF + ((wn & 1) * 64 + brow) * 128 + ((lg ^ kswz(brow)) << 4);
+  const uint32_t rb1 = rb0 ^ 64;
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bfg[4][2];
+
+  auto readA01 = [&](uint32_t sa) {
+    const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
+    af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
+    af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
+  };
+  auto readA23 = [&](uint32_t sa) {
+    const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
+    af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
+    af[3][0] = lds_read128<6144>(a1);  af[3][1] = lds_read128<6144>(a0);
+  };
+  auto readB = [&](uint32_t sb) {
+    const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
+    bfg[0][0] = lds_read128<0>(b0);     bfg[0][1] = lds_read128<0>(b1);
+    bfg[1][0] = lds_read128<512>(b1);   bfg[1][1] = lds_read128<512>(b0);
+    bfg[2][0] = lds_read128<4096>(b0);  bfg[2][1] = lds_read128<4096>(b1);
+    bfg[3][0] = lds_read128<4608>(b1);  bfg[3][1] = lds_read128<4608>(b0);
+  };
+
+#define D2_MFMA(Q, I0)                                                                        \
+  do {                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
+          acc[Q][(I0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+              bfg[j][ks], af[(I0) + i][ks], acc[Q][(I0) + i][j], 0, 0, 0);                    \
+    __builtin_amdgcn_s_setprio(0);                                                            \
+  } while (0)
+#define D2_MID()                                          \
+  do {                                                    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+#define D2_END()                             \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+  } while (0)
+#define D2_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+  int pend = 0, pm0 = 0, pn0 = 0;
+  const long lane_off = (long)(wm * 64 + lr) * p.ldc + wn * 64 + lg * 8;
+  auto store_unit = [&](auto Qtag, auto Utag) {
+    constexpr int Q = decltype(Qtag)::value, U = decltype(Utag)::value;
+    const long tile_off = (long)(pm0 + U * 16) * p.ldc + pn0;
+    bf16* c = p.C + tile_off + lane_off;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x4 x = acc[Q][U][2 * hh], y = acc[Q][U][2 * hh + 1];
+      u32x4 o;
+      o[0] = pack_bf2(x[0] * p.alpha, x[1] * p.alpha);
+      o[1] = pack_bf2(x[2] * p.alpha, x[3] * p.alpha);
+      o[2] = pack_bf2(y[0] * p.alpha, y[1] * p.alpha);
+      o[3] = pack_bf2(y[2] * p.alpha, y[3] * p.alpha);
+      if (PROBE != 5) *reinterpret_cast<u32x4*>(c + hh * 32) = o;
+      else asm volatile("" ::"v"(o));
+      acc[Q][U][2 * hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[Q][U][2 * hh + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto trickle = [&](auto Qtag) {
+    switch (4 - pend) {
+      case 0: store_unit(Qtag, std::integral_constant<int, 0>{}); break;
+      case 1: store_unit(Qtag, std::integral_constant<int, 1>{}); break;
+      case 2: store_unit(Qtag, std::integral_constant<int, 2>{}); break;
+      default: store_unit(Qtag, std::integral_constant<int, 3>{}); break;
+    }
+    --pend;
+  };
+
+  // ---- prologue: B(0) A(0) | B(1) A(1) A(2) in flight; K-tile 0 landed
+  DbCursor cur{};
+  cur.j = 0; cur.t = 0;
+  load_item(cur);
+  DbCursor ca = cur, cb = cur;     // A stream runs 3 K-tiles ahead of the math, B stream 2
+  issueB(cb, 0); issueA(ca, 0);
+  advance(ca); advance(cb);
+  int a_prev = 0;                  // A DMA issued after the most recent B issue (see the wait below)
+  {
+    int after = 0;
+    if (cb.j < nmy) { issueB(cb, 1); advance(cb); after += 4; }
+    if (ca.j < nmy) { issueA(ca, 1); advance(ca); after += 2; }
+    if (ca.j < nmy) { issueA(ca, 2); advance(ca); after += 2; a_prev = 2; }
+    if (after == 8) D2_WAIT(8);
+    else if (after == 6) D2_WAIT(6);
+    else D2_WAIT(0);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind waves 0-3
+
+  int slotA = 0, slotB = 0, stores_prev = 0;
+
+  auto tile = [&](auto Ptag) {
+    constexpr int P = decltype(Ptag)::value;
+    using Qt = std::integral_constant<int, 1 - P>;
+    for (int t = 0; t < nk; ++t) {
+      const uint32_t sa = slotA * HALF, sb = slotB * 2 * HALF;
+      const int slotA3 = (slotA + 3) & 3;                 // K-tile k+3 -> the slot K-tile k-1 used
+      const int slotB2 = slotB == 0 ? 2 : slotB - 1;      // K-tile k+2 -> the slot K-tile k-1 used
+      const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
+      // -------- phase a
+      readA01(sa);
+      readB(sb);
+      if (moreB) issueB(cb, slotB2);
+      D2_MID();
+      D2_MFMA(P, 0);
+      D2_END();
+      // -------- phase b
+      readA23(sa);
+      if (moreA) issueA(ca, slotA3);
+      // in-order queue: ... B(k+1)x4 | A(k+2)x2 [a_prev] | stores(k-1) | B(k+2)x4 | A(k+3)x2 :
+      // K-tile k+1 needs everything up to and including B(k+1)
+      {
+        const int allow = a_prev + stores_prev + (moreB ? 4 : 0) + (moreA ? 2 : 0);
+        if (allow >= 10) D2_WAIT(10);
+        else if (allow >= 8) D2_WAIT(8);
+        else if (allow >= 6) D2_WAIT(6);
+        else if (allow >= 4) D2_WAIT(4);
+        else if (allow >= 2) D2_WAIT(2);
+        else D2_WAIT(0);
+      }
+      D2_MID();
+      stores_prev = 0;
+      if (pend > 0) {
+        trickle(Qt{});
+        stores_prev = 2;
+      }
+      D2_MFMA(P, 2);
+      D2_END();
+      a_prev = moreA ? 2 : 0;
+      if (moreA) advance(ca);
+      if (moreB) advance(cb);
+      slotA = (slotA + 1) & 3;
+      slotB = slotB == 2 ? 0 : slotB + 1;
+    }
+    while (pend > 0) trickle(Qt{});
+    pend = 4;
+    pm0 = cur.m0; pn0 = cur.n0;
+    ++cur.j;
+    if (cur.j < nmy) {
+      const int w = cs + idx + cur.j * bpx;
+      const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
+      cur.m0 = tm * 128; cur.n0 = tn * 256;
+    }
+  };
+
+  for (int jt = 0; jt < nmy; jt += 2) {
+    tile(std::integral_constant<int, 0>{});
+    if (jt + 1 < nmy) tile(std::integral_constant<int, 1>{});
+  }
+  if ((nmy - 1) & 1) { while (pend > 0) trickle(std::integral_constant<int, 1>{}); }
+  else { while (pend > 0) trickle(std::integral_constant<int, 0>{}); }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef D2_MFMA
+#undef D2_MID
+#undef D2_END
+#undef D2_WAIT
+}
+
 }  // namespace
 
 static void fill(void* d, size_t n_bf16, unsigned seed) {
@@ -391,6 +638,24 @@ int main() {
     const float t5 = time_ms([&] { hipLaunchKernelGGL((gemm_dbuf_kernel<5>), dim3(g1), dim3(512), 0, 0, d); }, 5);
     printf("%-34s mismatches vs gemm256: %zu%s | gemm256 %.3f ms %6.0f TF | dbuf %.3f ms %6.0f TF | dbuf no-stores %.3f ms\n",
            s.name, bad, ref_ok ? "" : " (no reference: N % 256)", t0, t0 > 0 ? fl / t0 / 1e9 : 0.0, t1, fl / t1 / 1e9, t5);
+    // ---- v2: 128 x 256 tiles
+    if (ref_ok && s.M % 128 == 0) {
+      DbParams d2 = d;
+      d2.tiles_n = s.N / 256; d2.ntiles = (s.M / 128) * d2.tiles_n;
+      const int g2 = d2.ntiles < 256 ? d2.ntiles : 256;
+      hipMemset(c1, 0xee, (size_t)s.M * s.N * 2);
+      hipLaunchKernelGGL((gemm_dbuf2_kernel<0>), dim3(g2), dim3(512), 0, 0, d2);
+      hipDeviceSynchronize();
+      std::vector<unsigned short> h0((size_t)s.M * s.N), h1((size_t)s.M * s.N);
+      hipMemcpy(h0.data(), c0, h0.size() * 2, hipMemcpyDeviceToHost);
+      hipMemcpy(h1.data(), c1, h1.size() * 2, hipMemcpyDeviceToHost);
+      size_t bad2 = 0;
+      for (size_t i = 0; i < h0.size(); ++i) bad2 += h0[i] != h1[i];
+      const float u1 = time_ms([&] { hipLaunchKernelGGL((gemm_dbuf2_kernel<0>), dim3(g2), dim3(512), 0, 0, d2); }, 5);
+      const float u5 = time_ms([&] { hipLaunchKernelGGL((gemm_dbuf2_kernel<5>), dim3(g2), dim3(512), 0, 0, d2); }, 5);
+      printf("%-34s   v2 (128x256, A 4 stages): mismatches %zu | %.3f ms %6.0f TF | no-stores %.3f ms\n", "", bad2, u1,
+             fl / u1 / 1e9, u5);
+    }
   }
   return 0;
 }
