@@ -24,16 +24,18 @@
 // ones of gemm256.hip, which this file includes (also as the bit-exact reference: both kernels
 // accumulate K in the same order).
 //
-// STATUS (end of round 1, one run on MI355X): BIT-EXACT against gemm256 on every shape below
-// (incl. 100352 x 3072 x 768), but the main loop runs at HALF the speed (qkv forward 456 TF/s vs
-// 951; without stores 0.64 ms vs 0.78 ms, so it is the K loop, not the epilogue): ~4000 cycles
-// per 256x128x64 K-tile instead of ~1300.  The phase code is clean in the ISA (12 + 4 ds_reads,
-// 2 + 4 DMA, 16 MFMAs per phase).  First things to look at next round: (1) per-phase s_memtime
-// stamps (gemm256 PROBE 9 style) to see whether the time sits at the counted vmcnt (loads only
-// ~1 K-tile = 1300 cycles ahead of their use: latency-bound) or at the LDS reads; (2) that run
-// has C++ stores in the trickle, before which the compiler puts s_waitcnt vmcnt(0) (see the
-// note there); (3) deeper prefetch: 4 stages of BK = 32, or issue both A and B of K-tile k+2 in
-// phase a of K-tile k behind an lgkmcnt-retired read.
+// STATUS (end of round 1).  Two runs on the MI355X with the FIRST form of the trickle (a runtime
+// switch over the four fragments): v1 and v2 BIT-EXACT against gemm256 on every shape below (incl.
+// 100352 x 3072 x 768), but at half its speed (qkv forward 453-469 TF/s vs 947; the same without
+// the stores, the same with v2's deeper A ring - so neither the stores nor the load latency).  The
+// cause was found afterwards in the ISA: the optimiser merges the switch cases into one block
+// with a computed fragment index, which moves a whole accumulator set into SCRATCH memory
+// (ScratchSize 272 B/lane, 72 scratch_load/store in the loop - VMEM instructions in the same
+// in-order queue as the DMA, each followed by a wait that drains the load pipeline).  The code
+// below peels the first four K-tiles of a tile into separate instantiations (compile-time
+// fragment index): ScratchSize 0, 192 VGPRs, no wait in front of the trickled stores in the ISA.
+// THIS FORM HAS NOT RUN ON A GPU YET (the round's GPU budget was spent) - first thing to do next
+// round: run this probe (bit-exactness check + timing are built in).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
     p.dbg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
   }
 
-  auto load_item = [&](DbCursor& c) {
+  auto load_item = [&](DbCursor& c) __attribute__((always_inline)) {
     const int w = cs + idx + c.j * bpx;
     const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
     c.m0 = tm * 256; c.n0 = tn * 128;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
     c.offA = (long)c.m0 * p.lda;
     c.offB = (long)c.n0 * p.ldb;
   };
-  auto advance = [&](DbCursor& c) {
+  auto advance = [&](DbCursor& c) __attribute__((always_inline)) {
     if (++c.t == c.nk) {
       c.t = 0;
       ++c.j;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
   const bf16* srcB = p.B + (long)r * p.ldb + ch * 8;
   const long gA = 64 * p.lda, gB = 64 * p.ldb, hA = 128 * p.lda;
   const int wave_off = wave * 1024;
-  auto issueA = [&](const DbCursor& c, int slot) {   // 4 DMA instructions per thread
+  auto issueA = [&](const DbCursor& c, int slot) __attribute__((always_inline)) {   // 4 DMA instructions per thread
     char* d = smem + slot * DB_STAGE + wave_off;
     const bf16* s = srcA + c.offA + (long)c.t * 64;
     glds16(s, d);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
     glds16(s + hA, d + HALF);
     glds16(s + hA + gA, d + HALF + 8192);
   };
-  auto issueB = [&](const DbCursor& c, int slot) {   // 2 DMA instructions per thread
+  auto issueB = [&](const DbCursor& c, int slot) __attribute__((always_inline)) {   // 2 DMA instructions per thread
     char* d = smem + slot * DB_STAGE + 2 * HALF + wave_off;
     const bf16* s = srcB + c.offB + (long)c.t * 64;
     glds16(s, d);
@@ -150,17 +152,17 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
   bf16x8 af[4][2], bfg[4][2];
 
   // odd fragments (row bit 4 / row bit 2 set) swap the two k-step bases (kswz bit 2 flips)
-  auto readA01 = [&](uint32_t sb) {
+  auto readA01 = [&](uint32_t sb) __attribute__((always_inline)) {
     const uint32_t a0 = ra0 + sb, a1 = ra1 + sb;
     af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
     af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
   };
-  auto readA23 = [&](uint32_t sb) {
+  auto readA23 = [&](uint32_t sb) __attribute__((always_inline)) {
     const uint32_t a0 = ra0 + sb, a1 = ra1 + sb;
     af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
     af[3][0] = lds_read128<6144>(a1);  af[3][1] = lds_read128<6144>(a0);
   };
-  auto readB = [&](uint32_t sb) {
+  auto readB = [&](uint32_t sb) __attribute__((always_inline)) {
     const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
     bfg[0][0] = lds_read128<0>(b0);     bfg[0][1] = lds_read128<0>(b1);
     bfg[1][0] = lds_read128<512>(b1);   bfg[1][1] = lds_read128<512>(b0);
@@ -191,11 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
   } while (0)
 
   // ---- trickled epilogue: row fragment U of accumulator set Q -> C (2 x 16-B stores per lane)
-  int pend = 0;          // fragments of the previous tile still to be written
   int pm0 = 0, pn0 = 0;  // origin of the previous tile
   // per-lane part of the output address (elements); the tile / fragment part is wave-uniform
   const long lane_off = (long)(grp * 128 + wsub * 64 + lr) * p.ldc + wc * 64 + lg * 8;
-  auto store_unit = [&](auto Qtag, auto Utag) {
+  auto store_unit = [&](auto Qtag, auto Utag) __attribute__((always_inline)) {
     constexpr int Q = decltype(Qtag)::value, U = decltype(Utag)::value;
     const long tile_off = (long)(pm0 + U * 16) * p.ldc + pn0;          // SGPRs
     bf16* c = p.C + tile_off + lane_off;
@@ -207,27 +208,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
       o[1] = pack_bf2(x[2] * p.alpha, x[3] * p.alpha);
       o[2] = pack_bf2(y[0] * p.alpha, y[1] * p.alpha);
       o[3] = pack_bf2(y[2] * p.alpha, y[3] * p.alpha);
-      // NOTE: the compiler puts s_waitcnt vmcnt(0) in front of these stores (the output may alias
-      // the operands of the in-flight DMA), which drains the load pipeline at every fragment; an
-      // inline-asm global_store made the register allocator spill 188 VGPRs - to be solved.
       if (PROBE != 5) *reinterpret_cast<u32x4*>(c + hh * 32) = o;
       else asm volatile("" ::"v"(o));
       acc[Q][U][2 * hh] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[Q][U][2 * hh + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto trickle = [&](auto Qtag) {   // next pending fragment of set Q (uniform switch: static indices)
-    using I = std::integral_constant<int, 0>;
-    switch (4 - pend) {
-      case 0: store_unit(Qtag, std::integral_constant<int, 0>{}); break;
-      case 1: store_unit(Qtag, std::integral_constant<int, 1>{}); break;
-      case 2: store_unit(Qtag, std::integral_constant<int, 2>{}); break;
-      default: store_unit(Qtag, std::integral_constant<int, 3>{}); break;
-    }
-    (void)sizeof(I);
-    --pend;
-  };
-
+  // The fragment index must be a COMPILE-TIME constant all the way: a runtime switch over the
+  // four fragments is merged by the optimiser into one block with a computed index, which puts a
+  // whole accumulator set into scratch memory (272 B/lane, scratch loads/stores in the same
+  // in-order VMEM queue as the DMA: the first GPU run of this probe, at half speed).  The first
+  // four K-tiles of a tile are therefore separate instantiations of the K-tile body.
+  bool has_prev = false;   // a finished tile is waiting in the other accumulator set
   // ---- prologue: K-tiles 0 and 1 of the stream in flight, K-tile 0 landed
   DbCursor cur{};
   cur.j = 0; cur.t = 0;
@@ -248,57 +240,66 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
   int slot = 0;           // ring slot of the K-tile being consumed
   int stores_prev = 0;    // trickle stores issued in the previous K-tile (after its DMA)
 
-  auto tile = [&](auto Ptag) {
-    constexpr int P = decltype(Ptag)::value;
-    using Qt = std::integral_constant<int, 1 - P>;
-    for (int t = 0; t < nk; ++t) {
-      const uint32_t sb = slot * DB_STAGE;
-      const int slot2 = slot == 0 ? 2 : slot - 1;      // (slot + 2) % 3: slot of K-tile k+2 = K-tile k-1's
-      const bool more = ld.j < nmy;
-      // -------- phase a: rows 0-31 of the wave tile
-      readA01(sb);
-      readB(sb);
-      if (more) issueB(ld, slot2);
-      DB_MID();
-      DB_MFMA(P, 0);
-      DB_END();
-      // -------- phase b: rows 32-63; retire K-tile k+1's loads; one fragment of the previous tile
-      readA23(sb);
-      if (more) issueA(ld, slot2);
-      // in-order queue: ... [A(k+1)] [stores of K-tile k-1] [B(k+2) x2, A(k+2) x4]: retire through A(k+1)
-      if (more) {
-        if (stores_prev) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else {
-        if (stores_prev) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      DB_MID();
-      stores_prev = 0;
-      if (pend > 0) {
-        trickle(Qt{});
+  // one K-tile of the tile in accumulator set P; U >= 0: also write fragment U of the previous tile
+  auto ktile = [&](auto Ptag, auto Utag) __attribute__((always_inline)) {
+    constexpr int P = decltype(Ptag)::value, U = decltype(Utag)::value;
+    const uint32_t sb = slot * DB_STAGE;
+    const int slot2 = slot == 0 ? 2 : slot - 1;      // (slot + 2) % 3: slot of K-tile k+2 = K-tile k-1's
+    const bool more = ld.j < nmy;
+    // -------- phase a: rows 0-31 of the wave tile
+    readA01(sb);
+    readB(sb);
+    if (more) issueB(ld, slot2);
+    DB_MID();
+    DB_MFMA(P, 0);
+    DB_END();
+    // -------- phase b: rows 32-63; retire K-tile k+1's loads; one fragment of the previous tile
+    readA23(sb);
+    if (more) issueA(ld, slot2);
+    // in-order queue: ... [A(k+1)] [stores of K-tile k-1] [B(k+2) x2, A(k+2) x4]: retire through A(k+1)
+    if (more) {
+      if (stores_prev) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      if (stores_prev) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DB_MID();
+    stores_prev = 0;
+    if constexpr (U >= 0) {
+      if (has_prev) {
+        store_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, U>{});
         stores_prev = 2;
       }
-      DB_MFMA(P, 2);
-      DB_END();
-      if (more) advance(ld);
-      slot = slot == 2 ? 0 : slot + 1;
     }
-    // tile finished: whatever is left of the PREVIOUS tile (K loops shorter than 4 K-tiles) goes out now
-    while (pend > 0) trickle(Qt{});
-    pend = 4;
+    DB_MFMA(P, 2);
+    DB_END();
+    if (more) advance(ld);
+    slot = slot == 2 ? 0 : slot + 1;
+  };
+  auto flush = [&](auto Qtag, int from) __attribute__((always_inline)) {   // fragments `from`..3 of set Q
+    if (from <= 0) store_unit(Qtag, std::integral_constant<int, 0>{});
+    if (from <= 1) store_unit(Qtag, std::integral_constant<int, 1>{});
+    if (from <= 2) store_unit(Qtag, std::integral_constant<int, 2>{});
+    if (from <= 3) store_unit(Qtag, std::integral_constant<int, 3>{});
+  };
+  auto tile = [&](auto Ptag) __attribute__((always_inline)) {
+    constexpr int P = decltype(Ptag)::value;
+    using NoU = std::integral_constant<int, -1>;
+    if (nk > 0) ktile(Ptag, std::integral_constant<int, 0>{});
+    if (nk > 1) ktile(Ptag, std::integral_constant<int, 1>{});
+    if (nk > 2) ktile(Ptag, std::integral_constant<int, 2>{});
+    if (nk > 3) ktile(Ptag, std::integral_constant<int, 3>{});
+    for (int t = 4; t < nk; ++t) ktile(Ptag, NoU{});
+    // K loops shorter than 4 K-tiles: the rest of the PREVIOUS tile goes out now
+    if (has_prev && nk < 4) flush(std::integral_constant<int, 1 - P>{}, nk);
+    has_prev = true;
     pm0 = cur.m0; pn0 = cur.n0;
-    cur.t = cur.nk - 1;
-    {
-      if (++cur.t == cur.nk) {
-        cur.t = 0;
-        ++cur.j;
-        if (cur.j < nmy) {
-          const int w = cs + idx + cur.j * bpx;
-          const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
-          cur.m0 = tm * 256; cur.n0 = tn * 128;
-        }
-      }
+    ++cur.j;
+    if (cur.j < nmy) {
+      const int w = cs + idx + cur.j * bpx;
+      const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
+      cur.m0 = tm * 256; cur.n0 = tn * 128;
     }
   };
 
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf_kernel(DbParams p) {
     if (jt + 1 < nmy) tile(std::integral_constant<int, 1>{});
   }
   // the last tile's results
-  if ((nmy - 1) & 1) { while (pend > 0) trickle(std::integral_constant<int, 1>{}); }
-  else { while (pend > 0) trickle(std::integral_constant<int, 0>{}); }
+  if ((nmy - 1) & 1) flush(std::integral_constant<int, 1>{}, 0);
+  else flush(std::integral_constant<int, 0>{}, 0);
   if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
 #undef DB_MFMA
 #undef DB_MID
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
   if (nmy == 0) return;
   const int nk = p.K >> 6;
 
-  auto load_item = [&](DbCursor& c) {
+  auto load_item = [&](DbCursor& c) __attribute__((always_inline)) {
     const int w = cs + idx + c.j * bpx;
     const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
     c.m0 = tm * 128; c.n0 = tn * 256;
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
     c.offA = (long)c.m0 * p.lda;
     c.offB = (long)c.n0 * p.ldb;
   };
-  auto advance = [&](DbCursor& c) {
+  auto advance = [&](DbCursor& c) __attribute__((always_inline)) {
     if (++c.t == c.nk) {
       c.t = 0;
       ++c.j;
@@ -375,13 +376,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
   const bf16* srcB = p.B + (long)r * p.ldb + ch * 8;
   const long gA = 64 * p.lda, gB = 64 * p.ldb, hB = 128 * p.ldb;
   const int wave_off = wave * 1024;
-  auto issueA = [&](const DbCursor& c, int slot) {   // 2 DMA instructions per thread
+  auto issueA = [&](const DbCursor& c, int slot) __attribute__((always_inline)) {   // 2 DMA instructions per thread
     char* d = smem + slot * HALF + wave_off;
     const bf16* s = srcA + c.offA + (long)c.t * 64;
     glds16(s, d);
     glds16(s + gA, d + 8192);
   };
-  auto issueB = [&](const DbCursor& c, int slot) {   // 4 DMA instructions per thread
+  auto issueB = [&](const DbCursor& c, int slot) __attribute__((always_inline)) {   // 4 DMA instructions per thread
     char* d = smem + D2_A_BYTES + slot * 2 * HALF + wave_off;
     const bf16* s = srcB + c.offB + (long)c.t * 64;
     glds16(s, d);
@@ -406,17 +407,17 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
       for (int j = 0; j < 4; ++j) acc[q][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], bfg[4][2];
 
-  auto readA01 = [&](uint32_t sa) {
+  auto readA01 = [&](uint32_t sa) __attribute__((always_inline)) {
     const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
     af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
     af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
   };
-  auto readA23 = [&](uint32_t sa) {
+  auto readA23 = [&](uint32_t sa) __attribute__((always_inline)) {
     const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
     af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
     af[3][0] = lds_read128<6144>(a1);  af[3][1] = lds_read128<6144>(a0);
   };
-  auto readB = [&](uint32_t sb) {
+  auto readB = [&](uint32_t sb) __attribute__((always_inline)) {
     const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
     bfg[0][0] = lds_read128<0>(b0);     bfg[0][1] = lds_read128<0>(b1);
     bfg[1][0] = lds_read128<512>(b1);   bfg[1][1] = lds_read128<512>(b0);
@@ -447,9 +448,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
   } while (0)
 #define D2_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-  int pend = 0, pm0 = 0, pn0 = 0;
+  int pm0 = 0, pn0 = 0;
   const long lane_off = (long)(wm * 64 + lr) * p.ldc + wn * 64 + lg * 8;
-  auto store_unit = [&](auto Qtag, auto Utag) {
+  auto store_unit = [&](auto Qtag, auto Utag) __attribute__((always_inline)) {
     constexpr int Q = decltype(Qtag)::value, U = decltype(Utag)::value;
     const long tile_off = (long)(pm0 + U * 16) * p.ldc + pn0;
     bf16* c = p.C + tile_off + lane_off;
@@ -467,15 +468,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
       acc[Q][U][2 * hh + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto trickle = [&](auto Qtag) {
-    switch (4 - pend) {
-      case 0: store_unit(Qtag, std::integral_constant<int, 0>{}); break;
-      case 1: store_unit(Qtag, std::integral_constant<int, 1>{}); break;
-      case 2: store_unit(Qtag, std::integral_constant<int, 2>{}); break;
-      default: store_unit(Qtag, std::integral_constant<int, 3>{}); break;
-    }
-    --pend;
-  };
+  bool has_prev = false;
 
   // ---- prologue: B(0) A(0) | B(1) A(1) A(2) in flight; K-tile 0 landed
   DbCursor cur{};
@@ -499,51 +492,65 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
 
   int slotA = 0, slotB = 0, stores_prev = 0;
 
-  auto tile = [&](auto Ptag) {
-    constexpr int P = decltype(Ptag)::value;
-    using Qt = std::integral_constant<int, 1 - P>;
-    for (int t = 0; t < nk; ++t) {
-      const uint32_t sa = slotA * HALF, sb = slotB * 2 * HALF;
-      const int slotA3 = (slotA + 3) & 3;                 // K-tile k+3 -> the slot K-tile k-1 used
-      const int slotB2 = slotB == 0 ? 2 : slotB - 1;      // K-tile k+2 -> the slot K-tile k-1 used
-      const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
-      // -------- phase a
-      readA01(sa);
-      readB(sb);
-      if (moreB) issueB(cb, slotB2);
-      D2_MID();
-      D2_MFMA(P, 0);
-      D2_END();
-      // -------- phase b
-      readA23(sa);
-      if (moreA) issueA(ca, slotA3);
-      // in-order queue: ... B(k+1)x4 | A(k+2)x2 [a_prev] | stores(k-1) | B(k+2)x4 | A(k+3)x2 :
-      // K-tile k+1 needs everything up to and including B(k+1)
-      {
-        const int allow = a_prev + stores_prev + (moreB ? 4 : 0) + (moreA ? 2 : 0);
-        if (allow >= 10) D2_WAIT(10);
-        else if (allow >= 8) D2_WAIT(8);
-        else if (allow >= 6) D2_WAIT(6);
-        else if (allow >= 4) D2_WAIT(4);
-        else if (allow >= 2) D2_WAIT(2);
-        else D2_WAIT(0);
-      }
-      D2_MID();
-      stores_prev = 0;
-      if (pend > 0) {
-        trickle(Qt{});
+  auto ktile = [&](auto Ptag, auto Utag) __attribute__((always_inline)) {
+    constexpr int P = decltype(Ptag)::value, U = decltype(Utag)::value;
+    const uint32_t sa = slotA * HALF, sb = slotB * 2 * HALF;
+    const int slotA3 = (slotA + 3) & 3;                 // K-tile k+3 -> the slot K-tile k-1 used
+    const int slotB2 = slotB == 0 ? 2 : slotB - 1;      // K-tile k+2 -> the slot K-tile k-1 used
+    const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
+    // -------- phase a
+    readA01(sa);
+    readB(sb);
+    if (moreB) issueB(cb, slotB2);
+    D2_MID();
+    D2_MFMA(P, 0);
+    D2_END();
+    // -------- phase b
+    readA23(sa);
+    if (moreA) issueA(ca, slotA3);
+    // in-order queue: ... B(k+1)x4 | A(k+2)x2 [a_prev] | stores(k-1) | B(k+2)x4 | A(k+3)x2 :
+    // K-tile k+1 needs everything up to and including B(k+1)
+    {
+      const int allow = a_prev + stores_prev + (moreB ? 4 : 0) + (moreA ? 2 : 0);
+      if (allow >= 10) D2_WAIT(10);
+      else if (allow >= 8) D2_WAIT(8);
+      else if (allow >= 6) D2_WAIT(6);
+      else if (allow >= 4) D2_WAIT(4);
+      else if (allow >= 2) D2_WAIT(2);
+      else D2_WAIT(0);
+    }
+    D2_MID();
+    stores_prev = 0;
+    if constexpr (U >= 0) {
+      if (has_prev) {
+        store_unit(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, U>{});
         stores_prev = 2;
       }
-      D2_MFMA(P, 2);
-      D2_END();
-      a_prev = moreA ? 2 : 0;
-      if (moreA) advance(ca);
-      if (moreB) advance(cb);
-      slotA = (slotA + 1) & 3;
-      slotB = slotB == 2 ? 0 : slotB + 1;
     }
-    while (pend > 0) trickle(Qt{});
-    pend = 4;
+    D2_MFMA(P, 2);
+    D2_END();
+    a_prev = moreA ? 2 : 0;
+    if (moreA) advance(ca);
+    if (moreB) advance(cb);
+    slotA = (slotA + 1) & 3;
+    slotB = slotB == 2 ? 0 : slotB + 1;
+  };
+  auto flush = [&](auto Qtag, int from) __attribute__((always_inline)) {
+    if (from <= 0) store_unit(Qtag, std::integral_constant<int, 0>{});
+    if (from <= 1) store_unit(Qtag, std::integral_constant<int, 1>{});
+    if (from <= 2) store_unit(Qtag, std::integral_constant<int, 2>{});
+    if (from <= 3) store_unit(Qtag, std::integral_constant<int, 3>{});
+  };
+  auto tile = [&](auto Ptag) __attribute__((always_inline)) {
+    constexpr int P = decltype(Ptag)::value;
+    using NoU = std::integral_constant<int, -1>;
+    if (nk > 0) ktile(Ptag, std::integral_constant<int, 0>{});
+    if (nk > 1) ktile(Ptag, std::integral_constant<int, 1>{});
+    if (nk > 2) ktile(Ptag, std::integral_constant<int, 2>{});
+    if (nk > 3) ktile(Ptag, std::integral_constant<int, 3>{});
+    for (int t = 4; t < nk; ++t) ktile(Ptag, NoU{});
+    if (has_prev && nk < 4) flush(std::integral_constant<int, 1 - P>{}, nk);
+    has_prev = true;
     pm0 = cur.m0; pn0 = cur.n0;
     ++cur.j;
     if (cur.j < nmy) {
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dbuf2_kernel(DbParams p) {   // t
     tile(std::integral_constant<int, 0>{});
     if (jt + 1 < nmy) tile(std::integral_constant<int, 1>{});
   }
-  if ((nmy - 1) & 1) { while (pend > 0) trickle(std::integral_constant<int, 1>{}); }
-  else { while (pend > 0) trickle(std::integral_constant<int, 0>{}); }
+  if ((nmy - 1) & 1) flush(std::integral_constant<int, 1>{}, 0);
+  else flush(std::integral_constant<int, 0>{}, 0);
   if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef D2_MFMA
 #undef D2_MID
