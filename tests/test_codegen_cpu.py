@@ -1,0 +1,51 @@
+"""Code-generation guard for the hot kernels (cross-compiled here, no GPU needed): no register
+spills and NO SCRATCH MEMORY.  A private array that the optimiser ends up indexing at run time
+(e.g. accumulator fragments selected by a merged `switch`) silently moves to scratch: the kernel
+stays bit-exact and runs at half speed, with scratch loads/stores in the same in-order VMEM queue
+as the LDS DMA (this happened to tools/probes/gemm_dbuf_probe.hip).  hipcc's resource remarks
+make it visible at build time."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "big_vision_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# file -> kernels that may use scratch (general fallbacks outside the default dispatch)
+ALLOWED_SCRATCH = {"attention.hip": ("attn_fwd_kernelILi28E", "attn_fwd_kernelILi36E")}
+
+
+def _resources(src, tmp_path):
+  cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-x", "hip", "-c",
+         os.path.join(CSRC, src), "-o", str(tmp_path / "x.o"), "-Rpass-analysis=kernel-resource-usage"]
+  out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+  res, name = {}, None
+  for line in out.splitlines():
+    m = re.search(r"Function Name: (\S+)", line)
+    if m:
+      name = m.group(1)
+      res[name] = {}
+    for key in ("VGPRs Spill", "SGPRs Spill", "ScratchSize [bytes/lane]", "VGPRs"):
+      m = re.search(re.escape(key) + r": (\d+)", line)
+      if m and name and key not in res[name]:
+        res[name][key] = int(m.group(1))
+  return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src", ["gemm256.hip", "attention2.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
+                                 "elementwise.hip", "loss_optim.hip"])
+def test_no_spills_no_scratch(src, tmp_path):
+  res = _resources(src, tmp_path)
+  assert res, "no kernels found in the compiler remarks"
+  for name, r in res.items():
+    # (SGPR spills go to VGPR lanes, not to memory: tolerated - attn2_fwd_kernel<14,2> has 160)
+    assert r.get("VGPRs Spill", 0) == 0, f"{src}:{name} spills vector registers: {r}"
+    if any(a in name for a in ALLOWED_SCRATCH.get(src, ())):
+      continue
+    assert r.get("ScratchSize [bytes/lane]", 0) == 0, f"{src}:{name} uses scratch memory: {r}"
+    assert r.get("VGPRs", 0) <= 256, (name, r)
