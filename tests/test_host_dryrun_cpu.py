@@ -1,0 +1,178 @@
+"""Dry run of the trainers' HOST logic on CPU: every libbvhip entry point is replaced by a recorder
+(no arithmetic), tensors live on the CPU, and the CUDA memory probes are faked.  What is under
+test is control flow that the GPU parity tests only reach in one configuration: how many times
+each kernel group is launched per micro-batch scheme (keep / recompute / light contexts), the
+memory-driven switch to light contexts, and the order in which gradient ranges are handed to the
+all-reduce on N > 1 ranks (dp.GradSync hooks).  Values are garbage by construction."""
+import collections
+
+import pytest
+import torch
+
+from big_vision_amd import _lib, dp, ops
+from big_vision_amd.compat.ml_collections import ConfigDict
+from big_vision_amd.models.proj.image_text import two_towers
+from big_vision_amd.trainers.proj.image_text import siglip
+
+IMG = dict(width=128, depth=3, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+TXT = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=50)
+
+
+@pytest.fixture()
+def dry(monkeypatch):
+  calls = collections.Counter()
+  monkeypatch.setattr(_lib, "call", lambda name, *a: calls.update([name]))
+  monkeypatch.setattr(ops, "_chk", lambda t, dtype, name: t)
+  monkeypatch.setattr(ops, "_stream", lambda: 0)
+  mem = {"free": 1 << 40, "total": 1 << 40, "alloc": 0}
+  monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (mem["free"], mem["total"]))
+  monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a: 0)
+
+  def fake_allocated(*a):       # every probe sees 1 GiB more "allocated": a forward "costs" 1 GiB
+    mem["alloc"] += 1 << 30
+    return mem["alloc"]
+  monkeypatch.setattr(torch.cuda, "memory_allocated", fake_allocated)
+  return calls, mem
+
+
+def _cfg(**kw):
+  c = ConfigDict()
+  c.lr, c.wd, c.optax_name, c.total_steps, c.grad_clip_norm = 1e-3, 1e-2, "scale_by_adam", 10, 1.0
+  c.schedule = dict(decay_type="cosine", warmup_steps=2)
+  for k, v in kw.items():
+    c[k] = v
+  return c
+
+
+def _setup(config, comm=None, n=8):
+  model = two_towers.Model(image=IMG, text=TXT, out_dim=(None, 64), temperature_init=10.0, bias_init=-10.0)
+  image = torch.zeros((n, 32, 32, 3))
+  text = torch.ones((n, 8), dtype=torch.int32)
+  state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, comm=comm,
+                                     total_steps=10, device="cpu")
+  fn = siglip.make_update_fn(model, config, comm=comm)
+  return fn, state, {"image": image, "labels": text}
+
+
+BLOCKS = IMG["depth"] + TXT["depth"]
+
+
+def test_single_pass_launch_counts(dry):
+  calls, _ = dry
+  fn, state, batch = _setup(_cfg())
+  calls.clear()
+  state, meas = fn(state, None, batch)
+  assert calls["bv_attn_fwd"] == BLOCKS and calls["bv_attn_bwd"] == BLOCKS
+  assert calls["bv_siglip_loss"] == 1 and calls["bv_adam_step"] == 1 and calls["bv_sqnorm"] == 1
+  assert calls["bv_embed_fwd"] == 1 and calls["bv_embed_bwd"] == 1 and calls["bv_patchify"] == 1
+  assert calls["bv_gemm_bf16_colsum"] == BLOCKS + 1            # fc2 dX with fused Dense_0 bias sums (+ MAP head MLP)
+  assert set(meas) == {"training_loss", "l2_grads", "l2_params", "l2_updates"}
+
+
+@pytest.mark.parametrize("keep,light,fwd_passes", [
+    ("all", False, 4), (0, False, 8), (1, False, 7), (2, True, 6), ("all", True, 4)])
+def test_microbatch_schemes_recompute_exactly_what_was_not_kept(dry, keep, light, fwd_passes):
+  calls, _ = dry
+  fn, state, batch = _setup(_cfg(microbatch=2, microbatch_keep=keep, microbatch_light=light))
+  calls.clear()
+  fn(state, None, batch)
+  assert calls["bv_attn_fwd"] == BLOCKS * fwd_passes          # 4 micro-batches + re-run forwards
+  assert calls["bv_attn_bwd"] == BLOCKS * 4
+  assert calls["bv_siglip_loss"] == 1 and calls["bv_adam_step"] == 1
+  assert fn.state_cache["keep_n"] == (4 if keep == "all" else keep)
+  # light contexts: LayerNorm outputs are re-derived in the backward (2 per block and kept micro-batch
+  # beyond the forward's own), and the fc2 dX GEMM re-emits gelu(h)
+  if light:
+    assert calls["bv_layernorm_fwd"] > (2 * BLOCKS + 4) * fwd_passes
+
+
+def test_auto_switches_to_light_contexts_when_full_ones_do_not_fit(dry):
+  calls, mem = dry
+  fn, state, batch = _setup(_cfg(microbatch=2))               # keep "auto", light "auto"
+  mem["free"] = int(2.5 * (1 << 30)) + int(0.06 * mem["total"])   # room for ~2 more 1 GiB contexts, not 3
+  calls.clear()
+  fn(state, None, batch)
+  assert fn.state_cache["light"] is True
+  first = calls["bv_attn_fwd"]
+  assert first >= BLOCKS * 5                                   # 4 micro-batches + the re-run of micro-batch 0 in light mode
+  mem["free"] = 1 << 40                                        # plenty of memory from now on: everything is kept
+  calls.clear()
+  fn(state, None, batch)
+  assert fn.state_cache["light"] is True and fn.state_cache["keep_n"] == 4
+  assert calls["bv_attn_fwd"] == BLOCKS * 4
+  # a model whose full contexts fit never switches
+  fn2, state2, batch2 = _setup(_cfg(microbatch=2))
+  fn2(state2, None, batch2)
+  assert fn2.state_cache["light"] is False and fn2.state_cache["keep_n"] == 4
+
+
+class _FakeComm(dp.Comm):
+  """Two 'ranks' without a process group: collectives are recorded, data is passed through."""
+
+  def __init__(self, log):
+    self.enabled, self.group, self.rank, self.size, self.log = False, None, 1, 2, log
+
+  def all_gather_rows(self, x):
+    self.log.append("all_gather")
+    return torch.cat([x, x])
+
+  def reduce_scatter_rows(self, x):
+    self.log.append("reduce_scatter")
+    return x[: x.shape[0] // 2].contiguous()
+
+  def all_reduce_sum_(self, flat, bucket_bytes=0):
+    self.log.append(("all_reduce", flat.storage_offset(), flat.numel()))
+
+  def all_reduce_scalars_(self, t):
+    self.log.append("scalars")
+
+  def barrier(self):
+    pass
+
+
+def test_gradient_ranges_are_reduced_in_backward_order_on_two_ranks(dry):
+  calls, _ = dry
+  log = []
+  comm = _FakeComm(log)
+  fn, state, batch = _setup(_cfg(), comm=comm, n=4)
+  store = state["params"].store
+  log.clear()
+  fn(state, None, batch)
+  reds = [e for e in log if isinstance(e, tuple)]
+  txt = store.grad_range(lambda n: n.startswith("txt/"))
+  assert log.index("all_gather") < log.index("reduce_scatter") < log.index(reds[0])
+  assert (reds[0][1], reds[0][1] + reds[0][2]) == txt           # text tower first (its backward runs first)
+  lo, n = reds[1][1], reds[1][2]
+  assert lo + n == txt[0] and lo > store.entries["img/Transformer/encoderblock_0/LayerNorm_0/scale"].offset
+  covered = sorted((a, a + b) for _, a, b in reds)
+  assert covered[0][0] == 0 and covered[-1][1] == store.trainable_count      # every element exactly once
+  assert all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
+  # with the overlap switched off it is one plain all-reduce of the whole buffer
+  log.clear()
+  fn2, state2, batch2 = _setup(_cfg(overlap_grad_sync=False), comm=comm, n=4)
+  fn2(state2, None, batch2)
+  reds = [e for e in log if isinstance(e, tuple)]
+  assert reds == [("all_reduce", 0, state2["params"].store.trainable_count)]
+
+
+def test_classification_step_launches(dry):
+  """big_vision_amd.train: mixup on images AND labels, pre_logits tanh, the configured loss."""
+  from big_vision_amd import train
+  calls, _ = dry
+  cfg = _cfg(model_name="vit", num_classes=10, loss="softmax_xent", mixup=dict(p=0.2, fold_in=None),
+             model=dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap",
+                        rep_size=True, posemb="sincos2d"))
+  _, model = train.get_model(cfg)
+  state, _ = train.make_train_state(model, cfg, (4, 32, 32, 3), rng=0, total_steps=10, device="cpu")
+  fn = train.make_update_fn(model, cfg)
+  calls.clear()
+  state, meas = fn(state, 0, {"image": torch.zeros((4, 32, 32, 3)), "labels": torch.zeros((4, 10))})
+  assert calls["bv_mixup"] == 2 and calls["bv_softmax_xent"] == 1 and calls["bv_sigmoid_xent"] == 0
+  assert calls["bv_tanh_fwd"] == 1 and calls["bv_tanh_bwd"] == 1
+  assert calls["bv_attn_fwd"] == 2 and calls["bv_attn_bwd"] == 2 and calls["bv_adam_step"] == 1
+  assert "pos_embedding" not in state["params"]                 # sincos2d: no learned table
+  cfg2 = ConfigDict(cfg.to_dict()); cfg2.loss = "sigmoid_xent"; del cfg2["mixup"]
+  fn2 = train.make_update_fn(model, cfg2)
+  calls.clear()
+  fn2(state, 0, {"image": torch.zeros((4, 32, 32, 3)), "labels": torch.zeros((4, 10))})
+  assert calls["bv_mixup"] == 0 and calls["bv_sigmoid_xent"] == 1
