@@ -287,9 +287,10 @@ class Encoder:
         saved.append(s)
       if out is not None:
         x1 = s[7]
-        out[f"block{i:02d}"] = {"sa": x1 - x_in, "+sa": x1, "mlp": x - x1, "+mlp": x}
+        v = lambda t: t.view(n, L, -1)   # the reference's activations are [n, L, D]
+        out[f"block{i:02d}"] = {"sa": v(x1 - x_in), "+sa": v(x1), "mlp": v(x - x1), "+mlp": v(x)}
     if out is not None:
-      out["pre_ln"] = x
+      out["pre_ln"] = x.view(n, L, -1)
     return x, saved
 
   def last_b2_grad(self):

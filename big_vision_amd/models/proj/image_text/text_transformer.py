@@ -51,6 +51,13 @@ class TextExec:
     if collect:
       _, yf, _, _ = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
       out["transformed"] = yf.view(n, L, D)
+      # text_transformer.py:64 / :80: the token embedding before the position embedding, and the
+      # weight-tied vocabulary logits embedding.attend(x) = x . table^T (fp32, diagnostics only)
+      out["embedded"] = ops.embed_fwd(ids, self.table.f32, torch.zeros_like(self.pos.f32), n, L).view(n, L, D)
+      V = self.table.f32.shape[0]
+      vl = torch.empty((T, V), device=yf.device, dtype=F32)
+      ops.sgemm(yf, D, 1, self.table.f32, 1, D, vl, T, V, D)
+      out["vocab_logits"] = vl.view(n, L, V)
     if m.pool_type in ("last", "first"):
       off = L - 1 if m.pool_type == "last" else 0
       zb, z, mean, rstd = self.enc.norm.fwd(xL, n, D, row_stride=L, row_offset=off, want_f32=True)

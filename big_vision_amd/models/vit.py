@@ -101,6 +101,10 @@ class VitExec:
     pos = self.pos.f32 if self.pos is not None else self.pos_const
     x = E.linear_fwd(patches, self.wemb, self.bemb, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L0)
     if collect:
+      # `out` is part of the API (vit.py:207-274).  The stem output without the position
+      # embedding is not materialised on the training path (the add is the GEMM's epilogue):
+      # recompute it for the diagnostics dict.
+      out["stem"] = E.linear_fwd(patches, self.wemb, self.bemb, out_dtype=F32).view(n, h, w, D)
       out["with_posemb"] = x.view(n, L0, D)
     L = L0
     if m.pool_type == "tok":
@@ -128,7 +132,7 @@ class VitExec:
       if collect:
         _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
         enc = yf.view(n, L, D)
-        out["encoded"] = enc[:, 1:] if m.pool_type == "tok" else enc
+        out["encoded"] = enc   # all L (+1 cls) tokens, as in the reference (vit.py:240); x_2d drops the cls row
         z = enc[:, 0].contiguous()
         mean, rstd = mean.view(n, L)[:, 0].contiguous(), rstd.view(n, L)[:, 0].contiguous()
       else:
@@ -148,6 +152,14 @@ class VitExec:
       x = E.linear_fwd(zb, self.head[0], self.head[1], out_dtype=F32)
       out["logits"] = x
       ctx["head_in"] = zb
+    if collect and "encoded" in out:
+      # the same tail applied to every patch token (vit.py:257-273: x_2d; unused by training)
+      x2 = (out["encoded"][:, 1:] if m.pool_type == "tok" else out["encoded"]).contiguous().view(n * L0, D)
+      if self.pre is not None:
+        x2 = ops.tanh_fwd(E.linear_fwd(ops.cast_bf16(x2), self.pre[0], self.pre[1], out_dtype=F32))
+      out["pre_logits_2d"] = x2.view(n, h, w, -1)
+      if self.head is not None:
+        out["logits_2d"] = E.linear_fwd(ops.cast_bf16(x2), self.head[0], self.head[1], out_dtype=F32).view(n, h, w, -1)
     return x, out, (ctx if save else None)
 
   # ------------------------------------------------------------- backward --

@@ -176,3 +176,57 @@ def test_classification_step_launches(dry):
   calls.clear()
   fn2(state, 0, {"image": torch.zeros((4, 32, 32, 3)), "labels": torch.zeros((4, 10))})
   assert calls["bv_mixup"] == 0 and calls["bv_sigmoid_xent"] == 1
+
+
+def _flat(d, prefix=""):
+  out = {}
+  for k, v in d.items():
+    if isinstance(v, dict):
+      out.update(_flat(v, prefix + k + "/"))
+    else:
+      out[prefix + k] = v
+  return out
+
+
+@pytest.mark.parametrize("img_kw,num_classes", [
+    (dict(pool_type="map"), None), (dict(pool_type="tok"), 7), (dict(pool_type="gap", rep_size=True, posemb="sincos2d"), 10),
+    (dict(pool_type="0"), None)])
+def test_out_dict_has_the_reference_keys_and_shapes(dry, img_kw, num_classes):
+  """The `out` dictionary of `apply` is API (two_towers.py:56-57,69-70; vit.py:207-274;
+  text_transformer.py:56-98): same keys and shapes as the oracle restatement produces."""
+  import bv_oracle as O
+  from big_vision_amd.models import vit
+  base = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16))
+  cfg = {**base, **img_kw}
+  image = torch.zeros((3, 48, 32, 3))
+  m = vit.Model(num_classes, **cfg)
+  from big_vision_amd.params import ParamStore
+  st = ParamStore(m.entries("", m.grid(tuple(image.shape))), "cpu")
+  st.init_random(0)
+  _, out = m.apply({"params": st.tree()}, image)
+  gen = torch.Generator().manual_seed(0)
+  p = O.init_vit(gen, (48, 32), num_classes=num_classes, **cfg)
+  _, ref = O.vit_forward(p, image, num_classes=num_classes, **cfg)
+  ours, want = _flat(out), _flat(ref)
+  assert set(ours) == set(want), (sorted(set(want) - set(ours)), sorted(set(ours) - set(want)))
+  for k in want:
+    assert tuple(ours[k].shape) == tuple(want[k].shape), (k, tuple(ours[k].shape), tuple(want[k].shape))
+
+
+def test_two_towers_out_dict_keys(dry):
+  import bv_oracle as O
+  model = two_towers.Model(image=IMG, text=TXT, out_dim=(None, 64), temperature_init=10.0, bias_init=-10.0)
+  st = model.make_store((2, 32, 32, 3), (2, 8), device="cpu")
+  st.init_random(0)
+  image, text = torch.zeros((2, 32, 32, 3)), torch.ones((2, 8), dtype=torch.int32)
+  _, _, out = model.apply({"params": st.tree()}, image, text)
+  p = O.init_two_towers(0, (32, 32), 8, image_cfg=IMG, text_cfg=TXT, out_dim=(None, 64), temperature_init=10.0,
+                        bias_init=-10.0)
+  _, _, ref = O.two_towers_forward(p, image, text.long(), image_cfg=IMG, text_cfg=TXT, out_dim=(None, 64))
+  ours, want = _flat(out), _flat(ref)
+  assert set(ours) == set(want), (sorted(set(want) - set(ours)), sorted(set(ours) - set(want)))
+  for k in want:
+    assert tuple(ours[k].shape) == tuple(want[k].shape), (k, tuple(ours[k].shape), tuple(want[k].shape))
+  # one input only (two_towers.py:43)
+  zimg, ztxt, out_i = model.apply({"params": st.tree()}, image, None)
+  assert ztxt is None and not any(k.startswith("txt/") for k in out_i)
