@@ -118,7 +118,8 @@ def encoder_entries(prefix, depth, D, H, M):
 
 def map_entries(prefix, D, H, M):
   """MAPHead params (vit.py:163-183)."""
-  ents = [Entry(f"{prefix}/probe", (1, 1, D), init_xavier_uniform(D, D))]
+  # xavier_uniform on shape (1, 1, D): Flax takes fan_in from axis -2 (= 1) and fan_out from axis -1
+  ents = [Entry(f"{prefix}/probe", (1, 1, D), init_xavier_uniform(1, D))]
   ents += mha_entries(f"{prefix}/MultiHeadDotProductAttention_0", D, H, "kv")
   ents += ln_entries(f"{prefix}/LayerNorm_0")(D)
   ents += mlp_entries(f"{prefix}/MlpBlock_0", D, M)

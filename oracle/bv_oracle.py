@@ -641,7 +641,8 @@ def _init_encoder(gen, depth, d, m, h, dtype):
 
 
 def _init_map(gen, d, m, h, dtype):
-  return {"probe": _xavier_uniform(gen, (1, 1, d), d, d, dtype),
+  # nn.initializers.xavier_uniform() on (1, 1, d): fan_in = shape[-2] = 1, fan_out = shape[-1] = d
+  return {"probe": _xavier_uniform(gen, (1, 1, d), 1, d, dtype),
           "MultiHeadDotProductAttention_0": _init_mha(gen, d, h, dtype),
           "LayerNorm_0": _init_ln(d, dtype),
           "MlpBlock_0": _init_mlp(gen, d, m, dtype)}

@@ -222,3 +222,44 @@ def test_oracle_sigmoid_xent_and_mixup():
     a = u.get_mixup_coefficient(0, s, 0.2)
     assert 0.5 <= a <= 1.0
   assert u.get_mixup_coefficient(0, 3, 0.2) == u.get_mixup_coefficient(0, 3, 0.2)
+
+
+def test_initialisers_have_the_flax_statistics():
+  """Initialisers of the reference modules (SURVEY.md §8c "Flax facts"): xavier_uniform for the
+  attention / MLP kernels (vit.py:66-69,93-98), normal(1e-6) MLP biases, lecun_normal (truncated,
+  variance 1/fan_in) for the stem conv and heads, normal(1/sqrt(D)) position embeddings and token
+  table, ones / zeros for LayerNorm, log(temperature_init) and bias_init for t / b."""
+  import math
+  m = two_towers.Model(image=dict(width=256, depth=1, mlp_dim=1024, num_heads=4, patch_size=(16, 16), pool_type="map"),
+                       text=dict(width=256, depth=1, mlp_dim=1024, num_heads=4, vocab_size=2000),
+                       out_dim=(None, 256), temperature_init=10.0, bias_init=-10.0)
+  st = m.make_store((2, 64, 64, 3), (2, 16), device="cpu")
+  st.init_random(0)
+  leaf = lambda n: st.leaf(n).double()
+
+  def close(x, want, rel):
+    assert abs(x - want) <= rel * abs(want), (x, want)
+
+  D, M = 256, 1024
+  blk = "img/Transformer/encoderblock_0/"
+  q = leaf(blk + "MultiHeadDotProductAttention_0/query/kernel")
+  lim = math.sqrt(6.0 / (D + D))
+  assert q.abs().max() <= lim and q.abs().max() >= 0.98 * lim
+  close(q.var().item(), lim * lim / 3.0, 0.05)                      # U(-lim, lim)
+  w1 = leaf(blk + "MlpBlock_0/Dense_0/kernel")
+  close(w1.var().item(), (6.0 / (D + M)) / 3.0, 0.05)
+  b1 = leaf(blk + "MlpBlock_0/Dense_0/bias")
+  close(b1.std().item(), 1e-6, 0.15)
+  assert torch.all(leaf(blk + "LayerNorm_0/scale") == 1) and torch.all(leaf(blk + "LayerNorm_0/bias") == 0)
+  assert torch.all(leaf(blk + "MultiHeadDotProductAttention_0/out/bias") == 0)
+  stem = leaf("img/embedding/kernel")
+  close(stem.var().item(), 1.0 / (16 * 16 * 3), 0.05)               # lecun_normal: variance 1 / fan_in
+  assert stem.abs().max() <= 2.0 / 0.87962566103423978 * math.sqrt(1.0 / (16 * 16 * 3)) + 1e-9   # truncated at 2 sigma
+  close(leaf("img/pos_embedding").std().item(), 1 / math.sqrt(D), 0.05)
+  close(leaf("txt/Embed_0/embedding").std().item(), 1 / math.sqrt(D), 0.02)
+  close(leaf("txt/head/kernel").var().item(), 1.0 / D, 0.05)
+  close(leaf("t").item(), math.log(10.0), 1e-6)
+  close(leaf("b").item(), -10.0, 1e-6)
+  probe = leaf("img/MAPHead_0/probe")             # (1, 1, D): fan_in 1, fan_out D (vit.py:172-173)
+  lim_p = math.sqrt(6.0 / (1 + D))
+  assert 0.9 * lim_p <= probe.abs().max() <= lim_p
