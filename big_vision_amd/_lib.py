@@ -30,6 +30,8 @@ PROTOTYPES = {
     "bv_gemm_tune": [c_int, c_int, c_int],
     "bv_gemm_pre_issue": [c_int],
     "bv_set_workspace": [P, c_long],
+    "bv_set_stream_workspace": [P, P, c_long],
+    "bv_gemm_workspace_bytes": [c_int, c_int, c_int],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
@@ -61,6 +63,8 @@ PROTOTYPES = {
                      c_float, c_float, c_float, P, P],
 }
 
+RESTYPES = {"bv_gemm_workspace_bytes": c_long}   # everything else returns an int status
+
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT = range(7)
 
 _lib = None
@@ -80,7 +84,7 @@ def load():
   lib.bv_last_error.argtypes = []
   for name, argtypes in PROTOTYPES.items():
     fn = getattr(lib, name)  # AttributeError if the ABI drifted
-    fn.restype = c_int
+    fn.restype = RESTYPES.get(name, c_int)
     fn.argtypes = argtypes
   if lib.bv_version() != 1:
     raise RuntimeError("libbvhip.so ABI version mismatch")
@@ -100,5 +104,7 @@ def call(name, *args):
   rc = getattr(lib, name)(*args)
   if tok is not None:
     obs.end(tok)
+  if name in RESTYPES:
+    return rc
   if rc != 0:
     raise RuntimeError(f"{name} failed (rc={rc}): {lib.bv_last_error().decode()}")

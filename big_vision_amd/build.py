@@ -37,9 +37,16 @@ def build(force=False, verbose=True):
   os.makedirs(objdir, exist_ok=True)
   objs = []
   procs = []
+  headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+  headers.append(os.path.join(HERE, "..", "include", "bvhip.h"))
+  hdr_t = max(os.path.getmtime(h) for h in headers)
   for src in SOURCES:
     obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     objs.append(obj)
+    # per-object staleness: only the sources that changed (or everything, after a header edit)
+    if (not force and os.path.exists(obj) and
+        os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src)))):
+      continue
     cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
       print(" ".join(cmd), flush=True)

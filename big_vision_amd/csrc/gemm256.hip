@@ -724,12 +724,54 @@ extern "C" int bv_gemm_tune(int nt, int skew_mode, int skew_pct) {
   if (skew_pct >= 0) g_skew_pct = skew_pct;
   return BV_OK;
 }
-static void* g_ws = nullptr;
-static long g_ws_bytes = 0;
+// Split-K workspaces: a default one (bv_set_workspace) and up to 16 bound to specific streams
+// (bv_set_stream_workspace), so weight-gradient GEMMs enqueued on different streams never share
+// a slab.  Looked up per launch under a mutex; the kernels only ever see the pointer.
+#include <mutex>
+namespace {
+struct WsSlot { void* stream; void* ptr; long bytes; };
+std::mutex g_ws_mu;
+WsSlot g_ws_default = {nullptr, nullptr, 0};
+WsSlot g_ws_stream[16] = {};
+int g_ws_nstream = 0;
+WsSlot ws_for(void* stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < g_ws_nstream; ++i)
+    if (g_ws_stream[i].stream == stream && g_ws_stream[i].ptr) return g_ws_stream[i];
+  return g_ws_default;
+}
+}  // namespace
 extern "C" int bv_set_workspace(void* ptr, long bytes) {
-  g_ws = ptr;
-  g_ws_bytes = ptr ? bytes : 0;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws_default = {nullptr, ptr, ptr ? bytes : 0};
   return BV_OK;
+}
+extern "C" int bv_set_stream_workspace(void* stream, void* ptr, long bytes) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < g_ws_nstream; ++i)
+    if (g_ws_stream[i].stream == stream) {
+      g_ws_stream[i] = {stream, ptr, ptr ? bytes : 0};
+      return BV_OK;
+    }
+  if (g_ws_nstream == 16) {
+    bv_set_error("bv_set_stream_workspace: more than 16 streams");
+    return BV_ERR_UNSUPPORTED;
+  }
+  g_ws_stream[g_ws_nstream++] = {stream, ptr, ptr ? bytes : 0};
+  return BV_OK;
+}
+// Bytes of split-K scratch a dW GEMM (a_kmajor = b_kmajor = 0, EPI_ATOMIC) of this shape uses
+// with the automatic split choice; 0 = the shape takes no workspace.
+extern "C" long bv_gemm_workspace_bytes(int M, int N, int K) {
+  if ((M & 255) || (N & 255) || (K & 63)) return 0;
+  const int ntiles = (M >> 8) * (N >> 8), nk = K >> 6;
+  int splits = 256 / (ntiles > 0 ? ntiles : 1);
+  const int max_splits = nk / 8 > 0 ? nk / 8 : 1;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int per = (nk + splits - 1) / splits;
+  splits = (nk + per - 1) / per;
+  return splits > 1 ? (long)ntiles * splits * 65536 * 4 : 0;
 }
 
 // Internal entry used by bv_gemm_bf16 (gemm_bf16.hip).  Returns 1 if the problem
@@ -778,9 +820,10 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   p.ktiles_per_split = (nk + splits - 1) / splits;
   splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
   const long slab_bytes = (long)p.ntiles * splits * 65536 * 4;
-  const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && g_ws && slab_bytes <= g_ws_bytes &&
+  const WsSlot ws = epilogue == BV_EPI_ATOMIC ? ws_for(stream) : WsSlot{nullptr, nullptr, 0};
+  const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && ws.ptr && slab_bytes <= ws.bytes &&
                         (ldc & 3) == 0;
-  if (use_slab) p.slab = (float*)g_ws;
+  if (use_slab) p.slab = (float*)ws.ptr;
   p.splits = splits;
   const int nwork = p.ntiles * splits;
   // start skew (see kernel): one tile period (~3600 cycles per K-tile + epilogue) when every
@@ -805,7 +848,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   else if (out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, false>), grid, block, 0, s, p);
   if (use_slab)
-    hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)g_ws,
+    hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)ws.ptr,
                        (float*)C, ldc, p.ntiles, p.tiles_n, splits, alpha, 1);
   return 1;
 }

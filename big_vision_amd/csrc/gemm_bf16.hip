@@ -319,6 +319,8 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
     BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: epilogue %d needs bf16 C and C2", epilogue);
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
+  if (epilogue == BV_EPI_GELU_BWD)
+    BV_REQUIRE(!out_f32, "bv_gemm_bf16: epilogue GELU_BWD writes bf16 (out_f32 must be 0)");
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
   if (colsum)
     BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT,

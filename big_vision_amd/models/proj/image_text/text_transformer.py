@@ -17,7 +17,7 @@ from big_vision_amd import ops
 from big_vision_amd import utils
 from big_vision_amd.models import common
 from big_vision_amd.models import vit
-from big_vision_amd.params import Entry, ParamStore, ParamTree
+from big_vision_amd.params import Entry, ParamStore, ParamTree, adhoc_store
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -167,13 +167,11 @@ class _Model:
     if isinstance(params, ParamTree) and params.store is not None:
       store, prefix = params.store, params.prefix
     else:
-      key = ("adhoc", id(params))
-      if key not in self._execs:
-        store = ParamStore(self.entries("", text.shape[1]), torch.device("cuda", torch.cuda.current_device()),
-                           scan_prefixes=self.scan_prefixes())
-        store.load_tree(params)
-        self._execs[key] = store
-      store, prefix = self._execs[key], ""
+      dev = torch.device("cuda", torch.cuda.current_device())
+      store = adhoc_store(self._execs, ("txt", int(text.shape[1]), dev.index), params,
+                          lambda: ParamStore(self.entries("", text.shape[1]), dev,
+                                             scan_prefixes=self.scan_prefixes()))
+      prefix = ""
     store.refresh_shadow()
     x, out, _ = self.executor(store, prefix, text.shape[1]).fwd(text, save=False, collect=collect)
     return x, out
@@ -186,12 +184,14 @@ def Model(num_classes, *, variant=None, **kw):  # pylint: disable=invalid-name
 
 def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=invalid-name
   """Load init from checkpoint (text_transformer.py:107-119)."""
-  del model_cfg
   params = utils.load_params(init_file)
   params = utils.tree_map(lambda x: x, params)
   extra_posemb = params["Encoder_0"].pop("pos_embedding", 0)
   params["pos_embedding"] = params["pos_embedding"] + extra_posemb
-  want_scan = bool(init_params) and "encoderblock" in init_params.get("Encoder_0", {})
+  if init_params:
+    want_scan = "encoderblock" in init_params.get("Encoder_0", {})
+  else:
+    want_scan = bool((model_cfg or {}).get("scan", False))
   have_scan = "encoderblock" in params["Encoder_0"]
   if have_scan and not want_scan:
     params["Encoder_0"] = vit.scan_to_pyloop({"Transformer": params["Encoder_0"]})["Transformer"]

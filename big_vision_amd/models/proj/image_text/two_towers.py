@@ -17,7 +17,7 @@ import torch
 from big_vision_amd import engine as E
 from big_vision_amd import ops
 from big_vision_amd import utils
-from big_vision_amd.params import Entry, ParamStore, ParamTree
+from big_vision_amd.params import Entry, ParamStore, ParamTree, adhoc_store
 
 F32 = torch.float32
 MODELS_PKG = "big_vision_amd.models"
@@ -159,14 +159,12 @@ class Model:
     if isinstance(params, ParamTree) and params.store is not None:
       store, prefix = params.store, params.prefix
     else:
-      key = ("adhoc", id(params))
-      if key not in self._execs:
-        if image is None or text is None:
-          raise ValueError("ad-hoc parameter trees need both inputs to size the store")
-        store = self.make_store(tuple(image.shape), tuple(text.shape))
-        store.load_tree(params)
-        self._execs[key] = store
-      store, prefix = self._execs[key], ""
+      if image is None or text is None:
+        raise ValueError("ad-hoc parameter trees need both inputs to size the store")
+      ishape, tshape = tuple(image.shape), tuple(text.shape)
+      store = adhoc_store(self._execs, ("two_towers", ishape[1:], tshape[1:], torch.cuda.current_device()),
+                          params, lambda: self.make_store(ishape, tshape))
+      prefix = ""
     store.refresh_shadow()
     ex = self.executor(store, prefix, None if image is None else tuple(image.shape),
                        None if text is None else tuple(text.shape))

@@ -19,7 +19,7 @@ from big_vision_amd import engine as E
 from big_vision_amd import ops
 from big_vision_amd import utils
 from big_vision_amd.models import common
-from big_vision_amd.params import Entry, ParamStore, ParamTree
+from big_vision_amd.params import Entry, ParamStore, ParamTree, adhoc_store
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -138,9 +138,19 @@ class VitExec:
       else:
         _, z, mean, rstd = self.enc.norm.fwd(xL, n, D, row_stride=L, row_offset=0, want_bf16=False, want_f32=True)
       ctx.update(norm=(mean, rstd))
+    elif m.pool_type == "none":
+      # vit.py:252-253: no pooling, the tail (pre_logits / head) runs on every token; forward only
+      # (no trainer on the accelerated path back-propagates through an un-pooled tower)
+      if save:
+        raise NotImplementedError("pool_type='none' is forward-only on the accelerated path")
+      _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
+      z = yf
+      if collect:
+        out["encoded"] = yf.view(n, L, D)
     else:
       raise ValueError(f"Unknown pool type: '{m.pool_type}'")
-    out["head_input"] = z
+    if m.pool_type != "none":
+      out["head_input"] = z
     if self.pre is not None:
       zb0 = ops.cast_bf16(z)
       z = ops.tanh_fwd(E.linear_fwd(zb0, self.pre[0], self.pre[1], out_dtype=F32))
@@ -152,6 +162,11 @@ class VitExec:
       x = E.linear_fwd(zb, self.head[0], self.head[1], out_dtype=F32)
       out["logits"] = x
       ctx["head_in"] = zb
+    if m.pool_type == "none":   # [n, L, features], like the reference's un-pooled x
+      for k in ("pre_logits", "logits"):
+        if k in out:
+          out[k] = out[k].view(n, L, -1)
+      x = x.view(n, L, -1)
     if collect and "encoded" in out:
       # the same tail applied to every patch token (vit.py:257-273: x_2d; unused by training)
       x2 = (out["encoded"][:, 1:] if m.pool_type == "tok" else out["encoded"]).contiguous().view(n * L0, D)
@@ -277,13 +292,9 @@ class _Model:
   def _store_for(self, params, hw):
     if isinstance(params, ParamTree) and params.store is not None:
       return params.store, params.prefix
-    key = ("adhoc", id(params))
-    if key not in self._execs:
-      dev = torch.device("cuda", torch.cuda.current_device())
-      store = ParamStore(self.entries("", hw), dev, scan_prefixes=self.scan_prefixes())
-      store.load_tree(params)
-      self._execs[key] = store
-    return self._execs[key], ""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return adhoc_store(self._execs, ("vit", tuple(hw), dev.index), params,
+                       lambda: ParamStore(self.entries("", hw), dev, scan_prefixes=self.scan_prefixes())), ""
 
   def apply(self, variables, image, *, train=False, rngs=None, collect=True, **kw):
     del rngs, train, kw
@@ -305,7 +316,8 @@ def Model(num_classes=None, *, variant=None, **kw):  # pylint: disable=invalid-n
 def resample_posemb(old, new):
   """"High-res finetuning": bilinear resize of the posemb grid (vit.py:306-321)."""
   import scipy.ndimage
-  old, new_shape = np.asarray(old), tuple(np.asarray(new).shape)
+  # `new` is only consulted for its shape: it may be a device view of the flat parameter store
+  old, new_shape = np.asarray(old), tuple(new.shape)
   if old.shape == new_shape:
     return old
   gs_old = int(np.sqrt(old.shape[1]))
@@ -364,13 +376,15 @@ def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=in
   restored_params = fix_old_checkpoints(restored_params)
   # Bring the checkpoint to the layout the model presents (vit.py:416-424): stacked blocks for
   # scan=True models, encoderblock_{i} otherwise.
-  want_scan = bool(init_params) and "encoderblock" in init_params.get("Transformer", {})
+  if init_params:
+    want_scan = "encoderblock" in init_params.get("Transformer", {})
+  else:   # no init tree to look at: the model config decides (vit.py:416-424 reads model_cfg.scan)
+    want_scan = bool((model_cfg or {}).get("scan", False))
   have_scan = "encoderblock" in restored_params["Transformer"]
   if have_scan and not want_scan:
     restored_params = scan_to_pyloop(restored_params)
   elif want_scan and not have_scan:
     restored_params = pyloop_to_scan(restored_params)
-  del model_cfg
   restored_params = common.merge_params(restored_params, init_params, dont_load)
   if init_params and "pos_embedding" in init_params:
     restored_params["pos_embedding"] = resample_posemb(

@@ -56,6 +56,7 @@ class Optimizer:
 
   def __init__(self, config, store: ParamStore, *, sched_kw):
     self.store = store
+    self._cfg = {k: config.get(k) for k in ("lr_mults", "wd", "wd_mults", "grad_clip_norm") if config.get(k) is not None}
     dev = store.device
     leaves = store.leaf_names()
     # ---- schedules (optax.py:79-97)
@@ -177,9 +178,86 @@ class Optimizer:
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
 
-  # checkpoint-ish helpers
+  # ---------------------------------------------------------------- checkpointing --
+  def _chain_layout(self):
+    """Positions inside the reference's optax.chain (optax.py:143-149) whose state is not empty:
+    index of masked(optimizer) and of every masked(scale_by_schedule).  chain = [clip | identity,
+    masked(opt), scale(lr), *lr_mults, *weight_decay, *schedules, set_to_zero, scale(-1)]."""
+    cfg = self._cfg
+    n_lr = 1 + (len(cfg["lr_mults"]) if cfg.get("lr_mults") else 0)
+    n_wd = len(cfg.get("wd_mults", [(".*/kernel$", 1.0)])) if cfg.get("wd") else 0
+    first_sched = 2 + n_lr + n_wd
+    return 1, [first_sched + i for i in range(len(self.schedule_fns))]
+
+  def _moment_tree(self, flat):
+    st = self.store
+    names = [n for n in st.leaf_names() if not any(e in st.frozen for e in st.entries_of(n))]
+    views = {}
+    for n in names:
+      group = st.ext_index[n]
+      per = []
+      for leaf in group:
+        sname, sl = st.leaf_index[leaf]
+        e = st.entries[sname]
+        t = flat[e.offset:e.offset + e.numel].view(e.shape)
+        per.append(t if sl is None else t.select(sl[0], sl[1]))
+      views[n] = per[0] if (len(per) == 1 and group[0] == n) else torch.stack(per)
+    return u.recover_tree(list(views.keys()), list(views.values()))
+
+  def state_tree(self):
+    """The optimizer state with the names `u.tree_flatten_with_names` gives the reference's
+    optax state (tuples are indexed, utils.py:616-641): `<i>/0/0` = count, `<i>/0/1/<leaf>` = mu,
+    `<i>/0/2/<leaf>` = nu of masked(scale_by_adam) at chain position i (MaskedState.inner_state ->
+    ScaleByAdamState(count, mu, nu); frozen leaves are MaskedNode()s and emit nothing), and
+    `<j>/0/0` = count of every masked(scale_by_schedule).  Adafactor (scale_by_factored_rms +
+    ema, optax.py:187-216): `<i>/0/0/{0: count, 1: v_row, 2: v_col, 3: v}` and `<i>/0/2/0` = the
+    momentum trace.  Tensors are copies (stacked for scan-layout leaves)."""
+    i_opt, i_sched = self._chain_layout()
+    cnt = np.asarray(self.count, np.int32)
+    tree = {str(j): {"0": {"0": cnt}} for j in i_sched}
+    tree[str(i_opt)] = {"0": self._opt_state_tree(cnt)}
+    return tree
+
+  def _opt_state_tree(self, cnt):
+    return {"0": cnt, "1": self._moment_tree(self.mu), "2": self._moment_tree(self.nu)}
+
+  def load_state_tree(self, tree):
+    """Inverse of `state_tree` (accepts the flat `{name: array}` form too)."""
+    flat = dict(u.tree_flatten_with_names(tree)[0])   # flat '/'-joined keys pass through unchanged
+    i_opt, _ = self._chain_layout()
+    self._load_opt_state(flat, f"{i_opt}/0/")
+
+  def _assign_moment(self, flat_buf, flat, prefix):
+    st = self.store
+    for n in st.leaf_names():
+      if any(e in st.frozen for e in st.entries_of(n)):
+        continue
+      key = prefix + n
+      if key not in flat:
+        raise ValueError(f"optimizer state is missing '{key}'")
+      v = torch.as_tensor(np.asarray(flat[key], np.float32) if not torch.is_tensor(flat[key]) else flat[key])
+      group = st.ext_index[n]
+      stacked = not (len(group) == 1 and group[0] == n)
+      for k, leaf in enumerate(group):
+        sname, sl = st.leaf_index[leaf]
+        e = st.entries[sname]
+        t = flat_buf[e.offset:e.offset + e.numel].view(e.shape)
+        dst = t if sl is None else t.select(sl[0], sl[1])
+        src = v[k] if stacked else v
+        if tuple(src.shape) != tuple(dst.shape):
+          raise ValueError(f"Shape mismatch for optimizer state {key}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+        dst.copy_(src.to(dst.dtype).to(dst.device))
+
+  def _load_opt_state(self, flat, pre):
+    self.count = int(np.asarray(flat[pre + "0"]))
+    self._assign_moment(self.mu, flat, pre + "1/")
+    self._assign_moment(self.nu, flat, pre + "2/")
+
   def state_dict(self):
     return {"mu": self.mu, "nu": self.nu, "count": self.count}
+
+  def load_state_dict(self, d):
+    self.mu.copy_(d["mu"].to(self.mu.dtype)); self.nu.copy_(d["nu"]); self.count = int(d["count"])
 
 
 def make(config, store: ParamStore, *, sched_kw):

@@ -265,6 +265,20 @@ class ParamStore:
     self.ensure_grad().zero_()
 
 
+def adhoc_store(cache: dict, key, params, factory) -> "ParamStore":
+  """Store for `model.apply({"params": tree}, ...)` with a plain (numpy / torch) tree that is not
+  bound to a ParamStore.  ONE store per (model, input geometry) is kept in `cache` and re-used
+  for its device allocations only: the values are re-loaded from `tree` on every call, so a
+  different tree (CPython re-uses ids after GC) or an in-place edit of the same tree can never
+  run with stale weights, and repeated ad-hoc applies do not accumulate device copies."""
+  key = ("adhoc",) + tuple(key)
+  store = cache.get(key)
+  if store is None:
+    store = cache[key] = factory()
+  store.load_tree(params)
+  return store
+
+
 # ------------------------------------------------------------ regex masks ----
 def make_masks(names: Sequence[str], patterns: Sequence[str]) -> List[Dict[str, bool]]:
   """First-match-wins masks with fullmatch (reference utils.py:1169-1212)."""

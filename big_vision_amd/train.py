@@ -103,6 +103,7 @@ def make_update_fn(model, config, comm=None):
     params, opt = train_state["params"], train_state["opt"]
     store = params.store
     store.want_grads = True
+    store.refresh_shadow()   # no-op when clean; picks up load_tree() / in-place master edits
     store.zero_grad()
     images = images.to(F32).contiguous()
     labels = labels.to(F32).contiguous()

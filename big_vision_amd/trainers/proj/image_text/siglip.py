@@ -91,6 +91,9 @@ def make_update_fn(model, config, comm=None):
     params, opt = train_state["params"], train_state["opt"]
     store = params.store
     store.want_grads = True
+    # a checkpoint loaded with store.load_tree() / an in-place edit of the master weights only
+    # marks the bf16 shadow dirty; forward and backward read the shadow (no-op when clean)
+    store.refresh_shadow()
     store.zero_grad()
     n = images.shape[0]
     ex = model.executor(store, "", tuple(images.shape[:1]) + tuple(images.shape[1:]), tuple(labels.shape))

@@ -224,6 +224,26 @@ def save_params_npz(fname, tree):
                      for n, v in names_and_vals})
 
 
+def save_train_state(fname, train_state):
+  """Writes {"params": ..., "opt": ...} as a flat .npz with the reference's '/'-joined key naming
+  (`params/<leaf>`, `opt/<chain index>/...`, utils.py:616-641 + trainers/.../siglip.py:263-268): what
+  `load_params("file.npz")` / `load_train_state` read back."""
+  tree = {"params": train_state["params"], "opt": train_state["opt"].state_tree()}
+  save_params_npz(fname, tree)
+
+
+def load_train_state(fname, train_state):
+  """Resumes in place: parameters into the store (master + bf16 shadow), optimizer moments and
+  step count into the fused optimizer.  Returns the train_state."""
+  flat = npload(fname) if isinstance(fname, str) else dict(fname)
+  params = recover_tree(*zip(*[(k[len("params/"):], v) for k, v in flat.items() if k.startswith("params/")]))
+  store = train_state["params"].store
+  store.load_tree(params)
+  store.refresh_shadow()
+  train_state["opt"].load_state_tree({k[len("opt/"):]: v for k, v in flat.items() if k.startswith("opt/")})
+  return train_state
+
+
 # ------------------------------------------------------------------ mixup ----
 def get_mixup_coefficient(rng, step, p):
   """a ~ Beta(p, p), a := max(a, 1 - a) (utils.py:1148-1150).  The reference draws it from

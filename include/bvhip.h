@@ -14,7 +14,9 @@
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
  *     returns immediately: 0 = ok, <0 = error (BV_ERR_*); the message is
  *     available from bv_last_error().  No call synchronises.
- *   - thread-safe per stream; no global state besides the last-error string.
+ *   - thread-safe per stream.  Process-global state: the last-error string, the split-K
+ *     workspace registry (bv_set_workspace / bv_set_stream_workspace) and the diagnostic
+ *     dispatch / tuning switches (bv_gemm_fast_path, bv_gemm_tune, bv_gemm_pre_issue).
  */
 #ifndef BVHIP_H_
 #define BVHIP_H_
@@ -80,8 +82,15 @@ int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, con
  * partial tiles of the weight-gradient GEMMs (EPI_ATOMIC): with a workspace the
  * partials are written with plain coalesced stores and combined by a second
  * small kernel (deterministic); without one (ptr = NULL) fp32 atomics are used.
- * The workspace is process-global: calls that use it must be stream-ordered. */
+ * bv_set_workspace registers the DEFAULT workspace: every dW GEMM whose stream has no
+ * workspace of its own uses it, so such calls must be ordered on ONE stream.  To run dW
+ * GEMMs concurrently on several streams give each its own slab with
+ * bv_set_stream_workspace(stream, ptr, bytes) (up to 16 streams; ptr = NULL unbinds).
+ * bv_gemm_workspace_bytes(M, N, K) = bytes the dW GEMM C[M,N] = A[K,M]^T B[K,N] takes with
+ * the automatic split choice (0: the shape needs none) -- size the slab for the largest. */
 int bv_set_workspace(void* ptr, long bytes);
+int bv_set_stream_workspace(void* stream, void* ptr, long bytes);
+long bv_gemm_workspace_bytes(int M, int N, int K);
 
 /* Dispatch control (diagnostics / A-B benchmarking).  With the switch on (default)
  * GEMMs with M,N multiples of 256, K a multiple of 64 and both operands in the

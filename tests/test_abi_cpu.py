@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "bvhip.h")
 def _header_symbols():
   src = open(HEADER).read()
   src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-  return sorted(set(re.findall(r"^(?:int|const char\*)\s+(bv_\w+)\s*\(", src, re.M)))
+  return sorted(set(re.findall(r"^(?:int|long|const char\*)\s+(bv_\w+)\s*\(", src, re.M)))
 
 
 @pytest.fixture(scope="module")
