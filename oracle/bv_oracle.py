@@ -66,8 +66,61 @@ def layernorm(x, p, eps=1e-6):
   return (x - mu) * torch.rsqrt(var + eps) * p["scale"] + p["bias"]
 
 
+# --- optional emulation of the product's arithmetic (NOT the reference's) ---------------------
+# `with bf16_operands():` rounds BOTH operands of every tower contraction (and the incoming
+# cotangent in the backward) to bfloat16 and accumulates in the working dtype: the arithmetic the
+# north star prescribes for the MFMA GEMMs / attention (bf16 operands, fp32 accumulate).  The
+# tests use it to MEASURE the noise floor of that arithmetic per gradient tensor (oracle-bf16 vs
+# oracle-fp64), so a stated tolerance above SURVEY.md §8c's proposal carries a measured reason.
+# Outside the context manager nothing changes (plain torch matmul / einsum).
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+  def __enter__(self):
+    global _BF16_OPERANDS
+    self.prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+
+  def __exit__(self, *exc):
+    global _BF16_OPERANDS
+    _BF16_OPERANDS = self.prev
+
+
+def _rb(t):
+  return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16Contract(torch.autograd.Function):
+  """einsum(eq, a, b) with operands (forward) and cotangent (backward) rounded to bf16.  Every
+  index of an operand appears in the output or in the other operand (true for all contractions of
+  the model), so the two gradient contractions are einsums over the permuted equation."""
+
+  @staticmethod
+  def forward(ctx, eq, a, b):
+    ra, rb = _rb(a), _rb(b)
+    ctx.save_for_backward(ra, rb)
+    ctx.eq = eq
+    return torch.einsum(eq, ra, rb)
+
+  @staticmethod
+  def backward(ctx, g):
+    ra, rb = ctx.saved_tensors
+    lhs, out = ctx.eq.split("->")
+    ia, ib = lhs.split(",")
+    rg = _rb(g)
+    return None, torch.einsum(f"{out},{ib}->{ia}", rg, rb), torch.einsum(f"{ia},{out}->{ib}", ra, rg)
+
+
+def contract(eq, a, b):
+  if _BF16_OPERANDS:
+    return _Bf16Contract.apply(eq, a, b)
+  return torch.einsum(eq, a, b)
+
+
 def dense(x, p):
   """flax.linen.Dense: y = x @ kernel + bias (models/vit.py:72,77)."""
+  if _BF16_OPERANDS:
+    return _Bf16Contract.apply("...d,df->...f", x, p["kernel"]) + p["bias"]
   return x @ p["kernel"] + p["bias"]
 
 
@@ -82,15 +135,18 @@ def mha(xq, xkv, p, num_heads):
   q/k/v kernels (D,H,Dh) + bias (H,Dh); out kernel (H,Dh,D) + bias (D).
   query scaled by 1/sqrt(Dh) before the dot; softmax over keys; no mask.
   """
-  q = torch.einsum("nld,dhk->nlhk", xq, p["query"]["kernel"]) + p["query"]["bias"]
-  k = torch.einsum("nld,dhk->nlhk", xkv, p["key"]["kernel"]) + p["key"]["bias"]
-  v = torch.einsum("nld,dhk->nlhk", xkv, p["value"]["kernel"]) + p["value"]["bias"]
+  q = contract("nld,dhk->nlhk", xq, p["query"]["kernel"]) + p["query"]["bias"]
+  k = contract("nld,dhk->nlhk", xkv, p["key"]["kernel"]) + p["key"]["bias"]
+  v = contract("nld,dhk->nlhk", xkv, p["value"]["kernel"]) + p["value"]["bias"]
   dh = q.shape[-1]
-  q = q / math.sqrt(dh)
-  s = torch.einsum("nqhd,nkhd->nhqk", q, k)
+  if _BF16_OPERANDS:   # the kernels keep q unscaled in bf16 and fold 1/sqrt(dh) into the exponent
+    s = contract("nqhd,nkhd->nhqk", q, k) / math.sqrt(dh)
+  else:
+    q = q / math.sqrt(dh)
+    s = contract("nqhd,nkhd->nhqk", q, k)
   a = torch.softmax(s, dim=-1)
-  o = torch.einsum("nhqk,nkhd->nqhd", a, v)
-  return torch.einsum("nlhk,hkd->nld", o, p["out"]["kernel"]) + p["out"]["bias"]
+  o = contract("nhqk,nkhd->nqhd", a, v)
+  return contract("nlhk,hkd->nld", o, p["out"]["kernel"]) + p["out"]["bias"]
 
 
 def mlp_block(x, p):
@@ -170,7 +226,10 @@ def vit_forward(params, image, *, num_classes=None, patch_size=(16, 16), width=7
   out = {}
   patches, (h, w) = extract_patches(image, patch_size)
   kern = params["embedding"]["kernel"]
-  x = patches @ kern.reshape(-1, kern.shape[-1]) + params["embedding"]["bias"]
+  if _BF16_OPERANDS:
+    x = _Bf16Contract.apply("nlp,pd->nld", patches, kern.reshape(-1, kern.shape[-1])) + params["embedding"]["bias"]
+  else:
+    x = patches @ kern.reshape(-1, kern.shape[-1]) + params["embedding"]["bias"]
   out["stem"] = x.reshape(x.shape[0], h, w, -1)
   if posemb == "learn":
     pe = params["pos_embedding"]

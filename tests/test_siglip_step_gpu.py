@@ -7,9 +7,11 @@ oracle restatement of the reference step (oracle/bv_oracle.py).  Tolerances
   embeddings zimg/ztxt (unit norm)   max-abs  <= 2e-2
   logits  S = t z.z + b  (t = 10)    max-abs  <= 0.25
   loss                               rel      <= 1e-2
-  parameter gradients                cosine >= 0.99, rel-L2 <= 0.1 per tensor (0.15 for the
-                                     two-sample L/16@336 case)
-                                     (>= 1e-3 of the global grad norm)
+  parameter gradients                per tensor: cosine >= 0.999 and rel-L2 <= 3e-2, or
+                                     up to 2x the error the prescribed bf16-operand arithmetic
+                                     itself shows on that tensor (oracle with bf16-rounded
+                                     contraction operands vs fp64, measured per case: _parity.py);
+                                     tensors below 1e-3 of the global grad norm: abs err <= 2e-3 of it
   params after 1 Adam step           compared to the oracle chain fed OUR grads
                                      (isolates the optimizer): rtol 1e-5
 """
@@ -38,12 +40,19 @@ def _cfg(total_steps=10, **kw):
 
 
 def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, config=None,
-              tol_z=2e-2, tol_logit=0.25, tol_grad_rel=0.1):
+              tol_z=2e-2, tol_logit=0.25, frozen=(), floor=False, dirty_step=False, case=None):
+  """frozen: leaf-name prefixes config.schedule freezes (LiT).  floor: also measure the bf16-operand
+  noise floor of the oracle for this case (tests/_parity.py) and allow 2x that per tensor.
+  dirty_step: the weights are edited in place (as store.load_tree does) and update_fn runs FIRST,
+  with the bf16 shadow still dirty - the step itself has to refresh it; the forward-only parity
+  then runs on the restored pre-step weights."""
   import bv_oracle as O
+  import _parity
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
   from big_vision_amd import utils as u
 
+  case = case or f"siglip {image_cfg.get('variant', image_cfg.get('width'))} n={n} res={res} seq={seq}"
   model = two_towers.Model(image=image_cfg, text={**text_cfg, "vocab_size": vocab},
                            out_dim=(None, E), temperature_init=10.0, bias_init=bias_init)
   config = config or _cfg()
@@ -52,79 +61,132 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
   train_state, sched_fns = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape),
                                                    rng=0, total_steps=config.total_steps)
   store = train_state["params"].store
+  is_frozen = lambda k: any(k.startswith(p) for p in frozen)
+  assert {e for e in store.frozen} == {e for e in store.entries if is_frozen(e)}
   # break the symmetric inits (zero biases, unit scales) so every gradient path is exercised
   g = torch.Generator().manual_seed(7)
   for name in store.leaf_names():
     if name.endswith(("bias", "scale", "cls")):
       leaf = store.leaf(name)
       leaf.add_((0.05 * torch.randn(leaf.shape, generator=g)).to(dev))
-  store.mark_dirty(); store.refresh_shadow()
+  store.mark_dirty()
+  if not dirty_step:
+    store.refresh_shadow()
 
-  params64 = O.recover_tree([(k, v.detach().cpu().double().clone().requires_grad_(True))
+  params64 = O.recover_tree([(k, v.detach().cpu().double().clone().requires_grad_(not is_frozen(k)))
                              for k, v in u.tree_flatten_with_names(train_state["params"])[0]])
-  # ---- forward parity (apply) -------------------------------------------------
-  zimg, ztxt, out = model.apply({"params": train_state["params"]}, image_d, text_d, collect=False)
   okw = dict(image_cfg=image_cfg, text_cfg={**text_cfg, "vocab_size": vocab}, out_dim=(None, E))
   loss_ref, (zi_ref, zt_ref, logits_ref, _) = O.siglip_step_loss(params64, image.double(), text, **okw)
-  assert (zimg.cpu().double() - zi_ref).abs().max() <= tol_z
-  assert (ztxt.cpu().double() - zt_ref).abs().max() <= tol_z
-  t = math.exp(store.leaf("t").item()); b = store.leaf("b").item()
-  logits = (zimg.double() @ ztxt.double().T * t + b).cpu()
-  assert (logits - logits_ref).abs().max() <= tol_logit
-  loss_fwd = siglip.loss_fn(model, train_state["params"], image_d, text_d)
-  assert abs(loss_fwd.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
+  p_before = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(train_state["params"])[0]}
+
+  def forward_parity():
+    zimg, ztxt, out = model.apply({"params": train_state["params"]}, image_d, text_d, collect=False)
+    assert (zimg.cpu().double() - zi_ref).abs().max() <= tol_z
+    assert (ztxt.cpu().double() - zt_ref).abs().max() <= tol_z
+    t = math.exp(store.leaf("t").item()); b = store.leaf("b").item()
+    logits = (zimg.double() @ ztxt.double().T * t + b).cpu()
+    assert (logits - logits_ref).abs().max() <= tol_logit
+    loss_fwd = siglip.loss_fn(model, train_state["params"], image_d, text_d)
+    assert abs(loss_fwd.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
+
+  if not dirty_step:
+    forward_parity()
 
   # ---- one training step --------------------------------------------------------
-  p_before = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(train_state["params"])[0]}
   update_fn = siglip.make_update_fn(model, config)
   train_state, meas = update_fn(train_state, None, {"image": image_d, "labels": text_d})
   assert abs(meas["training_loss"].item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
   loss_ref.backward()
-  gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0]}
+  gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0] if v.grad is not None}
   gours = {k: v.detach().cpu().double() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
-  gnorm = math.sqrt(sum((v ** 2).sum().item() for v in gref.values()))
-  assert abs(meas["l2_grads"].item() - gnorm) <= 5e-2 * gnorm
-  worst = []
-  for k, gr in gref.items():
-    go = gours[k]
-    nr = gr.norm().item()
-    if nr < 1e-3 * gnorm:
-      assert (go - gr).norm().item() <= 2e-2 * gnorm, k
-      continue
-    cos = (go * gr).sum().item() / (go.norm().item() * nr + 1e-30)
-    rel = (go - gr).norm().item() / nr
-    worst.append((cos, rel, k))
-    assert cos >= 0.99 and rel <= tol_grad_rel, f"{k}: cosine {cos:.5f} rel-L2 {rel:.4f}"
+  fl = None
+  if floor:
+    fl = _parity.bf16_floor(lambda p: O.siglip_step_loss(p, image.double(), text, **okw)[0], params64)
+  gnorm, rows = _parity.compare_grads(case, gref, gours, frozen=frozen, floor=fl)
+  # l2_grads / clip norm cover the trainable leaves only (optax.py:105, siglip.py:316)
+  assert abs(meas["l2_grads"].item() - gnorm) <= 2e-2 * gnorm, (meas["l2_grads"].item(), gnorm)
   # ---- optimizer: oracle chain on OUR grads must reproduce OUR new params -------
+  opt = train_state["opt"]
+  assert opt.mu.numel() == store.trainable_count == opt.nu.numel() == store.grad.numel()
   orc = O.OptaxOracle(config.to_dict(), O.recover_tree(list(p_before.items())),
                       sched_kw=dict(total_steps=config.total_steps, batch_size=n))
-  upd = orc.update(O.recover_tree(list(gours.items())), O.recover_tree(list(p_before.items())))
+  g_all = {k: gours.get(k, torch.zeros_like(v)) for k, v in p_before.items()}
+  upd = orc.update(O.recover_tree(list(g_all.items())), O.recover_tree(list(p_before.items())))
   upd = dict(O.tree_flatten_with_names(upd))
-  for k, v in u.tree_flatten_with_names(train_state["params"])[0]:
+  p_after = {k: v.detach().cpu().double() for k, v in u.tree_flatten_with_names(train_state["params"])[0]}
+  for k, v in p_after.items():
     ref = p_before[k] + upd[k]
-    err = (v.detach().cpu().double() - ref).abs().max().item()
+    err = (v - ref).abs().max().item()
     assert err <= 1e-5 * max(1.0, ref.abs().max().item()), f"{k}: param err {err:.3e}"
-  return sorted(worst)[:3]
+    if is_frozen(k):
+      assert torch.equal(v, p_before[k]), f"frozen leaf {k} changed"
+  l2p = math.sqrt(sum((v ** 2).sum().item() for v in p_after.values()))          # incl. frozen (siglip.py:318)
+  l2u = math.sqrt(sum((upd[k] ** 2).sum().item() for k in p_after))
+  assert abs(meas["l2_params"].item() - l2p) <= 1e-4 * l2p
+  assert abs(meas["l2_updates"].item() - l2u) <= 1e-3 * l2u
+  if dirty_step:   # forward-only parity on the restored pre-step weights (load_tree -> dirty -> apply refreshes)
+    store.load_tree(O.recover_tree(list(p_before.items())))
+    forward_parity()
+  return rows
 
 
 def test_tiny_two_towers_step(dev):
   image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
   text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2)
-  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100)
+  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100, floor=True)
 
 
-def test_tiny_gap_tok_pooling(dev):
-  """LiT-style tower options: pool_type='tok' image tower (cls token), frozen image tower."""
+def test_tiny_tok_pooling(dev):
+  """pool_type='tok' image tower (cls token) with LiT's bias_init; nothing frozen here - the
+  frozen-tower step is test_lit_frozen_image_tower_step below."""
   image_cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok")
   text_cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2)
-  _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71)
+  _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71, floor=True)
+
+
+LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]
+
+
+def test_lit_frozen_image_tower_step_tiny(dev):
+  """LiT (configs/proj/image_text/siglip_lit_coco.py:79-104) on a toy width: the image tower is
+  frozen by `schedule=[("img/.*", None), ...]` - no image-tower gradient, no Adam state, clip norm
+  / l2_grads over the text tower + t + b only, l2_params including the frozen weights; the step
+  runs FIRST on a dirty bf16 shadow (advisor r1: update_fn must refresh it itself)."""
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok",
+                   head_zeroinit=False)
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2)
+  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100, bias_init=-2.71,
+            config=_cfg(schedule=LIT_SCHEDULE), frozen=("img/",), dirty_step=True, floor=True,
+            case="LiT tiny frozen img")
+
+
+def test_lit_frozen_image_tower_step_b16(dev):
+  """BASELINE configs[4] shapes: frozen ViT-B/16 (pool 'tok': 197 tokens) + trainable text-B at
+  16 tokens, bias_init -2.71, out_dim (None, 768), n = 8 (siglip_lit_coco.py:33,46,79-104 with the
+  in-repo text transformer standing in for BERT)."""
+  image_cfg = dict(variant="B/16", pool_type="tok", head_zeroinit=False)
+  text_cfg = dict(variant="B")
+  _run_case(dev, image_cfg, text_cfg, E=768, n=8, res=224, seq=16, vocab=32_000, bias_init=-2.71,
+            config=_cfg(schedule=LIT_SCHEDULE), frozen=("img/",), dirty_step=True, floor=True,
+            case="LiT B/16 frozen img n=8")
 
 
 def test_b16_siglip_step_small_batch(dev):
   """The real ViT-B/16 + text-B SigLIP model (BASELINE config 3 shapes) at n=4."""
   image_cfg = dict(variant="B/16", pool_type="map")
   text_cfg = dict(variant="B")
-  _run_case(dev, image_cfg, text_cfg, E=768, n=4, res=224, seq=64, vocab=32_000)
+  _run_case(dev, image_cfg, text_cfg, E=768, n=4, res=224, seq=64, vocab=32_000, floor=True)
+
+
+def test_b16_siglip_step_n32_through_microbatches(dev):
+  """The real B/16 + text-B model at n = 32 through the two-pass micro-batch path (4 micro-batches of
+  8, light contexts) against the fp64 oracle on the whole batch - the production N=1 code path
+  checked against the oracle rather than against itself."""
+  image_cfg = dict(variant="B/16", pool_type="map")
+  text_cfg = dict(variant="B")
+  _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000,
+            config=_cfg(microbatch=8, microbatch_keep="all", microbatch_light=True), floor=True,
+            case="siglip B/16 n=32 microbatch=8 light")
 
 
 def test_l16_336_siglip_step_small_batch(dev):
@@ -135,9 +197,18 @@ def test_l16_336_siglip_step_small_batch(dev):
   same tolerances in 134 s; every block has the same shapes)."""
   image_cfg = dict(variant="L/16", pool_type="map", depth=4)
   text_cfg = dict(variant="L", depth=4)
-  # Two samples only: the text key-projection gradient (softmax-shift invariant, hence small and
-  # cancellation-heavy) shows rel-L2 0.107 at cosine 0.994 here; 0.15 for this case, 0.1 elsewhere.
-  _run_case(dev, image_cfg, text_cfg, E=1024, n=2, res=336, seq=64, vocab=32_000, tol_grad_rel=0.15)
+  # The text key-projection gradient (cancellation-heavy: every row of dS sums to zero) showed rel-L2
+  # 0.107 at cosine 0.994 in round 1; the per-tensor bf16-operand floor measured here is what bounds it.
+  _run_case(dev, image_cfg, text_cfg, E=1024, n=2, res=336, seq=64, vocab=32_000, floor=True)
+
+
+def test_l16_336_siglip_step_n16(dev):
+  """Same shapes at n = 16 (depth 2): the evidence the round-1 review asked for - the worst tensors of
+  the two-sample case re-measured on a larger batch, each next to its bf16-operand floor."""
+  image_cfg = dict(variant="L/16", pool_type="map", depth=2)
+  text_cfg = dict(variant="L", depth=2)
+  _run_case(dev, image_cfg, text_cfg, E=1024, n=16, res=336, seq=64, vocab=32_000, floor=True,
+            case="siglip L/16@336 depth2 n=16")
 
 
 @pytest.mark.parametrize("keep,light", [(0, False), (1, False), ("all", False), ("auto", "auto"),

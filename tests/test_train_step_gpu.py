@@ -1,8 +1,8 @@
 """Classification trainer parity (BASELINE configs[0], big_vision/train.py:275-315): the HIP
 `big_vision_amd.train.update_fn` vs the fp64 oracle restatement on identical weights and a
 synthetic batch.  Tolerances as in test_siglip_step_gpu.py (bf16 MFMA operands / fp32 accumulate
-vs fp64): loss rel <= 1e-2, logits max-abs <= 5e-2, per-tensor gradient cosine >= 0.99 and
-rel-L2 <= 0.1 (tensors above 1e-3 of the global gradient norm)."""
+vs fp64): loss rel <= 1e-2, logits max-abs <= 5e-2, per-tensor gradient bounds of tests/_parity.py
+(cosine >= 0.999, rel-L2 <= 3e-2, or 2x the measured bf16-operand floor of the tensor)."""
 import math
 
 import pytest
@@ -64,16 +64,13 @@ def _run(dev, model_cfg, num_classes, n, res, loss, mixup_a):
   loss_ref.backward()
   gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0]}
   gours = {k: v.detach().cpu().double() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
-  gnorm = math.sqrt(sum((v ** 2).sum().item() for v in gref.values()))
-  assert abs(meas["l2_grads"].item() - gnorm) <= 5e-2 * gnorm
-  for k, gr in gref.items():
-    go, nr = gours[k], gr.norm().item()
-    if nr < 1e-3 * gnorm:
-      assert (go - gr).norm().item() <= 2e-2 * gnorm, k
-      continue
-    cos = (go * gr).sum().item() / (go.norm().item() * nr + 1e-30)
-    rel = (go - gr).norm().item() / nr
-    assert cos >= 0.99 and rel <= 0.1, f"{k}: cosine {cos:.5f} rel-L2 {rel:.4f}"
+  import _parity
+  fl = _parity.bf16_floor(
+      lambda p: O.classification_step_loss(p, image.double(), labels.double(), model_cfg=ocfg,
+                                           num_classes=num_classes, loss=loss, mixup_a=mixup_a)[0], params64)
+  gnorm, _ = _parity.compare_grads(f"classification {model_cfg.get('variant', 'tiny')} {loss} n={n}", gref, gours,
+                                   floor=fl)
+  assert abs(meas["l2_grads"].item() - gnorm) <= 2e-2 * gnorm
   train.check_finite(meas)
 
 
