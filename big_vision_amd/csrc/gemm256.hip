@@ -34,6 +34,7 @@
 // of k-row k lives at slot q ^ swzk(k); fragments come out of ds_read_b64_tr_b16.
 #include "bv_common.h"
 #include "bvhip_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -673,6 +674,428 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ROLLING-EPILOGUE variant of the k-major kernel (same tiles, LDS images, DMA ring and phase
+// structure as gemm256_kernel<true>; reference call sites as there).
+//
+// gemm256_kernel stops at every tile boundary: all 8 waves convert and store their 128x64 block,
+// the whole XCD pushes its C tiles through the L2 write path at the same time and the next tile's
+// first K-tile waits behind the stores (measured: 9-10 k of the 43 k cycles of a K = 768 tile).
+// Here there is NO epilogue phase.  The phases of a K-tile visit the wave's C quadrants in the
+// order (0,0) (0,1) (1,1) (1,0); quadrant q of tile t is final after phase q of t's LAST K-tile
+// and its registers are next written in phase q of tile t+1's FIRST K-tile.  Its epilogue
+// (scale, bias, activation, convert, 4-8 stores per lane) runs in the LOAD segment of the phase
+// after its last MFMA - while the partner wave group (one barrier behind / ahead) owns the matrix
+// pipe: (0,0) (0,1) (1,1) in phases 1-3 of the last K-tile, (1,0) in phase 0 of the next tile.
+// The K loop never drains: every VMEM wait is a counted s_waitcnt that leaves the youngest stores
+// (and the loads behind them) in flight.
+//   * first K-tile of a tile: the k-step-0 MFMAs take C = 0 (no accumulator clearing);
+//   * +residual (BV_EPI_RESIDUAL, alpha = 1): the fp32 residual tile of the NEXT tile is loaded
+//     straight INTO the accumulator registers of a quadrant right after that quadrant was stored
+//     (three phases before its first MFMA), so x + f(x) costs no extra registers, no VALU adds and
+//     its HBM read overlaps the K loop;
+//   * bias: 16 floats per lane, reloaded in phase 1 of every tile's first K-tile.
+// Loads with VGPR destinations are inline asm (hipcc would drain the DMA queue for any load it
+// counts itself); their waits name the destinations ("+v") so no consumer moves above them.
+// In-order VMEM queue per wave and K-tile kind (g = 2 DMA instructions, S / X = NS stores / NX
+// residual loads of one quadrant, BL = 4 bias loads):
+//   last  K-tile:  ph0 gA0 | ph1 gA1 S00 X00 | ph2 gB0 S01 X01 | ph3 gB1 WAIT(a) S11 X11
+//   first K-tile:  ph0 gA0 S10 X10 W(X00) | ph1 gA1 BL W(X01) | ph2 gB0 W(X11) | ph3 gB1 vmcnt(4)
+//   WAIT(a) retires gA1 of the last K-tile: 4 + 2 NS + 2 NX younger operations stay in flight.
+// Whenever a K-tile does not issue its full set of DMA (the last two K-tiles of a workgroup's
+// list) the counted waits fall back to vmcnt(0).  Requires K >= 128 (first != last K-tile).
+__device__ __forceinline__ void gl_load16(f32x4& d, const void* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr) : "memory");
+}
+// 16-byte load at (wave-uniform base in SGPRs) + (32-bit per-lane byte offset): no 64-bit VALU
+// address arithmetic, one VGPR of address per lane
+__device__ __forceinline__ void gl_load16s(f32x4& d, const void* sbase, uint32_t voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+// Waiting for asm loads: a counted s_waitcnt (no operands), THEN one empty statement that names the
+// destinations read-write.  The wait itself must not carry the "+v" ties: hipcc satisfies a tie
+// with register copies placed BEFORE the statement, i.e. before the wait - it did exactly that on
+// one of two branches here and copied bias registers whose loads had not landed.  With the tie on
+// a separate empty statement every such copy sits after the wait, and no consumer can be moved
+// above it.
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void vm_tie4(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3) {
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+}
+__device__ __forceinline__ void vm_tie8(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3, f32x4& a4, f32x4& a5,
+                                        f32x4& a6, f32x4& a7) {
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+}
+
+template <int EPI, bool OUTF32>
+__global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
+  static_assert(EPI == BV_EPI_NONE || EPI == BV_EPI_GELU || EPI == BV_EPI_RESIDUAL, "epilogue");
+  static_assert(OUTF32 == (EPI == BV_EPI_RESIDUAL), "fp32 output only with the residual epilogue");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  constexpr int NS = EPI == BV_EPI_NONE ? 4 : 8;        // stores per quadrant and lane
+  constexpr int NX = EPI == BV_EPI_RESIDUAL ? 8 : 0;    // residual loads per quadrant and lane
+  constexpr int W_A = 4 + 2 * NS + 2 * NX;
+  constexpr int W_X00 = 6 + 3 * NS + 3 * NX, W_X01 = 10 + 2 * NS + 2 * NX, W_X11 = 10 + NS + NX;
+  static_assert(W_X00 < 64, "vmcnt is a 6-bit field");
+
+  // ---- XCD-aware work distribution (as gemm256_kernel)
+  const int bid = blockIdx.x, G = gridDim.x;
+  const int nwork = p.ntiles;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q8 = nwork >> 3, r8 = nwork & 7;
+  const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int cl = q8 + (xcd < r8 ? 1 : 0);
+  const int bpx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+  const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
+  if (nmy == 0) return;
+  const int nk_all = p.K >> 6;
+
+  auto load_item = [&](Cursor& c) {
+    c.tile = cs + idx + c.j * bpx;
+    c.split = 0;
+    const int tm = c.tile / p.tiles_n, tn = c.tile - tm * p.tiles_n;
+    c.m0 = tm * 256; c.n0 = tn * 256;
+    c.nk = nk_all;
+    c.offA = (long)c.m0 * p.lda;
+    c.offB = (long)c.n0 * p.ldb;
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.t == c.nk) {
+      c.t = 0;
+      ++c.j;
+      if (c.j < nmy) load_item(c);
+    }
+  };
+
+  // ---- per-lane global source pointers of the DMA
+  const bf16* srcA;
+  const bf16* srcB;
+  {
+    const int r = wave * 8 + (lane >> 3);
+    const int pos = lane & 7;
+    const int cc = pos ^ kswz(r);
+    srcA = p.A + (long)r * p.lda + cc * 8;
+    srcB = p.B + (long)r * p.ldb + cc * 8;
+  }
+  const long gA = 64 * p.lda, gB = 64 * p.ldb, hA = 128 * p.lda, hB = 128 * p.ldb;
+  char* const ldsA = smem;
+  char* const ldsB = smem + A_BYTES;
+  const int wave_off = wave * 1024;
+  auto issueA = [&](const Cursor& c, int slot, int h) {
+    char* d = ldsA + (slot * 2 + h) * HALF + wave_off;
+    const bf16* s = srcA + c.offA + (long)c.t * 64 + (h ? hA : 0);
+    glds16(s, d);
+    glds16(s + gA, d + 8192);
+  };
+  auto issueB = [&](const Cursor& c, int slot, int h) {
+    char* d = ldsB + (slot * 2 + h) * HALF + wave_off;
+    const bf16* s = srcB + c.offB + (long)c.t * 64 + (h ? hB : 0);
+    glds16(s, d);
+    glds16(s + gB, d + 8192);
+  };
+
+  // ---- per-lane LDS read addresses (relative to the stage base), as gemm256_kernel<true>
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int brow = OUTF32 ? lr : (lr >> 2) * 8 + (lr & 3);
+  const uint32_t ra0 = lds0 + wr * HALF + lr * 128 + ((lg ^ kswz(lr)) << 4);
+  const uint32_t ra1 = ra0 ^ 64;
+  const uint32_t rb0 = lds0 + A_BYTES + (wc >> 1) * HALF + ((wc & 1) * 64 + brow) * 128 + ((lg ^ kswz(brow)) << 4);
+  const uint32_t rb1 = rb0 ^ 64;
+
+  f32x4 acc[8][4];
+  bf16x8 af[4][2], bfg[4][2];
+  f32x4 bq[4];   // bias of the tile whose epilogue is running: bq[j][r] = bias[col(j) + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto readA = [&](uint32_t sa, int sub) {
+    const uint32_t a0 = ra0 + sa, a1 = ra1 + sa;
+    if (sub == 0) {
+      af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
+      af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
+      af[2][0] = lds_read128<4096>(a0);  af[2][1] = lds_read128<4096>(a1);
+      af[3][0] = lds_read128<6144>(a1);  af[3][1] = lds_read128<6144>(a0);
+    } else {
+      af[0][0] = lds_read128<8192>(a0);  af[0][1] = lds_read128<8192>(a1);
+      af[1][0] = lds_read128<10240>(a1); af[1][1] = lds_read128<10240>(a0);
+      af[2][0] = lds_read128<12288>(a0); af[2][1] = lds_read128<12288>(a1);
+      af[3][0] = lds_read128<14336>(a1); af[3][1] = lds_read128<14336>(a0);
+    }
+  };
+  auto readB = [&](uint32_t sb, int sub) {
+    const uint32_t b0 = rb0 + sb, b1 = rb1 + sb;
+    constexpr int O1 = OUTF32 ? 2048 : 512, O2 = 4096, O3 = OUTF32 ? 6144 : 4608;
+    if (sub == 0) {
+      bfg[0][0] = lds_read128<0>(b0);    bfg[0][1] = lds_read128<0>(b1);
+      bfg[1][0] = lds_read128<O1>(b1);   bfg[1][1] = lds_read128<O1>(b0);
+    } else {
+      bfg[2][0] = lds_read128<O2>(b0);   bfg[2][1] = lds_read128<O2>(b1);
+      bfg[3][0] = lds_read128<O3>(b1);   bfg[3][1] = lds_read128<O3>(b0);
+    }
+  };
+
+  // Epilogue addressing: (wave-uniform 64-bit base, SALU) + (per-lane 32-bit byte offset, loop
+  // invariant).  Row fragment i of the wave sits at rows m0 + wr*128 + i*16 + lr; column fragment j
+  // at element n0 + wc*64 + {fp32 out: j*16 + lg*4 | bf16 out: (j>>1)*32 + lg*8 + (j&1)*4}
+  // (see the epilogue comment of gemm256_kernel).
+  constexpr int ESZ = OUTF32 ? 4 : 2;
+  const uint32_t lane_c = (uint32_t)lr * (uint32_t)p.ldc * ESZ + (OUTF32 ? lg * 16 : lg * 16);
+  const uint32_t lane_x = (uint32_t)lr * (uint32_t)p.ldaux * 4 + lg * 16;
+  const uint32_t lane_b = OUTF32 ? lg * 16 : lg * 32;
+  auto ucol = [&](int n0, int j) {   // wave-uniform part of fragment j's column
+    return n0 + wc * 64 + (OUTF32 ? j * 16 : (j >> 1) * 32 + (j & 1) * 4);
+  };
+  // issue the NX residual loads of quadrant (IH, JH) of the tile at (xm0, xn0) into its accumulators
+  auto xload = [&](auto IHc, auto JHc, int xm0, int xn0) {
+    constexpr int IH = decltype(IHc)::value, JH = decltype(JHc)::value;
+    if constexpr (NX > 0) {
+      const float* x0 = reinterpret_cast<const float*>(p.aux) + (long)(xm0 + wr * 128 + IH * 64) * p.ldaux;
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          gl_load16s(acc[IH * 4 + ii][JH * 2 + jj], x0 + (long)ii * 16 * p.ldaux + ucol(xn0, JH * 2 + jj), lane_x);
+    }
+  };
+  // issue the 4 bias loads of the tile with columns n0.. (no bias: any valid address, zeroed later)
+  auto bload = [&](int n0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      gl_load16s(bq[j], p.bias ? (const void*)(p.bias + ucol(n0, j)) : (const void*)p.A, p.bias ? lane_b : 0u);
+  };
+  // epilogue of quadrant (IH, JH) of the tile at (m0, n0): NS stores per lane
+  auto chunk = [&](auto IHc, auto JHc, int m0, int n0) {
+    constexpr int IH = decltype(IHc)::value, JH = decltype(JHc)::value;
+    const long mrow = m0 + wr * 128 + IH * 64;
+    if constexpr (OUTF32) {
+      char* c0 = reinterpret_cast<char*>(reinterpret_cast<float*>(p.C) + mrow * p.ldc);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int i = IH * 4 + ii, j = JH * 2 + jj;
+          const f32x4 v = acc[i][j] + bq[j];       // alpha = 1; the residual is already in acc
+          char* cb = c0 + ((long)ii * 16 * p.ldc + ucol(n0, j)) * 4;
+          *reinterpret_cast<f32x4*>(cb + lane_c) = v;
+        }
+    } else {
+      char* c0 = reinterpret_cast<char*>(reinterpret_cast<bf16*>(p.C) + mrow * p.ldc + ucol(n0, JH * 2));
+      char* g0 = reinterpret_cast<char*>(reinterpret_cast<bf16*>(p.C2) + mrow * p.ldc + ucol(n0, JH * 2));
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = IH * 4 + ii;
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][JH * 2 + jj][r] * p.alpha + bq[JH * 2 + jj][r];
+        uint32_t hw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hw[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<u32x4*>(c0 + (long)ii * 32 * p.ldc + lane_c) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+        if constexpr (EPI == BV_EPI_GELU) {
+          uint32_t gw[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gw[e] = pack_bf2(gelu_tanh_f(bflo(hw[e])), gelu_tanh_f(bfhi(hw[e])));
+          *reinterpret_cast<u32x4*>(g0 + (long)ii * 32 * p.ldc + lane_c) = u32x4{gw[0], gw[1], gw[2], gw[3]};
+        }
+      }
+    }
+  };
+
+#define BVR_MFMA_QUAD(I0, J0, ZERO)                                                            \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+          acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+              bfg[(J0) + j][ks], af[i][ks],                                                    \
+              ((ZERO) && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[(I0) + i][(J0) + j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+#define BVR_MID()                                         \
+  do {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    __builtin_amdgcn_s_barrier();                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+#define BVR_END()                            \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+  } while (0)
+#define BVR_PIN() __builtin_amdgcn_sched_barrier(0)
+
+  // ---- prologue: B(0), A(0), B(1) in flight; K-tile 0 must have landed.
+  Cursor cur{};
+  cur.j = 0; cur.t = 0;
+  load_item(cur);
+  Cursor ca = cur, cb = cur;   // A stream runs 1 K-tile ahead, B stream 2 K-tiles ahead
+  issueB(cb, 0, 0); issueB(cb, 0, 1);
+  issueA(ca, 0, 0); issueA(ca, 0, 1);
+  advance(ca);
+  advance(cb);
+  issueB(cb, 1, 0); issueB(cb, 1, 1);     // nk >= 2: K-tile 1 of the first tile always exists
+  advance(cb);
+  BVR_PIN();
+  if constexpr (NX > 0) {
+    // residual of the first tile into all four quadrants; drained here, once
+    xload(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, cur.m0, cur.n0);
+    xload(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, cur.m0, cur.n0);
+    xload(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, cur.m0, cur.n0);
+    xload(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, cur.m0, cur.n0);
+    vm_wait<0>();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vm_tie4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  BVR_PIN();
+  __builtin_amdgcn_s_barrier();
+
+  int gk = 0;  // K-tiles consumed so far (ring position)
+  int bs = 0;  // B ring slot of the current K-tile
+  int em0 = 0, en0 = 0;     // tile whose epilogue is rolling
+  int xm0 = 0, xn0 = 0;     // tile after it (target of the residual loads issued during its last K-tile)
+  bool have_prev = false, have_next = false;
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  auto ktile = [&](auto FIRSTc, auto LASTc) {
+    constexpr bool FIRST = decltype(FIRSTc)::value, LAST = decltype(LASTc)::value;
+    constexpr bool ZERO = FIRST && NX == 0;
+    const uint32_t sa = (gk & 1) * 2 * HALF;
+    const uint32_t sb = bs * 2 * HALF;
+    const int bs1 = (bs == 2) ? 0 : bs + 1;          // slot of K-tile gk+1
+    const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of K-tile gk+2
+    const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
+    const bool full = moreA && moreB;
+    // -------- phase 0: quadrant (0,0)
+    readA(sa, 0);
+    readB(sb, 0);
+    if (moreA) issueA(ca, (gk + 1) & 1, 0);
+    BVR_PIN();
+    if constexpr (FIRST) {
+      if (have_prev) {
+        chunk(I1{}, I0{}, em0, en0);
+        BVR_PIN();
+        xload(I1{}, I0{}, cur.m0, cur.n0);
+      }
+      if constexpr (NX > 0) {
+        if (full) vm_wait<W_X00>();
+        else vm_wait<0>();
+        vm_tie8(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+      }
+    }
+    BVR_MID();
+    BVR_MFMA_QUAD(0, 0, ZERO);
+    BVR_END();
+    // -------- phase 1: quadrant (0,1)
+    readB(sb, 1);
+    if (moreA) issueA(ca, (gk + 1) & 1, 1);
+    BVR_PIN();
+    if constexpr (LAST) {
+      chunk(I0{}, I0{}, em0, en0);
+      BVR_PIN();
+      if (have_next) xload(I0{}, I0{}, xm0, xn0);
+    }
+    if constexpr (FIRST) {
+      // bias of this tile (always 4 loads, so that the counts are static; no bias: any valid address)
+      bload(cur.n0);
+      if constexpr (NX > 0) {
+        if (full) vm_wait<W_X01>();
+        else vm_wait<0>();
+        vm_tie8(acc[0][2], acc[0][3], acc[1][2], acc[1][3], acc[2][2], acc[2][3], acc[3][2], acc[3][3]);
+      }
+    }
+    BVR_MID();
+    BVR_MFMA_QUAD(0, 2, ZERO);
+    BVR_END();
+    // -------- phase 2: quadrant (1,1)
+    readA(sa, 1);
+    if (moreB) issueB(cb, bs2, 0);
+    BVR_PIN();
+    if constexpr (LAST) {
+      chunk(I0{}, I1{}, em0, en0);
+      BVR_PIN();
+      if (have_next) xload(I0{}, I1{}, xm0, xn0);
+    }
+    if constexpr (FIRST && NX > 0) {
+      if (full) vm_wait<W_X11>();
+      else vm_wait<0>();
+      vm_tie8(acc[4][2], acc[4][3], acc[5][2], acc[5][3], acc[6][2], acc[6][3], acc[7][2], acc[7][3]);
+    }
+    BVR_MID();
+    BVR_MFMA_QUAD(4, 2, ZERO);
+    BVR_END();
+    // -------- phase 3: quadrant (1,0); retire K-tile gk+1's loads for the next iteration
+    if (moreB) issueB(cb, bs2, 1);
+    BVR_PIN();
+    if constexpr (LAST) {
+      if (full) vm_wait<W_A>();
+      else vm_wait<0>();
+      BVR_PIN();
+      chunk(I1{}, I1{}, em0, en0);
+      BVR_PIN();
+      if (have_next) xload(I1{}, I1{}, xm0, xn0);
+    } else if constexpr (FIRST) {
+      // also retires this tile's bias loads and the residual loads of quadrant (1,0)
+      if (moreB) vm_wait<4>();
+      else vm_wait<0>();
+      vm_tie4(bq[0], bq[1], bq[2], bq[3]);
+      if constexpr (NX > 0) vm_tie8(acc[4][0], acc[4][1], acc[5][0], acc[5][1], acc[6][0], acc[6][1], acc[7][0], acc[7][1]);
+      if (!p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      if (moreB) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BVR_MID();
+    BVR_MFMA_QUAD(4, 0, ZERO);
+    BVR_END();
+    if (moreA) advance(ca);
+    if (moreB) advance(cb);
+    bs = bs1;
+    ++gk;
+  };
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind, for the whole launch
+  for (int jt = 0; jt < nmy; ++jt) {
+    const int nkc = cur.nk;
+    ktile(T_{}, F_{});
+    for (int t = 1; t < nkc - 1; ++t) ktile(F_{}, F_{});
+    // the last K-tile rolls this tile's epilogue; the residual loads it issues belong to the next tile
+    em0 = cur.m0; en0 = cur.n0;
+    have_next = jt + 1 < nmy;
+    cur.t = cur.nk - 1;
+    advance(cur);
+    xm0 = cur.m0; xn0 = cur.n0;
+    ktile(F_{}, T_{});
+    have_prev = true;
+  }
+  BVR_PIN();
+  chunk(I1{}, I0{}, em0, en0);   // quadrant (1,0) of the last tile
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef BVR_MFMA_QUAD
+#undef BVR_MID
+#undef BVR_END
+#undef BVR_PIN
+}
+
 // C[m][n..n+3] += alpha * sum_s slab[s][tile][...]  (deterministic split-K combine).
 // One thread per float4 of a tile; slab layout [wave][i][j][lane][4] as written above.
 __global__ __launch_bounds__(256) void gemm256_reduce_kernel(const float* __restrict__ slab,
@@ -712,7 +1135,14 @@ extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
 // Tuning knobs of the k-major kernel (tools/gemm_step_shapes.py A/Bs them):
 //   nt: bit 0 streaming stores, bit 1 streaming aux loads;  skew_mode / skew_pct: start skew of
 //   the workgroups as a percentage of one tile period (0 = off).  Negative = leave unchanged.
-static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0;
+static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1;
+// Which epilogues run on the rolling-epilogue kernel (bit mask): 1 = +residual (default: the only one
+// it measured faster on, 2-5 %), 2 = none/bias (bf16), 4 = GELU.
+extern "C" int bv_gemm_roll(int mask) {
+  const int old = g_roll;
+  if (mask >= 0) g_roll = mask;
+  return old;
+}
 extern "C" int bv_gemm_pre_issue(int enable) {   // diagnostics: A/B the pre-epilogue load issue
   const int old = g_pre;
   if (enable >= 0) g_pre = enable;
@@ -839,6 +1269,17 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   p.dbg = nullptr;
   dim3 grid(nwork < 256 ? nwork : 256), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
+  // rolling-epilogue kernel: k-major, at least two K-tiles per tile, the epilogues it implements
+  const bool roll = km && nk >= 2 && !colsum &&
+                    (((g_roll & 2) && epilogue == BV_EPI_NONE && !out_f32) ||
+                     ((g_roll & 4) && epilogue == BV_EPI_GELU && !out_f32) ||
+                     ((g_roll & 1) && epilogue == BV_EPI_RESIDUAL && out_f32 && alpha == 1.0f));
+  if (roll) {
+    if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
+    else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_GELU, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_NONE, false>), grid, block, 0, s, p);
+    return 1;
+  }
   if (!km) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_POS) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_POS, true>), grid, block, 0, s, p);

@@ -108,6 +108,12 @@ int bv_gemm_tune(int nt, int skew_mode, int skew_pct);
  * the epilogue's stores (same in-order VMEM queue) and leaves the stores outstanding at the
  * next tile's first counted wait.  enable = 0/1 sets, -1 queries; returns the old value. */
 int bv_gemm_pre_issue(int enable);
+/* Which epilogues of k-major GEMMs with K >= 128 run on the rolling-epilogue kernel (no separate
+ * epilogue phase: the epilogue of each accumulator quadrant is folded into the load segments of
+ * the K loop; the residual is loaded straight into the accumulators).  Bit mask: 1 = RESIDUAL
+ * (alpha = 1), 2 = NONE (bf16 out), 4 = GELU; default 1 (the only one measured faster).
+ * mask < 0 only queries; returns the old value. */
+int bv_gemm_roll(int mask);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,

@@ -49,3 +49,21 @@ def test_no_spills_no_scratch(src, tmp_path):
     assert r.get("VGPRs Spill", 0) == 0, f"{src}:{name} spills vector registers: {r}"
     assert r.get("ScratchSize [bytes/lane]", 0) == 0, f"{src}:{name} uses scratch memory: {r}"
     assert r.get("VGPRs", 0) <= 256, (name, r)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_asm_loads_are_not_touched_before_their_wait(tmp_path):
+  """gemm256r_kernel hides its bias / residual loads from hipcc in inline asm (a load hipcc counts
+  itself would drain the LDS-DMA queue).  hipcc does not know such a destination is in flight: a
+  register copy placed between the asm load and the counted wait reads stale data (this happened:
+  the copies hipcc emits to satisfy a "+v" tie landed BEFORE the tied s_waitcnt on one branch).
+  tools/audit_asm_loads.py scans the ISA for any instruction that touches an asm-loaded register
+  before the next vmcnt wait."""
+  import sys
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import audit_asm_loads
+  out = tmp_path / "g256.s"
+  subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-x", "hip", "-S",
+                  "--cuda-device-only", os.path.join(CSRC, "gemm256.hip"), "-o", str(out)],
+                 check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+  assert audit_asm_loads.audit(str(out), "gemm256r") == 0

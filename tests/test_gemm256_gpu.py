@@ -154,3 +154,47 @@ def test_big_shape_spot_check(dev, fast):
   close(y[rows], ref, 1e-4, 2e-3, "fc1 rows")
   y2 = ops.gemm(x, wt, a_kmajor=True, b_kmajor=True, out_dtype=F32)
   assert torch.equal(y, y2)
+
+
+ROLL_SHAPES = [(256, 256, 128), (512, 256, 192), (1024, 768, 320), (66816, 768, 128), (2304, 768, 768),
+               (33024, 768, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", ROLL_SHAPES)
+def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, N, K):
+  """gemm256r_kernel (epilogue folded into the K loop, residual loaded into the accumulators) vs
+  gemm256_kernel through the same dispatcher (bv_gemm_roll mask): bit-identical for the bf16
+  epilogues (same accumulation order and epilogue arithmetic), fp32 rounding-order noise for
+  +residual; run-to-run bit-equality as the race screen.  66816 x 768 x 128 = 783 tiles of two
+  K-tiles: every workgroup rolls 3-4 tiles whose first K-tile is also the one before the last
+  (the shape that exposed a tie-induced register copy ahead of an asm wait)."""
+  from big_vision_amd import ops, _lib
+  lib = _lib.load()
+  a = rnd((M, K), dev, 21, dtype=BF16)
+  w = rnd((N, K), dev, 22, 0.05, dtype=BF16)
+  b = rnd((N,), dev, 23)
+  res = rnd((M, N), dev, 24, 2.0)
+  kw = dict(a_kmajor=True, b_kmajor=True)
+
+  def run_all():
+    y0 = ops.gemm(a, w, bias=b, out_dtype=BF16, **kw)
+    g = torch.empty((M, N), device=dev, dtype=BF16)
+    h = ops.gemm(a, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g, **kw)
+    y1 = ops.gemm(a, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
+    y2 = ops.gemm(a, w, out_dtype=BF16, alpha=0.5, **kw)          # no bias, alpha != 1
+    return y0, h, g, y1, y2
+
+  old = lib.bv_gemm_roll(0)
+  try:
+    ref = run_all()
+    lib.bv_gemm_roll(7)
+    new = [run_all() for _ in range(3)]
+  finally:
+    lib.bv_gemm_roll(old)
+  for k, name in enumerate(("bias bf16", "gelu h", "gelu g", "residual f32", "alpha bf16")):
+    for r in new[1:]:
+      assert torch.equal(r[k], new[0][k]), f"{name}: run-to-run difference"
+    if name == "residual f32":
+      close(new[0][k], ref[k], 1e-6, 1e-4, name)
+    else:
+      assert torch.equal(new[0][k], ref[k]), f"{name}: rolling kernel differs from the full-epilogue kernel"

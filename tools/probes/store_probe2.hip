@@ -8,7 +8,7 @@
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) unsigned u4;
 template <int PAT, bool NT>
-__global__ __launch_bounds__(512) void k(u4* out, long* cyc, int reps, long tile_stride_u4) {
+__global__ __launch_bounds__(512) void k(u4* out, long* cyc, int reps, long tile_stride_u4, int ld_u4 = 32) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
   constexpr int LPR = PAT / 16;          // lanes per row
@@ -16,7 +16,10 @@ __global__ __launch_bounds__(512) void k(u4* out, long* cyc, int reps, long tile
   const int lrow = lane / LPR, lcol = lane % LPR;
   long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
-    u4* base = out + (long)(blockIdx.x * reps + r) * tile_stride_u4;   // tile: 256 rows x 32 u4
+    // tile: 256 rows x 32 u4.  ld_u4 == 32: tiles are contiguous 128 KiB blocks; otherwise the tiles sit
+    // in a row-major [M][ld_u4] matrix (the GEMM's C: row stride N*2 bytes), 9 tiles per row of tiles
+    const long tix = (long)blockIdx.x * reps + r;
+    u4* base = ld_u4 == 32 ? out + tix * tile_stride_u4 : out + (tix / 9) * 256 * ld_u4 + (tix % 9) * 32;
     // wave owns 128 rows x 8 u4 (128 B) when PAT<=128 [2x4 wave grid]; for wider patterns the
     // wave owns 32 rows x 32 u4 (full 512-B rows) [8x1 wave grid].
 #pragma unroll
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(512) void k(u4* out, long* cyc, int reps, long tile
         row = wave * 32 + rg * RPI + lrow;
         col = cc * LPR + lcol;
       }
-      u4* p = base + (long)row * 32 + col;
+      u4* p = base + (long)row * ld_u4 + col;
       if (NT) __builtin_nontemporal_store(v, p); else *p = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -44,14 +47,14 @@ __global__ __launch_bounds__(512) void k(u4* out, long* cyc, int reps, long tile
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 template <int PAT, bool NT>
-void run(u4* out, long* cyc, const char* name) {
+void run(u4* out, long* cyc, const char* name, int ld_u4 = 32) {
   const int reps = 16;
   for (int nb : {1, 32, 256}) {
-    hipLaunchKernelGGL((k<PAT, NT>), dim3(nb), dim3(512), 0, 0, out, cyc, reps, 8192L);
+    hipLaunchKernelGGL((k<PAT, NT>), dim3(nb), dim3(512), 0, 0, out, cyc, reps, 8192L, ld_u4);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<PAT, NT>), dim3(nb), dim3(512), 0, 0, out, cyc, reps, 8192L);
+    hipLaunchKernelGGL((k<PAT, NT>), dim3(nb), dim3(512), 0, 0, out, cyc, reps, 8192L, ld_u4);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long> h(nb);
@@ -63,7 +66,7 @@ void run(u4* out, long* cyc, const char* name) {
 }
 int main() {
   u4* out; long* cyc;
-  hipMalloc(&out, (size_t)256 * 16 * 131072);
+  hipMalloc(&out, (size_t)256 * 16 * 131072 * 2);
   hipMalloc(&cyc, 1024 * 8);
   run<64, false>(out, cyc, "64B");
   run<128, false>(out, cyc, "128B");
@@ -73,5 +76,10 @@ int main() {
   run<64, true>(out, cyc, "64B nt");
   run<128, true>(out, cyc, "128B nt");
   run<1024, true>(out, cyc, "1024B nt");
+  // rows strided as in C[M][2304] bf16 (4608 B per row)
+  run<64, false>(out, cyc, "64B ld288", 288);
+  run<128, false>(out, cyc, "128B ld288", 288);
+  run<256, false>(out, cyc, "256B ld288", 288);
+  run<512, false>(out, cyc, "512B ld288", 288);
   return 0;
 }

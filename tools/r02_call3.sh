@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/c3
+rm -rf $O; mkdir -p $O
+timeout 120 tools/probes/store_probe2.out > $O/store_probe2.txt 2>&1; cat $O/store_probe2.txt
+timeout 300 tools/probes/gemm_roll_probe.out > $O/roll_probe.txt 2>&1; cut -c1-250 $O/roll_probe.txt
