@@ -6,11 +6,11 @@ pairwise sigmoid loss over the GLOBAL batch 4096, Adam + clip + wd + cosine
 schedule.  One "step" = forward + backward + gradient sync + optimizer update
 on one batch of synthetic pairs already resident in HBM.  The global batch is
 fixed at 4096 for every N ("strong" scaling): each of the N ranks owns 4096/N
-pairs and processes them in micro-batches of 512 (two-pass embedding /
-recompute scheme of big_vision_amd/trainers/proj/image_text/siglip.py when
-4096/N > 512; single pass at N=8).
+pairs and processes them in micro-batches of 2048 (two-pass embedding scheme of
+big_vision_amd/trainers/proj/image_text/siglip.py when 4096/N > 2048, i.e. N = 1;
+single pass for N >= 2).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -42,7 +42,8 @@ IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 DOMINANT = (("bv_gemm_bf16", "bv_gemm_bf16_colsum"), 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
-DOMINANT_KERNEL = "gemm256_kernel<true>"
+PMC_PROFILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
+DOMINANT_KERNEL = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
 
 
 class GemmObserver:
@@ -82,9 +83,9 @@ class GemmObserver:
 
 def pmc_traffic(world, micro):
   """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
-  THIS command (profiles/r01_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
+  THIS command (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
   be read from inside the process).  None when the profile does not match the configuration."""
-  path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+  path = os.path.join(ROOT, "profiles", PMC_PROFILE)
   try:
     with open(path) as f:
       d = json.load(f)
@@ -158,6 +159,37 @@ def cpu_baseline(sample_pairs):
                     f"pairs, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
+def _free_port():
+  import socket
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    return sk.getsockname()[1]
+
+
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: re-run this command as N ranks (one process per
+  GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), exactly
+  what `python -m torch.distributed.run --nproc-per-node N bench.py ...` would start."""
+  import subprocess
+  if torch.cuda.is_available() and torch.cuda.device_count() < n:
+    raise RuntimeError(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
+  port = str(_free_port())
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+  rc = 0
+  for p in procs:
+    p.wait()
+    rc = rc or p.returncode
+  if rc:
+    for p in procs:
+      if p.poll() is None:
+        p.kill()
+    raise SystemExit(rc)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +201,9 @@ def main():
   ap.add_argument("--cpu-sample", type=int, default=16)
   ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
   args = ap.parse_args()
+
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    return spawn_ranks(args.gpus)   # plain `python bench.py --gpus N`: one process per GPU, started here
 
   from big_vision_amd import _lib, dp
   from big_vision_amd.models.proj.image_text import two_towers
@@ -197,11 +232,22 @@ def main():
   batch = {"image": image, "labels": text}
 
   obs = GemmObserver()
-  if not args.no_roofline:
-    _lib.observer = obs
   meas = None
   for _ in range(args.warmup):
     state, meas = update_fn(state, None, batch)
+  # Host cost of one step = wall time to ENQUEUE it on an idle GPU with an empty launch queue (the
+  # average over the timed steps below also contains the time the host spends blocked on a full
+  # queue while the GPU is the bottleneck, so it says nothing about host-boundness).  Untimed extra
+  # step, outside the timed region.
+  host_unblocked_ms = None
+  if args.warmup > 0:
+    comm.barrier()
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    state, meas = update_fn(state, None, batch)
+    host_unblocked_ms = 1e3 * (time.perf_counter() - h0)
+  if not args.no_roofline:
+    _lib.observer = obs
   comm.barrier()
   torch.cuda.synchronize()
   obs.active = True
@@ -238,7 +284,8 @@ def main():
                                "activation contexts in HBM)")
                               if n > args.microbatch else "none",
                  "parallelism": f"dp{world}", "final_loss": loss,
-                 "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps},
+                 "host_enqueue_ms_idle_gpu": host_unblocked_ms,
+                 "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * host_dt / args.steps},
   }
   if not args.no_roofline:
     launches, ms, flops, nbytes = obs.summary()

@@ -39,6 +39,9 @@ PROTOTYPES = {
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_fwd_masked": [P, P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_bwd_masked": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_impl": [c_int],
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_patchify": [P, P, c_int, c_int, c_int, c_int, P],

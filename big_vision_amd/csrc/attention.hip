@@ -521,14 +521,28 @@ int launch_bwd(const void* qkv, const void* d_o, const float* lse, const float* 
 int bv_attn2_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
 int bv_attn2_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dqkv, float* dbias, int n, int L, int H, void* stream);
+// attention3.hip: one query fragment per wave iteration, 8 waves, prefetched fragments, exact delta,
+// optional key-padding length per sample (the default fast path)
+int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream);
+int bv_attn3_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
+                 const int* kv_len, int n, int L, int H, void* stream);
 int bv_fast_path_enabled();
+static int g_attn_impl = 3;
+// diagnostics / A-B benchmarking: 3 = attention3.hip (default), 2 = attention2.hip.  impl < 0 only
+// queries; returns the old value.
+extern "C" int bv_attn_impl(int impl) {
+  const int old = g_attn_impl;
+  if (impl == 2 || impl == 3) g_attn_impl = impl;
+  return old;
+}
 extern "C" int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int cols, void* stream);
 
 extern "C" int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_fwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_fwd: L=%d > 576 not supported", L);
   BV_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)o % 16 == 0, "bv_attn_fwd: unaligned pointers");
-  if (bv_fast_path_enabled()) return bv_attn2_fwd(qkv, o, lse, n, L, H, stream);
+  if (bv_fast_path_enabled())
+    return g_attn_impl == 3 ? bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, stream) : bv_attn2_fwd(qkv, o, lse, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   if (L <= 64) return launch_fwd<4>(qkv, o, lse, n, L, H, s);
   if (L <= 224) return launch_fwd<14>(qkv, o, lse, n, L, H, s);
@@ -540,7 +554,9 @@ extern "C" int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            float* delta, void* dqkv, float* dbias_rows, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_bwd: L=%d > 576 not supported", L);
-  if (bv_fast_path_enabled()) return bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, dbias_rows, n, L, H, stream);
+  if (bv_fast_path_enabled())
+    return g_attn_impl == 3 ? bv_attn3_bwd(qkv, d_o, lse, delta, dqkv, dbias_rows, nullptr, n, L, H, stream)
+                            : bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, dbias_rows, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * L * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
@@ -558,6 +574,25 @@ extern "C" int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     rc = bv_colsum((const bf16*)dqkv + (long)i * L * 3 * H * 64, 0, 3L * H * 64, dbias_rows + (long)i * 3 * H * 64, L,
                    3 * H * 64, stream);
   return rc;
+}
+
+// Self-attention with a key-padding length per sample (kv_len[i] valid keys, 1 <= kv_len[i] <= L;
+// keys >= kv_len[i] get zero probability, their dK / dV rows are written as zeros; query rows are
+// all computed).  Replaces nn.MultiHeadDotProductAttention(mask=...) of the NaFlex tower
+// (models/proj/image_text/naflex_vit.py:84-293) for masks that are a valid PREFIX of the sequence
+// (NaFlex pads at the end).  kv_len = NULL: no mask.
+extern "C" int bv_attn_fwd_masked(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H,
+                                  void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_fwd_masked: bad shape n=%d L=%d H=%d", n, L, H);
+  BV_REQUIRE(L <= 576, "bv_attn_fwd_masked: L=%d > 576 not supported", L);
+  BV_REQUIRE((uintptr_t)qkv % 16 == 0 && (uintptr_t)o % 16 == 0, "bv_attn_fwd_masked: unaligned pointers");
+  return bv_attn3_fwd(qkv, o, lse, kv_len, n, L, H, stream);
+}
+extern "C" int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float* lse, const int* kv_len,
+                                  float* delta, void* dqkv, float* dbias_rows, int n, int L, int H, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd_masked: bad shape n=%d L=%d H=%d", n, L, H);
+  BV_REQUIRE(L <= 576, "bv_attn_bwd_masked: L=%d > 576 not supported", L);
+  return bv_attn3_bwd(qkv, d_o, lse, delta, dqkv, dbias_rows, kv_len, n, L, H, stream);
 }
 
 extern "C" int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int L, int H,

@@ -1,0 +1,485 @@
+// Fused self-attention forward / backward for gfx950, Dh = 64, L <= 576: third generation of the
+// LDS-resident kernels.  Same mathematics and reference call sites as attention2.hip
+// (flax nn.MultiHeadDotProductAttention inside big_vision/models/vit.py:93-98, text tower via
+// vit.Encoder, models/proj/image_text/text_transformer.py:72-75; backward = jax.value_and_grad,
+// trainers/proj/image_text/siglip.py:311):
+//   S = (q/sqrt(Dh)) k^T,  P = softmax_rows(S),  O = P v
+//   dV = P^T dO, dP = dO V^T, dS = P o (dP - delta), dQ = dS K/sqrt(Dh), dK = dS^T Q/sqrt(Dh)
+// plus an optional KEY-PADDING length per sample (kv_len[i] <= L: keys >= kv_len[i] are masked,
+// the NaFlex path, models/proj/image_text/naflex_vit.py:84-293 passes mask = valid patches).
+//
+// Why a third version.  attention2 (4 waves, 2 query fragments per iteration, 8 waves per CU) ran at
+// 3.1 TB/s and 12 % of the MFMA rate: neither roof.  rocprof + arithmetic: per workgroup ~6 k
+// cycles of staging and ~14 k cycles per query block, of which the MFMAs are 1.8 k - the rest is
+// exposed latency (the block's Q fragments are fetched from HBM after the previous block's stores,
+// every LDS fragment read is waited for by the only wave that could hide it).  The shape is
+// bandwidth/latency-bound (97 FLOP per HBM byte at L = 196), so the lever is memory-level
+// parallelism, not MFMA efficiency:
+//   * ONE query fragment per wave iteration: a third of the registers (the score row of a
+//     fragment is KF x 4 VGPRs), 8 waves per workgroup and 2 workgroups per CU -> 16 waves per CU
+//     hide each other's LDS / HBM latencies; each LDS fragment feeds 1 MFMA instead of 2, which
+//     the LDS affords (65 MB per CU and launch at 256 B/clk = 0.12 ms, the HBM floor is 0.42 ms);
+//   * the NEXT query fragment's global loads are issued before the current one is computed, the
+//     first one before the K/V staging;
+//   * key fragments = ceil(L/16) exactly (13 for 196/197 tokens, not 14): the odd last fragment
+//     of the P V / dS K / P^T dO contractions uses the K = 16 MFMA;
+//   * delta = rowsum(P o dP) is computed EXACTLY from the fp32 P and dP of the row (a second
+//     sweep over the keys recomputes them; MFMAs are free here) instead of rowsum(dO o O) with the
+//     bf16-rounded O: that shortcut costs the q/k gradients of nearly-uniform attention rows
+//     (random init, repeated tokens) a relative error of 5-10 % at small batch, where dP - delta
+//     cancels to a fraction of delta; the backward no longer reads O at all.
+// MFMA plan as attention2: S^T[key][q] = K Q^T and dP^T = V dO^T put P^T / dS^T straight into the
+// B-operand layout of O^T += V^T P^T and dQ^T += K^T dS^T; the key-owned pass computes S = Q K^T,
+// dP = dO V^T and accumulates dV^T += dO^T P, dK^T += Q^T dS.
+#include "attn_common.h"
+#include "bvhip_internal.h"
+
+namespace {
+using namespace bvattn;
+
+// hipcc pads the MFMA-result -> VALU-read hazard inside a basic block; across a taken branch right
+// behind the MFMA it was seen to pad nothing (see sdp below).  Wherever the last MFMAs of a loop
+// feed VALU code behind control flow, the wait states are spelled out.
+__device__ __forceinline__ void mfma_drain(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  // the operands pin the wait states BEHIND the MFMAs that produce them
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// ------------------------------------------------------------------ forward --
+template <int KF, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __restrict__ qkv,
+                                                                 bf16* __restrict__ o,
+                                                                 float* __restrict__ lse,
+                                                                 const int* __restrict__ kv_len, int L,
+                                                                 int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + KF * 16 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x / H, h = blockIdx.x % H;
+  const int Lk = kv_len ? min(kv_len[i], L) : L;
+  const long ld = 3L * H * DH;
+  const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
+  const bf16* kb_ = qb_ + (long)H * DH;
+  const bf16* vb_ = qb_ + 2L * H * DH;
+  int qf = wave;
+  bf16x8 q0 = gfrag(qb_, ld, qf * 16 + lr, L, lg * 8), q1 = gfrag(qb_, ld, qf * 16 + lr, L, 32 + lg * 8);
+  t64_stage2<KF * 16, NW * 64>(Kt, kb_, ld, Vt, vb_, ld, Lk, tid);
+  __syncthreads();
+  const float c = scale * LOG2E;
+
+  for (; qf * 16 < L; qf += NW) {
+    f32x4 s[KF];
+#pragma unroll
+    for (int f = 0; f < KF; ++f) {
+      const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg);
+      const bf16x8 k1 = t64_row(Kt, f * 16 + lr, 4 + lg);
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      a = mfma16(k0, q0, a);
+      a = mfma16(k1, q1, a);
+      s[f] = a;
+      if (KF > 13 || (f & 1)) __builtin_amdgcn_sched_barrier(0);   // bound load hoisting (register pressure)
+    }
+    // the NEXT fragment of this wave goes straight into the registers the scores no longer need
+    // (rows >= L load nothing); its latency hides behind the softmax and the P V products
+    const int qrow = qf * 16 + lr;
+    {
+      const int qn = (qf + NW) * 16 + lr;
+      q0 = gfrag(qb_, ld, qn, L, lg * 8);
+      q1 = gfrag(qb_, ld, qn, L, 32 + lg * 8);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < KF; ++f) {
+      if (f * 16 + 16 > Lk) {   // wave-uniform: fragment straddles / lies beyond the last valid key
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (f * 16 + lg * 4 + r >= Lk) s[f][r] = -INFINITY;
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+    }
+    mx = xmax4(mx);
+    const float mc = mx * c;
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < KF; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc));
+        s[f][r] = p;
+        sum += p;
+      }
+    sum = xsum4(sum);
+    const float inv = 1.0f / sum;
+    const float lsev = mx * scale + __logf(sum);
+    f32x4 oa[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) oa[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int fp = 0; fp < KF / 2; ++fp) {
+      const bf16x8 pf = pack8(s[2 * fp], s[2 * fp + 1]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 vf = t64_trpair(Vt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
+        oa[d] = mfma16(vf, pf, oa[d]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (KF & 1) {
+      const s16x4 pf = pack4(s[KF - 1]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) oa[d] = mfma16k16(t64_tr(Vt, (KF - 1) * 16 + 4 * lg, d, lr), pf, oa[d]);
+    }
+    mfma_drain(oa[0], oa[1], oa[2], oa[3]);
+    if (qrow < L) {
+      bf16* orow = o + ((long)i * L + qrow) * H * DH + h * DH;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint2 w;
+        w.x = pack_bf2(oa[d][0] * inv, oa[d][1] * inv);
+        w.y = pack_bf2(oa[d][2] * inv, oa[d][3] * inv);
+        *reinterpret_cast<uint2*>(orow + d * 16 + lg * 4) = w;
+      }
+      if (lg == 0) lse[((long)i * H + h) * L + qrow] = lsev;
+    }
+  }
+}
+
+// ------------------------------------------------------------- backward: dQ --
+template <int KF, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq_kernel(const bf16* __restrict__ qkv,
+                                                                    const bf16* __restrict__ d_o,
+                                                                    const float* __restrict__ lse,
+                                                                    float* __restrict__ delta,
+                                                                    bf16* __restrict__ dqkv,
+                                                                    float* __restrict__ dbias,
+                                                                    const int* __restrict__ kv_len, int L,
+                                                                    int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + KF * 16 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x / H, h = blockIdx.x % H;
+  const int Lk = kv_len ? min(kv_len[i], L) : L;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
+  const bf16* kb_ = qb_ + (long)H * DH;
+  const bf16* vb_ = qb_ + 2L * H * DH;
+  const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+  const float* lse_ = lse + ((long)i * H + h) * L;
+  float* red = reinterpret_cast<float*>(smem + 2 * KF * 16 * 128);   // [NW waves][64] column sums of dQ
+  int qf = wave;
+  bf16x8 q0 = gfrag(qb_, ld, qf * 16 + lr, L, lg * 8), q1 = gfrag(qb_, ld, qf * 16 + lr, L, 32 + lg * 8);
+  bf16x8 g0 = gfrag(dob_, ldo, qf * 16 + lr, L, lg * 8), g1 = gfrag(dob_, ldo, qf * 16 + lr, L, 32 + lg * 8);
+  float lse2 = qf * 16 + lr < L ? lse_[qf * 16 + lr] * LOG2E : INFINITY;
+  t64_stage2<KF * 16, NW * 64>(Kt, kb_, ld, Vt, vb_, ld, Lk, tid);
+  if (dbias && tid < NW * 64) red[tid] = 0.f;
+  __syncthreads();
+  const float c = scale * LOG2E;
+
+  // S^T and dP^T fragment f of the current query fragment; p = P^T, dp = dP^T (keys >= Lk: p = 0)
+  auto sdp = [&](int f, f32x4& p, f32x4& dp) {
+    const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg), k1 = t64_row(Kt, f * 16 + lr, 4 + lg);
+    const bf16x8 v0 = t64_row(Vt, f * 16 + lr, lg), v1 = t64_row(Vt, f * 16 + lr, 4 + lg);
+    f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+    dp = f32x4{0.f, 0.f, 0.f, 0.f};
+    st = mfma16(k0, q0, st);
+    st = mfma16(k1, q1, st);
+    dp = mfma16(v0, g0, dp);
+    dp = mfma16(v1, g1, dp);
+    // keys >= Lk: branch-free select.  (A wave-uniform `if (fragment straddles Lk)` around the mask put
+    // the consumers of dp - the delta FMAs - first in the block after a loop back-edge, straight
+    // behind the MFMA that writes dp in the predecessor block; hipcc (ROCm 7.2) emitted no wait
+    // states on that edge and the first two FMAs read stale registers: delta was wrong by 30 %.)
+    const int lim = Lk - f * 16 - lg * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, -lse2));
+      p[r] = r < lim ? e : 0.f;
+    }
+  };
+
+  for (; qf * 16 < L; qf += NW) {
+    const int qn = (qf + NW) * 16 + lr;
+    const bf16x8 nq0 = gfrag(qb_, ld, qn, L, lg * 8), nq1 = gfrag(qb_, ld, qn, L, 32 + lg * 8);
+    const bf16x8 ng0 = gfrag(dob_, ldo, qn, L, lg * 8), ng1 = gfrag(dob_, ldo, qn, L, 32 + lg * 8);
+    const float nlse = qn < L ? lse_[qn] * LOG2E : INFINITY;
+    // ---- sweep 1: delta = sum_keys P o dP of this query row (exact: fp32 P and dP)
+    float dacc = 0.f;
+#pragma unroll 1
+    for (int f = 0; f < KF; ++f) {
+      f32x4 p, dp;
+      sdp(f, p, dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dacc = __builtin_fmaf(p[r], dp[r], dacc);
+    }
+    const float del = xsum4(dacc);
+    const int qrow = qf * 16 + lr;
+    if (lg == 0 && qrow < L) delta[((long)i * H + h) * L + qrow] = del;
+    // ---- sweep 2: dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
+    f32x4 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int fp = 0; fp < KF / 2; ++fp) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4 p, dp;
+        sdp(2 * fp + e, p, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[e][r] = p[r] * (dp[r] - del);
+      }
+      const bf16x8 dsf = pack8(ds[0], ds[1]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 kt = t64_trpair(Kt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
+        dq[d] = mfma16(kt, dsf, dq[d]);
+      }
+    }
+    if constexpr (KF & 1) {
+      f32x4 p, dp, ds;
+      sdp(KF - 1, p, dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[r] = p[r] * (dp[r] - del);
+      const s16x4 dsf = pack4(ds);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dq[d] = mfma16k16(t64_tr(Kt, (KF - 1) * 16 + 4 * lg, d, lr), dsf, dq[d]);
+    }
+    mfma_drain(dq[0], dq[1], dq[2], dq[3]);
+    if (dbias) {
+      // column sums of this fragment (fp32, before the bf16 rounding; padded query rows are exactly
+      // 0: q = dO = 0, P = 0) into the wave's private LDS row
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = rowsum16(dq[d][r]);
+          if (lr == 0) red[wave * 64 + d * 16 + lg * 4 + r] += t * scale;
+        }
+    }
+    if (qrow < L) {
+      bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint2 w;
+        w.x = pack_bf2(dq[d][0] * scale, dq[d][1] * scale);
+        w.y = pack_bf2(dq[d][2] * scale, dq[d][3] * scale);
+        *reinterpret_cast<uint2*>(row + d * 16 + lg * 4) = w;
+      }
+    }
+    q0 = nq0; q1 = nq1; g0 = ng0; g1 = ng1; lse2 = nlse;
+  }
+  if (dbias) {   // per-(sample, head) column sums of dQ -> dbias[i][0][h][:]; the host sums over samples
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 64 + tid];
+      dbias[((long)i * 3 * H + h) * DH + tid] = t;
+    }
+  }
+}
+
+// --------------------------------------------------------- backward: dK, dV --
+// QN = number of 16-row query fragments = ceil(L/16); one key fragment per wave iteration.
+template <int QN, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+                                                                     const bf16* __restrict__ d_o,
+                                                                     const float* __restrict__ lse,
+                                                                     const float* __restrict__ delta,
+                                                                     bf16* __restrict__ dqkv,
+                                                                     float* __restrict__ dbias,
+                                                                     const int* __restrict__ kv_len, int L,
+                                                                     int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Gt = smem + QN * 16 * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * QN * 16 * 128);
+  float* del_s = lse_s + QN * 16;
+  float* red = del_s + QN * 16;   // [NW waves][2][64] column sums of dK / dV
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x / H, h = blockIdx.x % H;
+  const int Lk = kv_len ? min(kv_len[i], L) : L;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
+  const bf16* kb_ = qb_ + (long)H * DH;
+  const bf16* vb_ = qb_ + 2L * H * DH;
+  const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+  int kf = wave;
+  bf16x8 k0 = gfrag(kb_, ld, kf * 16 + lr, Lk, lg * 8), k1 = gfrag(kb_, ld, kf * 16 + lr, Lk, 32 + lg * 8);
+  bf16x8 v0 = gfrag(vb_, ld, kf * 16 + lr, Lk, lg * 8), v1 = gfrag(vb_, ld, kf * 16 + lr, Lk, 32 + lg * 8);
+  t64_stage2<QN * 16, NW * 64>(Qt, qb_, ld, Gt, dob_, ldo, L, tid);
+  for (int idx = tid; idx < QN * 16; idx += NW * 64) {
+    // rows >= L: lse = +inf makes P = exp2(-inf) = 0 without an explicit mask
+    lse_s[idx] = idx < L ? lse[((long)i * H + h) * L + idx] * LOG2E : INFINITY;
+    del_s[idx] = idx < L ? delta[((long)i * H + h) * L + idx] : 0.f;
+  }
+  if (dbias)
+    for (int idx = tid; idx < NW * 128; idx += NW * 64) red[idx] = 0.f;
+  __syncthreads();
+  const float c = scale * LOG2E;
+
+  // S and dP of query fragment f against this wave's key fragment: p = P[q][key], ds = dS[q][key]
+  auto pds = [&](int f, f32x4& p, f32x4& ds) {
+    const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
+    const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
+    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + f * 16 + lg * 4);
+    const float4 d4 = *reinterpret_cast<const float4*>(del_s + f * 16 + lg * 4);
+    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+    s = mfma16(q0, k0, s);     // D[q = 4lg+r][key = lr]
+    s = mfma16(q1, k1, s);
+    dp = mfma16(g0, v0, dp);   // dP[q][key] = sum_d dO[q][d] V[key][d]
+    dp = mfma16(g1, v1, dp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -lv[r]));
+      ds[r] = p[r] * (dp[r] - dl[r]);
+    }
+  };
+
+  for (; kf * 16 < L; kf += NW) {
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int ip = 0; ip < QN / 2; ++ip) {
+      f32x4 pp[2], ds[2];
+      pds(2 * ip, pp[0], ds[0]);
+      __builtin_amdgcn_sched_barrier(0);   // one fragment's operand reads at a time (register pressure)
+      pds(2 * ip + 1, pp[1], ds[1]);
+      const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 gt = t64_trpair(Gt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
+        const bf16x8 qt = t64_trpair(Qt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
+        dv[d] = mfma16(gt, pf, dv[d]);    // D[d = 4lg+r][key = lr]
+        dk[d] = mfma16(qt, dsf, dk[d]);
+      }
+    }
+    if constexpr (QN & 1) {
+      f32x4 pp, ds;
+      pds(QN - 1, pp, ds);
+      const s16x4 pf = pack4(pp), dsf = pack4(ds);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dv[d] = mfma16k16(t64_tr(Gt, (QN - 1) * 16 + 4 * lg, d, lr), pf, dv[d]);
+        dk[d] = mfma16k16(t64_tr(Qt, (QN - 1) * 16 + 4 * lg, d, lr), dsf, dk[d]);
+      }
+    }
+    mfma_drain(dk[0], dk[1], dk[2], dk[3]);
+    mfma_drain(dv[0], dv[1], dv[2], dv[3]);
+    const int krow = kf * 16 + lr;
+    {
+      // the wave's NEXT key fragment goes straight into the registers of the finished one (rows >= Lk
+      // load nothing); the stores and the column sums below cover part of its latency
+      const int kn = (kf + NW) * 16 + lr;
+      k0 = gfrag(kb_, ld, kn, Lk, lg * 8); k1 = gfrag(kb_, ld, kn, Lk, 32 + lg * 8);
+      v0 = gfrag(vb_, ld, kn, Lk, lg * 8); v1 = gfrag(vb_, ld, kn, Lk, 32 + lg * 8);
+    }
+    // key rows >= Lk (masked or padded): k = v = 0 there, so S = 0 and P = exp2(-lse) != 0 - their
+    // columns are garbage and are replaced by zeros (rows < L must still be written: the dX GEMM
+    // reads every row of dqkv)
+    const bool live = krow < Lk;
+    if (krow < L) {
+      bf16* rowk = dqkv + ((long)i * L + krow) * ld + (long)H * DH + h * DH;
+      bf16* rowv = rowk + (long)H * DH;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint2 a, b;
+        a.x = live ? pack_bf2(dk[d][0] * scale, dk[d][1] * scale) : 0u;
+        a.y = live ? pack_bf2(dk[d][2] * scale, dk[d][3] * scale) : 0u;
+        *reinterpret_cast<uint2*>(rowk + d * 16 + lg * 4) = a;
+        b.x = live ? pack_bf2(dv[d][0], dv[d][1]) : 0u;
+        b.y = live ? pack_bf2(dv[d][2], dv[d][3]) : 0u;
+        *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
+      }
+    }
+    if (dbias) {
+      // column sums over this fragment's live keys (fp32, before the bf16 rounding), wave-private LDS row
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float tk = rowsum16(live ? dk[d][r] : 0.f), tv = rowsum16(live ? dv[d][r] : 0.f);
+          if (lr == 0) {
+            red[wave * 128 + d * 16 + lg * 4 + r] += tk * scale;
+            red[wave * 128 + 64 + d * 16 + lg * 4 + r] += tv;
+          }
+        }
+    }
+  }
+  if (dbias) {   // dbias[i][1][h][:] (key) and dbias[i][2][h][:] (value)
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, d = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 128 + tid];
+      dbias[((long)i * 3 * H + (long)(1 + which) * H + h) * DH + d] = t;
+    }
+  }
+}
+
+template <typename K>
+void set_lds(K kernel, size_t bytes) {
+  if (bytes > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <int KF, int NW, int WPS>
+int launch_fwd3(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, hipStream_t s) {
+  const size_t sh = (size_t)KF * 4096;
+  set_lds(attn3_fwd_kernel<KF, NW, WPS>, sh);
+  hipLaunchKernelGGL((attn3_fwd_kernel<KF, NW, WPS>), dim3(n * H), dim3(NW * 64), sh, s, (const bf16*)qkv,
+                     (bf16*)o, lse, kv_len, L, H, 0.125f);
+  return bv_check_launch("bv_attn_fwd");
+}
+template <int KF, int NW, int WPS, int WPS2>
+int launch_bwd3(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
+                const int* kv_len, int n, int L, int H, hipStream_t s) {
+  const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
+  set_lds(attn3_bwd_dq_kernel<KF, NW, WPS>, sh1);
+  hipLaunchKernelGGL((attn3_bwd_dq_kernel<KF, NW, WPS>), dim3(n * H), dim3(NW * 64), sh1, s, (const bf16*)qkv,
+                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+  int rc = bv_check_launch("bv_attn_bwd(dq)");
+  if (rc) return rc;
+  const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)NW * 128 * 4;
+  set_lds(attn3_bwd_dkv_kernel<KF, NW, WPS2>, sh2);
+  hipLaunchKernelGGL((attn3_bwd_dkv_kernel<KF, NW, WPS2>), dim3(n * H), dim3(NW * 64), sh2, s, (const bf16*)qkv,
+                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+  return bv_check_launch("bv_attn_bwd(dkv)");
+}
+
+}  // namespace
+
+// Entry points used by bv_attn_fwd / bv_attn_bwd (attention.hip).  Key fragments = ceil(L/16) for
+// the common sequence lengths (64 text tokens; 196/197 at 224 px; 256/257; 441 at 336 px; 576 at
+// 384 px), the next instantiated size otherwise.
+int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 64) return launch_fwd3<4, 4, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 448) return launch_fwd3<28, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
+  return launch_fwd3<36, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
+}
+
+int bv_attn3_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
+                 const int* kv_len, int n, int L, int H, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  return launch_bwd3<36, 8, 2, 2>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+}

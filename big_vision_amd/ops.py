@@ -126,16 +126,22 @@ def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_b
 
 
 # --------------------------------------------------------------- Attention --
-def attn_fwd(qkv, n, L, H):
+def attn_fwd(qkv, n, L, H, kv_len=None):
+  """kv_len (int32 [n], optional): valid keys per sample (key-padding mask of the NaFlex tower)."""
   _chk(qkv, BF16, "attn.qkv")
   assert qkv.is_contiguous() and qkv.numel() == n * L * 3 * H * 64, qkv.shape
   o = torch.empty((n * L, H * 64), device=qkv.device, dtype=BF16)
   lse = torch.empty((n, H, L), device=qkv.device, dtype=F32)
-  _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream())
+  if kv_len is not None:
+    _chk(kv_len, torch.int32, "attn.kv_len")
+    assert kv_len.is_contiguous() and kv_len.numel() == n
+    _lib.call("bv_attn_fwd_masked", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, _stream())
+  else:
+    _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream())
   return o, lse
 
 
-def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None):
+def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None, kv_len=None):
   """dbias (fp32, 3*H*64 elements): += column sums of dqkv (the q/k/v bias gradients)."""
   _chk(qkv, BF16, "attn.qkv"); _chk(o, BF16, "attn.o"); _chk(d_o, BF16, "attn.do")
   assert d_o.is_contiguous() and o.is_contiguous()
@@ -146,8 +152,13 @@ def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None):
     assert dbias.is_contiguous() and dbias.numel() == 3 * H * 64
   delta = torch.empty((n, H, L), device=qkv.device, dtype=F32)
   rows = torch.empty((n, 3 * H * 64), device=qkv.device, dtype=F32) if dbias is not None else None
-  _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(rows), n, L, H,
-            _stream())
+  if kv_len is not None:
+    _chk(kv_len, torch.int32, "attn.kv_len")
+    _lib.call("bv_attn_bwd_masked", _p(qkv), _p(d_o), _p(lse), _p(kv_len), _p(delta), _p(dqkv), _p(rows),
+              n, L, H, _stream())
+  else:
+    _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(rows), n, L, H,
+              _stream())
   if dbias is not None:
     colsum(rows, dbias)   # per-sample sums (written by the kernels) -> bias gradient
   return dqkv

@@ -159,6 +159,22 @@ int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void*
 int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                 void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
 
+/* The same with a key-padding length per sample: keys >= kv_len[i] (1 <= kv_len[i] <= L, int32
+ * device array, NULL = no mask) get zero probability and zero dK / dV rows; all L query rows are
+ * computed.  Replaces nn.MultiHeadDotProductAttention(mask=...) of the NaFlex tower
+ * (models/proj/image_text/naflex_vit.py:84-293: the mask marks the valid patches, padding sits
+ * at the end of the sequence).  The backward computes delta = rowsum(P o dP) itself (fp32) and
+ * does not read o. */
+int bv_attn_fwd_masked(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H,
+                       void* stream);
+int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float* lse, const int* kv_len, float* delta,
+                       void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
+/* Diagnostics / A-B benchmarking: which LDS-resident implementation bv_attn_fwd/bwd use on the
+ * fast path - 3 = attention3.hip (default: one query fragment per wave, 16 waves per CU,
+ * prefetched fragments, exact delta), 2 = attention2.hip.  impl < 0 only queries; returns the
+ * old value. */
+int bv_attn_impl(int impl);
+
 /* Single-query attention of the MAP head (models/vit.py:176-178): q [n][H][64]
  * bf16, kv packed [n*L][2][H][64] bf16 -> o [n][H][64] bf16, probabilities p
  * [n][H][L] fp32 (saved for the backward). */

@@ -10,13 +10,39 @@ import bench  # noqa: E402
 
 
 def test_pmc_traffic_is_tied_to_its_configuration():
+  path = os.path.join(ROOT, "profiles", bench.PMC_PROFILE)
   t, src = bench.pmc_traffic(1, bench.MICRO)
-  with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+  if not os.path.exists(path):          # counters not collected for this round's kernels yet: no number
+    assert (t, src) == (None, None)
+    return
+  with open(path) as f:
     d = json.load(f)
   assert d["microbatch"] == bench.MICRO and d["n_gpus"] == 1
-  assert src == "profiles/r01_pmc_traffic.json" and t == d["kernels"][bench.DOMINANT_KERNEL]["hbm_bytes"]
+  assert src == "profiles/" + bench.PMC_PROFILE and t == d["kernels"][bench.DOMINANT_KERNEL]["hbm_bytes"]
   assert bench.pmc_traffic(8, bench.MICRO) == (None, None)        # other world size: no number
   assert bench.pmc_traffic(1, bench.MICRO // 2) == (None, None)   # other micro-batch: no number
+
+
+def test_plain_multi_gpu_invocation_spawns_its_own_ranks(monkeypatch):
+  """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) must start N ranks itself."""
+  import subprocess
+  started = []
+
+  class P:
+    returncode = 0
+    def __init__(self, cmd, env): started.append((cmd, env))
+    def wait(self): return 0
+    def poll(self): return 0
+  monkeypatch.setattr(subprocess, "Popen", lambda cmd, env=None: P(cmd, env))
+  monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: False)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  bench.main()
+  assert len(started) == 4
+  ranks = sorted(int(e["RANK"]) for _, e in started)
+  assert ranks == [0, 1, 2, 3] and all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" for _, e in started)
+  assert len({e["MASTER_PORT"] for _, e in started}) == 1 and all(e["LOCAL_RANK"] == e["RANK"] for _, e in started)
+  assert all(c[-4:] == ["--gpus", "4", "--steps", "2"] for c, _ in started)
 
 
 def test_observer_filters_and_counts_bytes():

@@ -11,6 +11,10 @@ in-run calibration point and is printed with its expected byte count).
 import csv, json, re, sys, collections
 
 
+# the k-major GEMM family bench.py reports as its dominant kernel (same string as bench.DOMINANT_KERNEL)
+FAMILY = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
+
+
 def short(n):
   n = re.sub(r"\(anonymous namespace\)::", "", n)
   n = re.sub(r"^void ", "", n)
@@ -51,8 +55,8 @@ def main():
     wr = wt.get(k, 0.0) * 1024 / max(1, wc.get(k, 0))
     out["kernels"][k] = {"launches": n, "read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr,
                          "avg_us_under_pmc": fd[k] / n / 1e3}
-    if k.startswith("gemm256_kernel<true"):
-      f = fam["gemm256_kernel<true>"]
+    if k.startswith("gemm256_kernel<true") or k.startswith("gemm256r_kernel"):
+      f = fam[FAMILY]
       f[0] += n; f[1] += ft[k] * 1024 * 2; f[2] += wt.get(k, 0.0) * 1024; f[3] += fd[k]
   for k, (n, rd, wr, d) in fam.items():
     out["kernels"][k] = {"launches": n, "read_bytes": rd / n, "write_bytes": wr / n, "hbm_bytes": (rd + wr) / n,
