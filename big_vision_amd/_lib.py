@@ -57,6 +57,8 @@ PROTOTYPES = {
     "bv_l2norm_fwd": [P, P, P, c_int, c_int, c_float, P],
     "bv_l2norm_bwd": [P, P, P, P, c_int, c_int, c_float, P],
     "bv_siglip_loss": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_logit_stats": [P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_dot_f32": [P, P, c_long, P, P],
     "bv_softmax_xent": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_sigmoid_xent": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_tanh_fwd": [P, P, c_long, P],

@@ -54,6 +54,82 @@ __global__ __launch_bounds__(256) void siglip_loss_kernel(float* __restrict__ ra
   }
 }
 
+// ------------------------------------------------------------- logit stats --
+// The per-device logit statistics the pmap trainer logs next to the sigmoid loss
+// (trainers/proj/image_text/_deprecated_contrastive.py:143-160): logits = t raw + b of this rank's
+// n images against all B texts; "me" = the n x n block of this rank's own texts (columns
+// row_offset .. row_offset + n), whose diagonal holds the positives.
+//   part[block][0..5] = min / max of {positives, local negatives, all negatives}
+//   part[block][6..8] = sums of the same three sets
+// logit_stats_finish reduces the partials to out[9] = {pos_min, pos_max, pos_avg, local_neg_min,
+// local_neg_max, local_neg_avg, neg_min, neg_max, neg_avg}.
+__device__ __forceinline__ float block_red_256(float v, float* sh, int op) {   // op 0 min, 1 max, 2 sum
+  v = op == 0 ? -wave_max(-v) : (op == 1 ? wave_max(v) : wave_sum(v));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  if (op == 0) return fminf(fminf(sh[0], sh[1]), fminf(sh[2], sh[3]));
+  if (op == 1) return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void logit_stats_kernel(const float* __restrict__ raw,
+                                                          const float* __restrict__ t_param,
+                                                          const float* __restrict__ b_param,
+                                                          float* __restrict__ part, int n, int B,
+                                                          int row_offset) {
+  __shared__ float sh[4];
+  const float t = __expf(t_param[0]);
+  const float b = b_param ? b_param[0] : 0.f;
+  const long total = (long)n * B;
+  float v[9] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / B);
+    const int col = (int)(i - (long)row * B) - row_offset;
+    const float s = t * raw[i] + b;
+    if (col == row) {
+      v[0] = fminf(v[0], s); v[1] = fmaxf(v[1], s); v[6] += s;
+    } else {
+      if (col >= 0 && col < n) { v[2] = fminf(v[2], s); v[3] = fmaxf(v[3], s); v[7] += s; }
+      v[4] = fminf(v[4], s); v[5] = fmaxf(v[5], s); v[8] += s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float r = block_red_256(v[k], sh, k >= 6 ? 2 : (k & 1));
+    if (threadIdx.x == 0) part[blockIdx.x * 9 + k] = r;
+  }
+}
+__global__ __launch_bounds__(64) void logit_stats_finish(const float* __restrict__ part, int nblocks,
+                                                         float* __restrict__ out, int n, int B) {
+  const int k = threadIdx.x;
+  if (k >= 9) return;
+  const int src = k < 2 ? k : (k == 2 ? 6 : (k < 5 ? k - 1 : (k == 5 ? 7 : (k < 8 ? k - 2 : 8))));
+  // out order {pos_min, pos_max, pos_avg, lneg_min, lneg_max, lneg_avg, neg_min, neg_max, neg_avg}
+  const bool is_avg = k == 2 || k == 5 || k == 8;
+  const bool is_min = !is_avg && (src & 1) == 0;
+  double acc = is_avg ? 0.0 : (is_min ? INFINITY : -INFINITY);
+  for (int j = 0; j < nblocks; ++j) {
+    const double p = part[j * 9 + src];
+    acc = is_avg ? acc + p : (is_min ? fmin(acc, p) : fmax(acc, p));
+  }
+  if (is_avg) {
+    const double cnt = k == 2 ? (double)n : (k == 5 ? (double)n * n - n : (double)n * B - n);
+    acc = cnt > 0 ? acc / cnt : 0.0;
+  }
+  out[k] = (float)acc;
+}
+
+// out[0] += sum_i a[i] b[i] (double accumulator): dL/dt' of the softmax contrastive loss
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  long count, double* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) acc += a[i] * b[i];
+  const float r = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, (double)r);
+}
+
 // ------------------------------------------------------------ softmax xent --
 // utils.py:276-281; one workgroup per row.
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* __restrict__ logits,
@@ -296,6 +372,27 @@ extern "C" int bv_siglip_loss(float* raw, const float* t_param, const float* b_p
   hipLaunchKernelGGL(siglip_loss_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, raw, t_param,
                      b_param, stats, n, B, row_offset, 1.0f / (float)B_global);
   return bv_check_launch("bv_siglip_loss");
+}
+
+extern "C" int bv_logit_stats(const float* raw, const float* t_param, const float* b_param, float* part,
+                              float* out9, int n, int B, int row_offset, void* stream) {
+  BV_REQUIRE(n > 0 && B >= n, "bv_logit_stats: bad shape n=%d B=%d", n, B);
+  BV_REQUIRE(row_offset >= 0 && row_offset + n <= B, "bv_logit_stats: diagonal [%d,%d) outside B=%d", row_offset, row_offset + n, B);
+  long g = ((long)n * B + 1023) / 1024;
+  if (g > BV_LOGIT_STATS_BLOCKS) g = BV_LOGIT_STATS_BLOCKS;
+  hipLaunchKernelGGL(logit_stats_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, raw, t_param, b_param,
+                     part, n, B, row_offset);
+  hipLaunchKernelGGL(logit_stats_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)part, (int)g,
+                     out9, n, B);
+  return bv_check_launch("bv_logit_stats");
+}
+
+extern "C" int bv_dot_f32(const float* a, const float* b, long count, double* out, void* stream) {
+  BV_REQUIRE(count > 0, "bv_dot_f32: empty input");
+  long g = (count + 1023) / 1024;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(dot_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a, b, count, out);
+  return bv_check_launch("bv_dot_f32");
 }
 
 extern "C" int bv_softmax_xent(const float* logits, const float* labels, double* loss_sum,

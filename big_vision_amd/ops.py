@@ -287,6 +287,31 @@ def siglip_loss_(raw, t_param, b_param, stats, row_offset, B_global):
             B_global, _stream())
 
 
+LOGIT_STATS_NAMES = ("pos_min_logit", "pos_max_logit", "pos_avg_logit", "local_neg_min_logit",
+                     "local_neg_max_logit", "local_neg_avg_logit", "neg_min_logit", "neg_max_logit",
+                     "neg_avg_logit")
+
+
+def logit_stats(raw, t_param, b_param, row_offset):
+  """fp32[9] logit statistics of logits = exp(t') raw + b (order LOGIT_STATS_NAMES); raw [n, B] as
+  handed to siglip_loss_ (call this BEFORE it: the loss kernel overwrites raw)."""
+  _chk(raw, F32, "logit_stats.raw")
+  assert raw.is_contiguous()
+  n, B = raw.shape
+  part = torch.empty((512 * 9,), device=raw.device, dtype=F32)
+  out = torch.empty((9,), device=raw.device, dtype=F32)
+  _lib.call("bv_logit_stats", _p(raw), _p(t_param), _p(b_param), _p(part), _p(out), n, B, row_offset, _stream())
+  return out
+
+
+def dot_(a, b, out):
+  """out (f64[1]) += sum(a * b)."""
+  _chk(a, F32, "dot.a"); _chk(b, F32, "dot.b")
+  assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and out.dtype == torch.float64
+  _lib.call("bv_dot_f32", _p(a), _p(b), a.numel(), _p(out), _stream())
+  return out
+
+
 def softmax_xent(logits, labels, loss_sum, want_grad=True, n_global=None, name="bv_softmax_xent"):
   """loss_sum (f64[1]) += mean-over-n_global softmax cross-entropy; returns dlogits (or None)."""
   _chk(logits, F32, "xent.logits"); _chk(labels, F32, "xent.labels")

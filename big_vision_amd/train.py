@@ -71,6 +71,8 @@ def make_train_state(model, config, image_shape, *, rng=0, comm=None, total_step
   store.init_random(_seed_of(rng))
   store.refresh_shadow()
   store.want_grads = True
+  from big_vision_amd import sharding     # train.py:201-203: replicated, anything else is refused
+  sharding.check_config(config, store.tree(), mesh=comm)
   batch_size = config.get("input", {}).get("batch_size", image_shape[0] * comm.size)
   total_steps = total_steps if total_steps is not None else u.steps("total", config, None, batch_size)
   opt, sched_fns = bv_optax.make(config, store, sched_kw=dict(total_steps=total_steps, batch_size=batch_size,

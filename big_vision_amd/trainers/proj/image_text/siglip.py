@@ -70,6 +70,9 @@ def make_train_state(model, config, image_shape, text_shape, *, rng=0, comm=None
   store.init_random(_seed_of(rng))
   store.refresh_shadow()
   store.want_grads = True
+  # parameter placement (siglip.py:196, 232-237): replicated; any other strategy is refused, not ignored
+  from big_vision_amd import sharding
+  sharding.check_config(config, store.tree(), mesh=comm)
   batch_size = config.get("input", {}).get("batch_size", image_shape[0] * comm.size)
   total_steps = total_steps if total_steps is not None else u.steps(
       "total", config, None, batch_size)
@@ -78,9 +81,16 @@ def make_train_state(model, config, image_shape, text_shape, *, rng=0, comm=None
   return {"params": store.tree(), "opt": opt}, sched_fns
 
 
-def make_update_fn(model, config, comm=None):
-  """Builds `update_fn(train_state, rng, batch)` (siglip.py:271-323)."""
+def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
+  """Builds `update_fn(train_state, rng, batch)` (siglip.py:271-323).
+
+  loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm) -> (stats f64[3], dzimg, dztxt[, extras]): the
+  loss on the local embeddings and its gradients (default: the sigmoid loss of this trainer);
+  measure(extras, norms, t_param) -> dict of additional measurements, norms = list of
+  (img_norm, txt_norm) per micro-batch.  Both hooks exist for trainers.proj.image_text.contrastive
+  (config.loss_fn switch + the pmap trainer's measurement dict)."""
   comm = comm or dp.Comm()
+  loss_fwd_bwd = loss_fwd_bwd or sigmoid_loss_fwd_bwd
   assert "mixup" not in config, "Mixup is not supported for SigLIP."
   micro = int(config.get("microbatch", 0) or 0)
   state_cache = {"keep_n": 0, "light": None, "per_ctx": {}}
@@ -129,13 +139,14 @@ def make_update_fn(model, config, comm=None):
 
       if state_cache["light"] is None:
         state_cache["light"] = bool(light_cfg) if light_cfg != "auto" else None
-      zi, zt, kept = [], [], {}
+      zi, zt, kept, norms = [], [], {}, []
       for k, s in enumerate(starts):
         mode = "light" if state_cache["light"] else True
         per_ctx = state_cache["per_ctx"].get(mode)
         keep = len(kept) < keep_max and (per_ctx is None or keep_cfg == "all" or fits(per_ctx, 1))
         before = torch.cuda.memory_allocated(dev)
-        a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=(mode if keep else False))
+        a, b, o_, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=(mode if keep else False))
+        norms.append((o_.get("img/norm"), o_.get("txt/norm")))
         if keep and per_ctx is None:
           per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
           if state_cache["light"] is None:
@@ -153,7 +164,7 @@ def make_update_fn(model, config, comm=None):
         zi.append(a); zt.append(b)
       state_cache["keep_n"] = len(kept)
       zimg, ztxt = torch.cat(zi), torch.cat(zt)
-      stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
+      stats, dzimg, dztxt, *lx = loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
       # Pass 2: back-propagate every micro-batch's slice of the embedding gradients (grads
       # accumulate in the flat buffer); recompute the forward where it was not kept (those are
       # the LAST micro-batches: by then the kept contexts have been consumed and freed).
@@ -167,8 +178,9 @@ def make_update_fn(model, config, comm=None):
                sync=(sync if s == starts[-1] else None))   # gradients are final in the LAST backward only
         del ctx
     else:
-      zimg, ztxt, _, ctx = ex.fwd(images, labels, save=True)
-      stats, dzimg, dztxt = sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
+      zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=True)
+      norms = [(o_.get("img/norm"), o_.get("txt/norm"))]
+      stats, dzimg, dztxt, *lx = loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
       ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt, sync=sync)
 
     # dL/dt', dL/db (scalars computed by the loss kernel) into the flat grad buffer.
@@ -187,6 +199,8 @@ def make_update_fn(model, config, comm=None):
     comm.all_reduce_scalars_(loss)
 
     measurements = {"training_loss": loss[0]}
+    if measure is not None:
+      measurements.update(measure(lx[0] if lx else {}, norms, t_param))
     measurements.update(opt.step())
     return {"params": params, "opt": opt}, measurements
 
@@ -213,5 +227,7 @@ def check_finite(measurements):
 
 def get_model(config):
   """Model registry by module path (siglip.py:190-191)."""
+  # the reference spells it big_vision.models.<name>; the `big_vision` package of this repo maps that
+  # to the same module object
   model_mod = importlib.import_module(f"big_vision_amd.models.{config.model_name}")
   return model_mod, model_mod.Model(**config.get("model", {}))

@@ -236,6 +236,19 @@ int bv_l2norm_bwd(const float* z, const float* norm, const float* dzn, float* dz
 int bv_siglip_loss(float* raw, const float* t_param, const float* b_param, double* stats, int n,
                    int B, int row_offset, int B_global, void* stream);
 
+/* Logit statistics the pmap contrastive trainer logs with the sigmoid loss
+ * (trainers/proj/image_text/_deprecated_contrastive.py:143-160): for logits = exp(t') raw + b of this
+ * rank's n images against all B texts (raw as passed to bv_siglip_loss, BEFORE it is overwritten),
+ * out9 = {pos_min, pos_max, pos_avg, local_neg_min, local_neg_max, local_neg_avg, neg_min, neg_max,
+ * neg_avg}; "local" = the n x n block of this rank's own texts (columns row_offset ..).  part is
+ * scratch of BV_LOGIT_STATS_BLOCKS * 9 floats. */
+#define BV_LOGIT_STATS_BLOCKS 512
+int bv_logit_stats(const float* raw, const float* t_param, const float* b_param, float* part, float* out9,
+                   int n, int B, int row_offset, void* stream);
+/* out[0] += sum_i a[i] b[i] (fp64 accumulator): dL/dt' = sum G o logits of the softmax contrastive
+ * loss (_deprecated_contrastive.py:80-101). */
+int bv_dot_f32(const float* a, const float* b, long count, double* out, void* stream);
+
 /* Classification losses of big_vision/train.py:295-300 (BASELINE config 1), soft labels
  * [n, C] fp32.  n = rows of this call, n_global = rows of the whole (data-parallel) batch: the
  * mean is over n_global, so per-rank results are partial sums (all-reduce SUM).

@@ -362,6 +362,36 @@ def sigmoid_loss_per_device(zimg_r, ztxt_shards, r, t, b=0.0):
   return l
 
 
+def sigmoid_logit_stats_per_device(zimg_r, ztxt_shards, r, t, b=0.0):
+  """The measurement dict of _deprecated_contrastive.py:143-160 on "device" r (before the pmean)."""
+  N = len(ztxt_shards)
+  logits_me = zimg_r @ ztxt_shards[r].T * t + b
+  others = [ztxt_shards[(r + k) % N] for k in range(1, N)]
+  logits_ot = zimg_r @ torch.cat(others, 0).T * t + b if others else logits_me.new_zeros((logits_me.shape[0], 0))
+  n = logits_me.shape[0]
+  eye = torch.eye(n, dtype=logits_me.dtype)
+  diag = torch.diagonal(logits_me)
+
+  def avg_neg(x_me, x_ot=None):      # :104-111
+    nom = x_me.sum() - torch.diagonal(x_me).sum()
+    den = x_me.numel() - len(x_me)
+    if x_ot is not None and x_ot.numel():
+      nom = nom + x_ot.sum()
+      den += x_ot.numel()
+    return nom / den
+
+  inf = torch.tensor(float("inf"), dtype=logits_me.dtype)
+  return {
+      "pos_min_logit": diag.min(), "pos_max_logit": diag.max(), "pos_avg_logit": diag.mean(),
+      "local_neg_min_logit": (logits_me + 1e9 * eye).min(),
+      "local_neg_max_logit": (logits_me - 1e9 * eye).max(),
+      "local_neg_avg_logit": avg_neg(logits_me),
+      "neg_min_logit": torch.minimum((logits_me + 1e9 * eye).min(), logits_ot.min() if logits_ot.numel() else inf),
+      "neg_max_logit": torch.maximum((logits_me - 1e9 * eye).max(), logits_ot.max() if logits_ot.numel() else -inf),
+      "neg_avg_logit": avg_neg(logits_me, logits_ot),
+  }
+
+
 def chunked_sigmoid_loss_per_device(zimg_r, ztxt_shards, r, t, b=0.0):
   """_deprecated_contrastive.py:168-200 (one broadcast per other device)."""
   logits_me = zimg_r @ ztxt_shards[r].T * t + b

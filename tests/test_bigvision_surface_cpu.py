@@ -1,0 +1,126 @@
+"""The reference's import surface (`big_vision.*`) served by this repo: module paths a
+big_vision trainer uses verbatim - importlib.import_module(f"big_vision.models.{config.model_name}")
+(trainers/proj/image_text/siglip.py:190-191), big_vision.optax / utils / sharding, the historical
+names of BASELINE.json (trainers.proj.image_text.contrastive, configs.proj.image_text.lit_coco) -
+must resolve to the accelerated implementation; names outside the hot path must fail loudly.
+CPU only: kernels are replaced by a recorder (dry run), so this checks plumbing, not numbers."""
+import collections
+import importlib
+
+import pytest
+import torch
+
+
+@pytest.fixture()
+def dry(monkeypatch):
+  from big_vision_amd import _lib, ops
+  calls = collections.Counter()
+  monkeypatch.setattr(_lib, "call", lambda name, *a: calls.update([name]))
+  monkeypatch.setattr(ops, "_chk", lambda t, dtype, name: t)
+  monkeypatch.setattr(ops, "_stream", lambda: 0)
+  monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (1 << 40, 1 << 40))
+  monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a: 0)
+  monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a: 0)
+  return calls
+
+
+def test_module_paths_are_the_same_modules():
+  import big_vision_amd.models.vit as vit_amd
+  assert importlib.import_module("big_vision.models.vit") is vit_amd
+  from big_vision.models.proj.image_text import two_towers, text_transformer   # noqa: F401
+  import big_vision.optax as bv_optax
+  import big_vision.utils as u
+  import big_vision.sharding as sh
+  import big_vision.train as train
+  from big_vision.trainers.proj.image_text import siglip, contrastive, _deprecated_contrastive
+  from big_vision.evaluators.proj.image_text import retrieval            # noqa: F401
+  assert contrastive.loss_fn is _deprecated_contrastive.loss_fn
+  assert callable(bv_optax.make) and callable(u.steps) and callable(sh.infer_sharding) and callable(train.make_update_fn)
+  assert callable(siglip.make_update_fn)
+  with pytest.raises(ModuleNotFoundError, match="outside the accelerated hot path"):
+    importlib.import_module("big_vision.input_pipeline")
+  with pytest.raises(ModuleNotFoundError):
+    importlib.import_module("big_vision.models.bit")
+
+
+def test_lit_coco_config_under_both_names():
+  a = importlib.import_module("big_vision.configs.proj.image_text.lit_coco").get_config("batch_size=64")
+  b = importlib.import_module("big_vision.configs.proj.image_text.siglip_lit_coco").get_config("batch_size=64")
+  assert a.to_dict() == b.to_dict()
+  assert a.input.batch_size == 64 and a.model_name == "proj.image_text.two_towers"
+  assert a.schedule[0] == ("img/.*", None) and a.schedule[1][1]["warmup_steps"] == 150
+  assert a.model.bias_init == -2.71 and a.model.image.pool_type == "tok" and tuple(a.model.out_dim) == (None, 768)
+  assert a.lr == 1e-3 and a.wd == 1e-2 and a.grad_clip_norm == 1.0
+
+
+def test_reference_style_trainer_snippet(dry):
+  """What trainers/proj/image_text/siglip.py:180-323 does, with big_vision.* names only."""
+  import big_vision.optax as bv_optax
+  import big_vision.sharding as bv_sharding
+  import big_vision.utils as u
+  from big_vision.trainers.proj.image_text import siglip as trainer
+  config = importlib.import_module("big_vision.configs.proj.image_text.lit_coco").get_config("batch_size=4,res=32,token_len=8")
+  config.model.image = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok",
+                            head_zeroinit=False)
+  config.model.text = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=50)
+  config.model.out_dim = (None, 128)
+  model_mod = importlib.import_module(f"big_vision.models.{config.model_name}")      # siglip.py:190
+  model = model_mod.Model(**config.model)
+  image = torch.zeros((4,) + tuple(config.init_shapes[0][1:]))
+  text = torch.ones((4,) + tuple(config.init_shapes[1][1:]), dtype=torch.int32)
+  state, sched_fns = trainer.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
+  specs = bv_sharding.infer_sharding(state["params"], config.sharding_strategy, None)     # siglip.py:232-237
+  def leaves(t):
+    return [t] if isinstance(t, tuple) else [x for v in t.values() for x in leaves(v)]
+  flat = leaves(specs)
+  assert len(flat) == len(u.tree_flatten_with_names(state["params"])[0]) and all(all(a is None for a in spec) for spec in flat)
+  names = [n for n, _ in u.tree_flatten_with_names(state["params"])[0]]
+  assert set(bv_optax.frozen_leaves(config, names)) == {n for n in names if n.startswith("img/")}
+  update_fn = trainer.make_update_fn(model, config)
+  dry.clear()
+  state, meas = update_fn(state, None, {"image": image, "labels": text})
+  assert {"training_loss", "l2_grads", "l2_params", "l2_updates"} <= set(meas)
+  assert dry["bv_attn_fwd"] == 4 and dry["bv_attn_bwd"] == 2       # image tower frozen: text-only backward
+  assert len(sched_fns) >= 1
+
+
+def test_contrastive_trainer_loss_switch(dry):
+  from big_vision.trainers.proj.image_text import contrastive
+  from big_vision.models.proj.image_text import two_towers
+  from ml_collections import ConfigDict
+  tower = dict(width=128, depth=1, mlp_dim=256, num_heads=2)
+  model = two_towers.Model(image=dict(tower, patch_size=(16, 16), pool_type="map"), text=dict(tower, vocab_size=50),
+                           out_dim=(None, 64), temperature_init=10.0, bias_init=-10.0)
+  image, text = torch.zeros((4, 32, 32, 3)), torch.ones((4, 8), dtype=torch.int32)
+  for loss, kernel in (("sigmoid", "bv_siglip_loss"), ("chunked_sigmoid", "bv_siglip_loss"), ("softmax", "bv_softmax_xent")):
+    c = ConfigDict(dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
+                        schedule=dict(decay_type="cosine", warmup_steps=2), loss_fn=loss))
+    state, _ = contrastive.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
+    dry.clear()
+    state, meas = contrastive.make_update_fn(model, c)(state, None, {"image": image, "labels": text})
+    assert dry[kernel] >= 1, (loss, dict(dry))
+    assert {"t", "t/parameter", "train/nimg", "train/ntxt", "training_loss"} <= set(meas), (loss, set(meas))
+    if loss != "softmax":
+      assert dry["bv_logit_stats"] == 1 and "train/pos_avg_logit" in meas
+      assert ("train/neg_avg_logit" in meas) == (loss == "sigmoid")
+  bad = ConfigDict(dict(c.to_dict(), loss_fn="nce"))
+  with pytest.raises(NotImplementedError, match="Unrecognized loss"):
+    contrastive.make_update_fn(model, bad)
+
+
+def test_sharding_accepts_replicate_and_refuses_the_rest():
+  import numpy as np
+  import big_vision.sharding as sh
+  params = {"img": {"embedding": {"kernel": np.zeros((16, 16, 3, 8)), "bias": np.zeros(8)}}, "t": np.zeros(1)}
+  specs = sh.infer_sharding(params, [(".*", "replicate")], None)
+  assert specs == {"img": {"embedding": {"kernel": (None,) * 4, "bias": (None,)}}, "t": (None,)}
+  assert sh.infer_sharding(params) == specs                                       # default strategy
+  assert sh.infer_sharding(params, [("img/.*", "replicate")]) == specs            # unmatched leaves stay replicated
+  for bad in ("fsdp(axis='data')", "shard_dim('data', 0)", "logical_partitioning", "replicate|fsdp(axis='data')"):
+    with pytest.raises(NotImplementedError, match="replicated"):
+      sh.infer_sharding(params, [(".*", bad)])
+  with pytest.raises(KeyError):
+    sh.infer_sharding(params, [(".*", "bogus")])
+  from ml_collections import ConfigDict
+  with pytest.raises(NotImplementedError):
+    sh.check_config(ConfigDict(dict(sharding_strategy=[(".*", "fsdp(axis='data')")])), params)

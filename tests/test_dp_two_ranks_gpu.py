@@ -45,6 +45,8 @@ def _step(comm, image, text, **kw):
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
   from big_vision_amd import utils as u
+  if "loss_fn" in kw:     # the contrastive trainer (config.loss_fn switch) over the same DP machinery
+    from big_vision_amd.trainers.proj.image_text import contrastive as siglip
   model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, 128), temperature_init=10.0,
                            bias_init=-10.0)
   config = _config(**kw)
@@ -79,14 +81,15 @@ def _worker(rank, world, port, out, kw):
   torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2)])
+@pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2), dict(loss_fn="softmax"),
+                                dict(loss_fn="sigmoid")])
 def test_two_ranks_match_single_process(dev, kw):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import bv_oracle as O
   from big_vision_amd import dp
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
-  loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev))
+  loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev), **({"loss_fn": kw["loss_fn"]} if "loss_fn" in kw else {}))
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
   port = _free_port()
