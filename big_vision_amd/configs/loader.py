@@ -18,30 +18,48 @@ import sys
 import types
 
 
+def _is_bv(name):
+  return name == "big_vision" or name.startswith("big_vision.")
+
+
 def _alias_modules(reference_root):
+  """Installs the names a reference config file imports and returns a restore() callback.  While a
+  file is being loaded, `big_vision` is a bare namespace rooted at the reference checkout (so its
+  helper tables resolve there) with `big_vision.configs.common` served from this repo; the
+  repo's own `big_vision` alias package (if imported) is parked and comes back afterwards."""
   from big_vision_amd.compat import ml_collections as mlc
   from big_vision_amd.configs import common
-  added = {}
-
-  def put(name, mod):
-    if name not in sys.modules:
-      sys.modules[name] = mod
-      added[name] = mod
-
-  put("ml_collections", mlc)
+  parked = {n: m for n, m in sys.modules.items() if _is_bv(n)}
+  for n in parked:
+    del sys.modules[n]
+  finders = [f for f in sys.meta_path if type(f).__name__ == "_AliasFinder"]
+  for f in finders:
+    sys.meta_path.remove(f)
+  had_mlc = "ml_collections" in sys.modules
+  if not had_mlc:
+    sys.modules["ml_collections"] = mlc
   for pkg in ("big_vision", "big_vision.configs"):
     m = types.ModuleType(pkg)
     m.__path__ = [os.path.join(reference_root, *pkg.split("."))] if reference_root else []
-    put(pkg, m)
-  put("big_vision.configs.common", common)
+    sys.modules[pkg] = m
+  sys.modules["big_vision.configs.common"] = common
   sys.modules["big_vision.configs"].common = common
-  return added
+
+  def restore():
+    for n in [n for n in sys.modules if _is_bv(n)]:
+      del sys.modules[n]
+    if not had_mlc:
+      sys.modules.pop("ml_collections", None)
+    sys.modules.update(parked)
+    for f in finders:
+      sys.meta_path.insert(0, f)
+  return restore
 
 
 def load_config(path_and_arg, reference_root=None):
   """`path[:arg]` like `--config file.py:arg` of the reference launcher (train.py:63-64)."""
   path, _, arg = path_and_arg.partition(":")
-  added = _alias_modules(reference_root)
+  restore = _alias_modules(reference_root)
   try:
     spec = importlib.util.spec_from_file_location("_bv_config_file", path)
     mod = importlib.util.module_from_spec(spec)
@@ -53,8 +71,4 @@ def load_config(path_and_arg, reference_root=None):
       takes_arg = False
     return get_config(arg or None) if takes_arg else get_config()
   finally:
-    for name in added:
-      sys.modules.pop(name, None)
-    for name in [n for n in sys.modules if n.startswith("big_vision.") and not n.startswith("big_vision_amd")]:
-      if reference_root and name not in added:
-        sys.modules.pop(name, None)
+    restore()
