@@ -69,6 +69,9 @@ PROTOTYPES = {
                      c_float, c_float, c_float, P, P],
 }
 
+PROTOTYPES["bv_adafactor_leaf"] = [P, P, P, c_int, P, P, P, c_int, P, c_float, c_float, c_float, c_float,
+                                   c_float, c_float, c_float, P, P]
+
 RESTYPES = {"bv_gemm_workspace_bytes": c_long}   # everything else returns an int status
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT = range(7)

@@ -367,3 +367,13 @@ def adam_step_(params, grads, mu, nu, shadow, segs, chunk_seg, count, sched, gsq
             _p(segs), _p(chunk_seg), count, ctypes.cast(arr, ctypes.c_void_p), len(sched), _p(gsq),
             float(clip_norm or 0.0), float(b1), float(b2), float(eps), float(bc1), float(bc2),
             _p(stats), _stream())
+
+
+def adafactor_leaf_(params, grads, momentum, shadow, view, state, factored, gsq, clip_norm, decay, eps, mom,
+                    lr_eff, wd, sched, stats):
+  """One leaf of the fused Adafactor step (bv_adafactor_leaf); view: ctypes array of 9 longs (host)."""
+  import ctypes
+  _lib.call("bv_adafactor_leaf", _p(params), _p(grads), _p(momentum),
+            int(momentum is not None and momentum.dtype == BF16), _p(shadow),
+            ctypes.cast(view, ctypes.c_void_p), _p(state), int(factored), _p(gsq), float(clip_norm or 0.0),
+            float(decay), float(eps), float(mom), float(lr_eff), float(wd), float(sched), _p(stats), _stream())

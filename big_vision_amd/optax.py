@@ -27,6 +27,18 @@ from big_vision_amd import utils as u
 from big_vision_amd.params import ParamStore, make_masks
 
 MAX_SCHED = 8
+ADAFACTOR_NAMES = ("big_vision.scale_by_adafactor", "scale_by_adafactor")
+
+
+def factored_dims(shape, min_dim_size_to_factor=32):
+  """optax/_src/factorized.py `_factored_dims` (factored=True): None, or (d1, d0) = the axes of the
+  second-largest and the largest dimension (numpy argsort order on ties)."""
+  if len(shape) < 2:
+    return None
+  order = np.argsort(np.asarray(shape), kind="stable")
+  if shape[order[-2]] < min_dim_size_to_factor:
+    return None
+  return int(order[-2]), int(order[-1])
 
 
 def frozen_patterns(config) -> List[str]:
@@ -118,8 +130,15 @@ class Optimizer:
       assert okw.get("eps_root", 0.0) == 0.0, "eps_root is not supported"
       mu_dtype = okw.get("mu_dtype")
       mu_dtype = torch.bfloat16 if str(mu_dtype) in ("bfloat16", "torch.bfloat16") else torch.float32
+    elif self.name in ADAFACTOR_NAMES:
+      self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
+      assert not config.get("grad_clip_per_example"), "per-example clipping is not supported"
+      self.lr = float(config["lr"])
+      self._init_adafactor(okw, lr_mult, wd, sched_idx_of_leaf)
+      return
     else:
-      raise NotImplementedError(f"optax_name={self.name!r}: only scale_by_adam is on the fused path")
+      raise NotImplementedError(f"optax_name={self.name!r}: scale_by_adam and big_vision.scale_by_adafactor "
+                                "are on the fused path")
     self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
     assert not config.get("grad_clip_per_example"), "per-example clipping is not supported"
     self.lr = float(config["lr"])
@@ -150,6 +169,125 @@ class Optimizer:
     self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
     self._frozen_sq = None
 
+  # ------------------------------------------------------------------ Adafactor --
+  def _init_adafactor(self, okw, lr_mult, wd, sched_idx_of_leaf):
+    """BigVision Adafactor (optax.py:187-216) per Flax leaf: which two axes optax factors
+    (optax/_src/factorized.py `_factored_dims`: the two largest, if the second largest is >=
+    min_dim_size_to_factor), the leaf as a strided [B1][B2][R][C] view of the flat buffers, and
+    the layout of the second-moment state."""
+    import ctypes
+    st, dev = self.store, self.store.device
+    self.af = dict(min_dim=int(okw.get("min_dim_size_to_factor", 32)), decay_rate=float(okw.get("decay_rate", 0.8)),
+                   decay_offset=int(okw.get("decay_offset", 0)), beta2_cap=float(okw.get("beta2_cap", 0.999)),
+                   momentum=float(okw.get("momentum", 0.9) or 0.0), eps=float(okw.get("eps", 1e-30)))
+    if okw.get("clipping_threshold"):
+      raise NotImplementedError("scale_by_adafactor(clipping_threshold=...) (clip_by_block_rms) is not implemented")
+    mdt = okw.get("dtype_momentum", "bfloat16")
+    mom_dtype = torch.float32 if str(mdt) in ("float32", "torch.float32") else torch.bfloat16
+    self.af_leaves = []
+    off_state = 0
+    for leaf, (sname, sl) in st.leaf_index.items():
+      if sname in st.frozen:
+        continue
+      e = st.entries[sname]
+      t = torch.empty(e.shape, device="meta")
+      v = t if sl is None else t.select(sl[0], sl[1])
+      shape, strides = tuple(v.shape), tuple(v.stride())
+      fd = factored_dims(shape, self.af["min_dim"])
+      if fd is None:
+        d1 = d0 = None
+        rest = list(range(len(shape)))
+        R = C = 1
+        sR = sC = 0
+      else:
+        d1, d0 = fd
+        rest = [a for a in range(len(shape)) if a not in fd]
+        R, C, sR, sC = shape[d1], shape[d0], strides[d1], strides[d0]
+      rest = [a for a in rest if shape[a] > 1]
+      if fd is None:
+        # unfactored: enumerate the elements through (up to) four axes, last one as "C"
+        axes = rest[-4:] if len(rest) <= 4 else None
+        if axes is None:
+          raise NotImplementedError(f"{leaf}: more than 4 non-trivial axes")
+        ext = [1] * (4 - len(axes)) + [shape[a] for a in axes]
+        strd = [0] * (4 - len(axes)) + [strides[a] for a in axes]
+        B1, B2, R, C = ext
+        sB1, sB2, sR, sC = strd
+      else:
+        if len(rest) > 2:
+          raise NotImplementedError(f"{leaf} {shape}: more than two axes besides the factored pair")
+        ext = [1] * (2 - len(rest)) + [shape[a] for a in rest]
+        strd = [0] * (2 - len(rest)) + [strides[a] for a in rest]
+        (B1, B2), (sB1, sB2) = ext, strd
+      B = B1 * B2
+      n_state = (B * R + B * C + B) if fd is not None else B * R * C
+      view = (ctypes.c_long * 9)(e.offset + v.storage_offset(), B1, B2, R, C, sB1, sB2, sR, sC)
+      extn = st.ext_of[leaf]
+      self.af_leaves.append(dict(leaf=leaf, view=view, factored=fd is not None, dims=fd, shape=shape, rest=rest,
+                                 soff=off_state, n_state=n_state, lr_eff=self.lr * lr_mult[extn], wd=wd[extn],
+                                 sched=sched_idx_of_leaf[extn], B=B, R=R, C=C))
+      off_state += (n_state + 3) // 4 * 4
+    self.af_state = torch.zeros(max(4, off_state), device=dev, dtype=torch.float32)
+    self.mu = torch.zeros(st.trainable_count, device=dev, dtype=mom_dtype) if self.af["momentum"] > 0 else None
+    self.nu = None
+    self.count = 0
+    self.gsq = torch.zeros(1, device=dev, dtype=torch.float64)
+    self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
+    self._frozen_sq = None
+
+  def _adafactor_step(self):
+    st, af, k = self.store, self.af, self.count
+    sched = [fn(k) for fn in self.schedule_fns]
+    t = float(k - af["decay_offset"]) + 1.0
+    decay = min(af["beta2_cap"], 1.0 - t ** (-af["decay_rate"]))     # optax.py:196-199
+    self.gsq.zero_()
+    ops.sqnorm_(st.grad, self.gsq)
+    self.stats.zero_()
+    for lf in self.af_leaves:
+      ops.adafactor_leaf_(st.master, st.grad, self.mu, st.shadow, lf["view"],
+                          self.af_state[lf["soff"]:lf["soff"] + lf["n_state"]], lf["factored"], self.gsq,
+                          self.clip_norm, decay, af["eps"], af["momentum"], lf["lr_eff"], lf["wd"],
+                          sched[lf["sched"]], self.stats)
+    self.count = k + 1
+    st.shadow_version += 1
+    return {"l2_grads": torch.sqrt(self.gsq[0]),
+            "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
+            "l2_updates": torch.sqrt(self.stats[1])}
+
+  def adafactor_state_numel(self):
+    """Elements of the optax FactoredState (count, v_row, v_col, v) this optimizer stands for - the
+    number optax_test.py:320-337 checks (2 * 1024 + 2 for one 1024 x 1024 kernel)."""
+    n = 1
+    for lf in self.af_leaves:
+      n += (lf["B"] * lf["R"] + lf["B"] * lf["C"] + 1) if lf["factored"] else (1 + 1 + lf["B"] * lf["R"] * lf["C"])
+    return n
+
+  def adafactor_state_of(self, leaf):
+    """(v_row, v_col, v) of a storage leaf in the axis order optax keeps them (the leaf's shape without
+    d0 / without d1 / the full shape; (1,) zeros where optax keeps a placeholder)."""
+    lf = next(l for l in self.af_leaves if l["leaf"] == leaf)
+    buf = self.af_state[lf["soff"]:lf["soff"] + lf["n_state"]]
+    one = torch.zeros(1, device=buf.device)
+    shape, rest = lf["shape"], lf["rest"]
+    if not lf["factored"]:
+      full = [shape[a] for a in rest[-4:]]
+      return one, one, buf.view(full if full else (1,)).reshape(shape)
+    d1, d0 = lf["dims"]
+    B, R, C = lf["B"], lf["R"], lf["C"]
+
+    def to_axes(t, axes_canon):    # t: canonical [rest..., X] -> leaf axis order (axes sorted), size-1 axes re-inserted
+      order = sorted(range(len(axes_canon)), key=lambda i: axes_canon[i])
+      t = t.permute(order)
+      full = [shape[a] if a in axes_canon else 1 for a in range(len(shape)) if a in axes_canon or shape[a] == 1]
+      return t.reshape(full)
+    v_row = buf[:B * R].view([shape[a] for a in rest] + [R])
+    v_col = buf[B * R:B * R + B * C].view([shape[a] for a in rest] + [C])
+    keep_row = [a for a in range(len(shape)) if a != d0]
+    keep_col = [a for a in range(len(shape)) if a != d1]
+    v_row = to_axes(v_row, rest + [d1]).reshape([shape[a] for a in keep_row])
+    v_col = to_axes(v_col, rest + [d0]).reshape([shape[a] for a in keep_col])
+    return v_row, v_col, one
+
   def frozen_sqnorm(self):
     if self._frozen_sq is None:
       acc = torch.zeros(1, device=self.store.device, dtype=torch.float64)
@@ -162,6 +300,8 @@ class Optimizer:
   def step(self):
     """tx.update + optax.apply_updates on the store; returns device scalars
     (l2_grads, l2_params, l2_updates) without synchronising."""
+    if self.name in ADAFACTOR_NAMES:
+      return self._adafactor_step()
     st = self.store
     n_tr = st.trainable_count
     k = self.count

@@ -300,6 +300,22 @@ int bv_adam_step(float* params, const float* grads, void* mu, int mu_bf16, float
                  float clip_norm, float b1, float b2, float eps, float bc1, float bc2,
                  double* stats, void* stream);
 
+/* One parameter LEAF of the BigVision Adafactor step (big_vision/optax.py:187-216:
+ * scale_by_factored_rms(decay 1 - t^-0.8 capped at 0.999, min_dim_size_to_factor 32, eps 1e-30) ->
+ * ema(0.9, debias=False, bf16 accumulator)) fused with the rest of the bv_optax chain
+ * (optax.py:100-149: global-norm clip factor from gsq, lr * lr_mult, decoupled weight decay,
+ * schedule, sign, apply + bf16 shadow refresh).  The leaf is the strided 4-D view
+ * view = {offset, B1, B2, R, C, strideB1, strideB2, strideR, strideC} (HOST array of 9 longs,
+ * element units) of params / grads / momentum / shadow: C = its largest axis, R = the second
+ * largest (optax's factored dims), B1, B2 = the remaining axes (1 if absent).  state (device fp32):
+ * factored != 0: v_row[B*R], v_col[B*C], rcm[B] consecutively; factored == 0: v per element in the
+ * view's [B1][B2][R][C] order.  decay / sched / lr_eff / wd are this step's host scalars; mom = 0
+ * disables the momentum EMA; stats[0] += sum p_new^2, stats[1] += sum update^2 (may be NULL). */
+int bv_adafactor_leaf(float* params, const float* grads, void* momentum, int mom_bf16, void* shadow_bf16,
+                      const long* view, float* state, int factored, const double* gsq, float clip_norm,
+                      float decay, float eps, float mom, float lr_eff, float wd, float sched,
+                      double* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

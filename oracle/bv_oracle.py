@@ -632,6 +632,22 @@ class OptaxOracle:
         if not self.frozen[n]:  # optax_test.py:301-318: no state for frozen
           self.mu[n] = torch.zeros_like(p)
           self.nu[n] = torch.zeros_like(p)
+    if self.name in ("big_vision.scale_by_adafactor", "scale_by_adafactor"):
+      # optax.py:187-216 -> optax.scale_by_factored_rms state (v_row, v_col, v) + optax.ema state
+      self.af = {}
+      mind = self.okw.get("min_dim_size_to_factor", 32)
+      for n, p in flat:
+        if self.frozen[n]:
+          continue
+        fd = adafactor_factored_dims(tuple(p.shape), mind)
+        if fd is None:
+          st = dict(fd=None, v=torch.zeros_like(p))
+        else:
+          d1, d0 = fd
+          st = dict(fd=fd, v_row=torch.zeros([s_ for a, s_ in enumerate(p.shape) if a != d0], dtype=p.dtype),
+                    v_col=torch.zeros([s_ for a, s_ in enumerate(p.shape) if a != d1], dtype=p.dtype))
+        st["ema"] = torch.zeros_like(p)
+        self.af[n] = st
 
   def update(self, grads: Tree, params: Optional[Tree] = None) -> Tree:
     g = dict(tree_flatten_with_names(grads))
@@ -665,6 +681,8 @@ class OptaxOracle:
         self.mu[n] = mu.to(torch.bfloat16) if mu_dtype == "bfloat16" else mu
         self.nu[n] = nu
         u = mu_hat / (torch.sqrt(nu_hat) + eps)
+      elif self.name in ("big_vision.scale_by_adafactor", "scale_by_adafactor"):
+        u = self._adafactor(n, u, step)
       elif self.name == "identity":
         pass
       else:
@@ -676,6 +694,55 @@ class OptaxOracle:
       upd[n] = -u
     self.count += 1
     return recover_tree([(n, upd[n]) for n in self.names])
+
+
+def adafactor_factored_dims(shape, min_dim_size_to_factor=32):
+  """optax/_src/factorized.py `_factored_dims` with factored=True (optax is an un-vendored
+  dependency of the reference, requirements.txt; this restates its published algorithm)."""
+  import numpy as np
+  if len(shape) < 2:
+    return None
+  sorted_dims = np.argsort(shape)
+  if shape[sorted_dims[-2]] < min_dim_size_to_factor:
+    return None
+  return int(sorted_dims[-2]), int(sorted_dims[-1])
+
+
+def _adafactor(self, n, g, step):
+  """big_vision/optax.py:187-216: chain(scale_by_factored_rms(decay 1 - t^-0.8 capped 0.999, eps 1e-30),
+  [clip_by_block_rms if clipping_threshold], ema(momentum, debias=False, accumulator bf16))."""
+  kw = self.okw
+  decay_rate, offset = kw.get("decay_rate", 0.8), kw.get("decay_offset", 0)
+  cap, eps = kw.get("beta2_cap", 0.999), kw.get("eps", 1e-30)
+  mom = kw.get("momentum", 0.9)
+  t = float(step - offset) + 1.0
+  beta2 = min(cap, 1.0 - t ** (-decay_rate))
+  st = self.af[n]
+  g2 = g * g + eps
+  if st["fd"] is None:
+    st["v"] = beta2 * st["v"] + (1 - beta2) * g2
+    u = g * st["v"] ** -0.5
+  else:
+    d1, d0 = st["fd"]
+    st["v_row"] = beta2 * st["v_row"] + (1 - beta2) * g2.mean(dim=d0)
+    st["v_col"] = beta2 * st["v_col"] + (1 - beta2) * g2.mean(dim=d1)
+    reduced_d1 = d1 - 1 if d1 > d0 else d1
+    rcm = st["v_row"].mean(dim=reduced_d1, keepdim=True)
+    row_factor = (st["v_row"] / rcm) ** -0.5
+    col_factor = st["v_col"] ** -0.5
+    u = g * row_factor.unsqueeze(d0) * col_factor.unsqueeze(d1)
+  if kw.get("clipping_threshold"):
+    thr = kw["clipping_threshold"]
+    u = u / torch.clamp(torch.sqrt((u ** 2).mean()) / thr, min=1.0)      # optax.clip_by_block_rms
+  if mom:
+    ema = mom * st["ema"].to(u.dtype) + (1 - mom) * u
+    acc = kw.get("dtype_momentum", "bfloat16")
+    st["ema"] = ema.to(torch.bfloat16) if str(acc) in ("bfloat16", "torch.bfloat16") else ema
+    u = ema
+  return u
+
+
+OptaxOracle._adafactor = _adafactor
 
 
 # -----------------------------------------------------------------------------
