@@ -55,3 +55,25 @@ def test_edge_cases():
   d = np.array([[0.1, 0.9], [0.8, 0.2], [0.5, 0.5]])
   r = itr.image_to_text_retrieval_eval(d, [0, 1])
   assert r["Recall@1"] == pytest.approx(2 / 3) and r["Recall@10"] == pytest.approx(2 / 3)
+
+
+def test_zeroshot_class_average_matches_the_reference_function():
+  """tests/golden/zeroshot_average.npz holds outputs of the reference's own `_average_embeddings`
+  (discriminative_classifier.py:145-166, executed by oracle/make_zeroshot_golden.py)."""
+  import os
+  from big_vision_amd.evaluators.proj.image_text import discriminative_classifier as dc
+  g = np.load(os.path.join(os.path.dirname(__file__), "golden", "zeroshot_average.npz"))
+  got = dc._average_embeddings(g["emb"], labels=g["labels"], num_classes=7, normalize=True)
+  np.testing.assert_allclose(got, g["avg_norm"], rtol=1e-6, atol=1e-7)
+  got = dc._average_embeddings(g["emb"], labels=g["labels"], num_classes=7, normalize=False)
+  np.testing.assert_allclose(got, g["avg_raw"], rtol=1e-6, atol=1e-7)
+  with pytest.raises(AssertionError, match="Classes without embeddings"):
+    dc._average_embeddings(g["emb"], labels=g["labels"], num_classes=8, normalize=True)
+
+
+def test_zeroshot_prompt_expansion():
+  from big_vision_amd.evaluators.proj.image_text import discriminative_classifier as dc
+  got = dc.expand_prompts(["cat,kitty", "dog"], ["a photo of a {}.", "{}"])
+  assert got == [(0, "a photo of a cat."), (0, "cat"), (1, "a photo of a dog."), (1, "dog")]
+  got = dc.expand_prompts(["cat,kitty"], ["{}!"], first_class_name_only=False)
+  assert got == [(0, "cat!"), (0, "kitty!")]
