@@ -1,0 +1,74 @@
+"""tests/golden/siglip_hf_b16.npz: HuggingFace SiglipModel at the REAL ViT-B/16 + text-B shapes
+(BASELINE configs[2]: 224 px, 196 patches, 12 + 12 layers, width 768, 64 tokens, vocab 32 000),
+forward only, two pairs.  Extends the tiny-shape pin of oracle/make_golden.py ("extend
+the HF pin to the real B/16 shapes").  Only the OUTPUTS are stored (embeddings, logits, loss: a few
+KB); weights and inputs are regenerated from the seeds below by the test, which runs
+oracle/bv_oracle.py on them in fp32 and compares.  TEST INFRASTRUCTURE; needs `transformers`:
+
+    python oracle/make_golden_b16.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bv_oracle as O  # noqa: E402
+from make_golden import flax_to_hf_state  # noqa: E402
+
+CFG = dict(width=768, depth=12, mlp_dim=3072, num_heads=12, patch=16, res=224, vocab=32_000, seq=64, n=2,
+           temperature_init=10.0, bias_init=-10.0, seed=0, perturb_seed=123, batch_seed=1)
+IMAGE_CFG = dict(variant="B/16", pool_type="map")
+TEXT_CFG = dict(variant="B", vocab_size=32_000)
+
+
+def make_inputs(dtype=torch.float32):
+  """Seeded weights (Flax layout, biases / scales perturbed) and batch - shared with the test."""
+  c = CFG
+  params = O.init_two_towers(c["seed"], (c["res"], c["res"]), c["seq"], image_cfg=IMAGE_CFG, text_cfg=TEXT_CFG,
+                             out_dim=(None, c["width"]), temperature_init=c["temperature_init"],
+                             bias_init=c["bias_init"], dtype=dtype)
+  gen = torch.Generator().manual_seed(c["perturb_seed"])
+  flat = [(n, v + 0.05 * torch.randn(v.shape, generator=gen, dtype=dtype) if n.endswith(("bias", "scale")) else v)
+          for n, v in O.tree_flatten_with_names(params)]
+  image, text = O.synthetic_batch(c["batch_seed"], c["n"], c["res"], c["seq"], c["vocab"], dtype=dtype)
+  return O.recover_tree(flat), image, text
+
+
+def main():
+  from transformers import SiglipConfig, SiglipModel
+  c = CFG
+  params, image, text = make_inputs()
+  hf_cfg = SiglipConfig(
+      text_config=dict(hidden_size=c["width"], intermediate_size=c["mlp_dim"], num_hidden_layers=c["depth"],
+                       num_attention_heads=c["num_heads"], vocab_size=c["vocab"], max_position_embeddings=c["seq"],
+                       projection_size=c["width"], layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh",
+                       bos_token_id=None, eos_token_id=None, pad_token_id=1),
+      vision_config=dict(hidden_size=c["width"], intermediate_size=c["mlp_dim"], num_hidden_layers=c["depth"],
+                         num_attention_heads=c["num_heads"], image_size=c["res"], patch_size=c["patch"],
+                         layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh"))
+  hf = SiglipModel(hf_cfg).to(torch.float64).eval()
+  p64 = O.tree_map(lambda v: v.double(), params)
+  missing, unexpected = hf.load_state_dict(flax_to_hf_state(p64, c), strict=False)
+  missing = [m for m in missing if "position_ids" not in m]
+  assert not missing and not unexpected, (missing, unexpected)
+  with torch.no_grad():
+    res = hf(input_ids=text.long(), pixel_values=image.double().permute(0, 3, 1, 2).contiguous(), return_loss=True)
+    loss, (zimg, ztxt, logits, _) = O.siglip_step_loss(p64, image.double(), text, image_cfg=IMAGE_CFG,
+                                                       text_cfg=TEXT_CFG, out_dim=(None, c["width"]))
+  for name, a, b in (("zimg", zimg, res.image_embeds), ("ztxt", ztxt, res.text_embeds),
+                     ("logits", logits, res.logits_per_image), ("loss", loss, res.loss)):
+    err = (a - b).abs().max().item()
+    print(f"oracle(fp64) vs HF(fp64) {name}: max abs err {err:.3e}")
+    assert err < 1e-6, name
+  dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "siglip_hf_b16.npz")
+  np.savez_compressed(dst, hf_zimg=res.image_embeds.numpy(), hf_ztxt=res.text_embeds.numpy(),
+                      hf_logits=res.logits_per_image.numpy(), hf_loss=res.loss.numpy(),
+                      param_checksum=np.asarray(sum(float(v.double().sum()) for _, v in O.tree_flatten_with_names(params))),
+                      **{"cfg_" + k: np.asarray(v) for k, v in c.items()})
+  print("wrote", os.path.normpath(dst), os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+  main()
