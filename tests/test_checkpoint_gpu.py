@@ -1,0 +1,88 @@
+"""SURVEY.md §8(f) rank 1 on the GPU: a checkpoint written in the reference's npz format is loaded
+through `two_towers.load` (two_towers.py:93-137 -> vit.load / text_transformer.load with their
+fix-ups) INTO THE STORE-BOUND PARAMETER TREE of a freshly initialised model, and the HIP forward on
+the loaded weights must equal the oracle's forward on the checkpoint's weights - i.e. the weights
+that reach the kernels (master copy, bf16 shadow, transposed shadows) are the loaded ones, including
+a posemb resample and the scan-layout conversion; then a train-state round trip (save -> step ->
+load -> same step)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+IMG = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+TXT = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+
+
+def _np_tree(tree):
+  import bv_oracle as O
+  return O.tree_map(lambda v: v.numpy() if torch.is_tensor(v) else np.asarray(v), tree)
+
+
+@pytest.mark.parametrize("scan", [False, True])
+def test_loaded_checkpoint_reaches_the_kernels(dev, tmp_path, scan):
+  import bv_oracle as O
+  from big_vision_amd import utils as u
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  res_ckpt, res, seq = 32, 64, 16        # checkpoint trained at 32 px (2x2 posemb), model runs at 64 px (4x4)
+  ckpt = O.init_two_towers(7, (res_ckpt, res_ckpt), seq, image_cfg=IMG, text_cfg=TXT, out_dim=(None, 128),
+                           temperature_init=5.0, bias_init=-3.0, dtype=torch.float32)
+  g = torch.Generator().manual_seed(11)
+  ckpt = O.recover_tree([(n, v + 0.05 * torch.randn(v.shape, generator=g) if n.endswith(("bias", "scale")) else v)
+                         for n, v in O.tree_flatten_with_names(ckpt)])
+  f = str(tmp_path / "siglip.npz")
+  u.save_params_npz(f, {"params": _np_tree(ckpt)})
+  image_cfg = dict(IMG, scan=scan)
+  text_cfg = dict(TXT, scan=scan)
+  model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+  image, text = O.synthetic_batch(1, 4, res, seq, 100)
+  variables = model.init(0, image.to(dev), text.to(dev))                     # store-bound ParamTree on the GPU
+  store = variables["params"].store
+  model_cfg = ConfigDict(dict(image=image_cfg, text=text_cfg, bias_init=-10.0))
+  loaded = two_towers.load(variables["params"], f, model_cfg)                # init_params are CUDA views
+  store.load_tree(loaded)
+  zimg, ztxt, out = model.apply({"params": store.tree()}, image.to(dev), text.to(dev), collect=False)
+  # oracle on the checkpoint's weights with the posemb resampled the reference's way (vit.py:305-321)
+  from big_vision_amd.models import vit
+  want = O.tree_map(lambda v: v.double(), ckpt)
+  want["img"]["pos_embedding"] = torch.from_numpy(np.asarray(vit.resample_posemb(
+      ckpt["img"]["pos_embedding"].numpy(), np.zeros((1, (res // 16) ** 2, 128), np.float32)))).double()
+  zi, zt, _ = O.two_towers_forward(want, image.double(), text, image_cfg=IMG, text_cfg=TXT, out_dim=(None, 128))
+  assert (zimg.cpu().double() - zi).abs().max() <= 2e-2 and (ztxt.cpu().double() - zt).abs().max() <= 2e-2
+  assert abs(out["t"].item() - 5.0) < 1e-4 and abs(out["b"].item() + 3.0) < 1e-6
+  # the loaded values are what the master buffer holds, under the presented (possibly stacked) names
+  names = dict(u.tree_flatten_with_names(store.tree())[0])
+  k = "img/Transformer/encoderblock/MlpBlock_0/Dense_0/kernel" if scan else "img/Transformer/encoderblock_1/MlpBlock_0/Dense_0/kernel"
+  ref = ckpt["img"]["Transformer"]
+  ref = torch.stack([ref[f"encoderblock_{i}"]["MlpBlock_0"]["Dense_0"]["kernel"] for i in range(2)]) if scan \\
+      else ref["encoderblock_1"]["MlpBlock_0"]["Dense_0"]["kernel"]
+  assert torch.equal(names[k].cpu(), ref)
+
+
+def test_train_state_roundtrip_resumes_bit_exactly(dev, tmp_path):
+  import bv_oracle as O
+  from big_vision_amd import utils as u
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  model = two_towers.Model(image=IMG, text=TXT, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+  c = ConfigDict(dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
+                      schedule=dict(decay_type="cosine", warmup_steps=2)))
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+  state, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=0, total_steps=10)
+  fn = siglip.make_update_fn(model, c)
+  state, _ = fn(state, None, batch)
+  f = str(tmp_path / "state.npz")
+  u.save_train_state(f, state)
+  state, m2 = fn(state, None, batch)
+  after = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
+  # fresh state, resumed from the file: the next step must reproduce step 2 exactly
+  state_b, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=5, total_steps=10)
+  u.load_train_state(f, state_b)
+  state_b, m2b = siglip.make_update_fn(model, c)(state_b, None, batch)
+  assert m2["training_loss"].item() == m2b["training_loss"].item()
+  for k, v in u.tree_flatten_with_names(state_b["params"])[0]:
+    assert torch.equal(v, after[k]), k
