@@ -56,8 +56,10 @@ def test_loaded_checkpoint_reaches_the_kernels(dev, tmp_path, scan):
   names = dict(u.tree_flatten_with_names(store.tree())[0])
   k = "img/Transformer/encoderblock/MlpBlock_0/Dense_0/kernel" if scan else "img/Transformer/encoderblock_1/MlpBlock_0/Dense_0/kernel"
   ref = ckpt["img"]["Transformer"]
-  ref = torch.stack([ref[f"encoderblock_{i}"]["MlpBlock_0"]["Dense_0"]["kernel"] for i in range(2)]) if scan \\
-      else ref["encoderblock_1"]["MlpBlock_0"]["Dense_0"]["kernel"]
+  if scan:
+    ref = torch.stack([ref[f"encoderblock_{i}"]["MlpBlock_0"]["Dense_0"]["kernel"] for i in range(2)])
+  else:
+    ref = ref["encoderblock_1"]["MlpBlock_0"]["Dense_0"]["kernel"]
   assert torch.equal(names[k].cpu(), ref)
 
 
