@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 __global__ __launch_bounds__(256) void map_attn_fwd_kernel(const bf16* __restrict__ q,
                                                            const bf16* __restrict__ kv,
                                                            bf16* __restrict__ o, float* __restrict__ p,
+                                                           const int* __restrict__ kv_len,
                                                            int n, int L, int H, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sp = reinterpret_cast<float*>(smem) + (threadIdx.x >> 6) * L;
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) void map_attn_fwd_kernel(const bf16* __restric
   if (pair >= (long)n * H) return;
   const long i = pair / H;
   const int h = (int)(pair - i * H);
+  const int Lk = kv_len ? min(kv_len[i], L) : L;   // keys >= Lk are padding (NaFlex pool mask): p = 0
   const long ld = 2L * H * DH;
   const bf16* kb_ = kv + i * L * ld + h * DH;
   const bf16* vb_ = kb_ + (long)H * DH;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256) void map_attn_fwd_kernel(const bf16* __restric
              bfhi(a.y) * bfhi(b.y) + bflo(a.z) * bflo(b.z) + bfhi(a.z) * bfhi(b.z) +
              bflo(a.w) * bflo(b.w) + bfhi(a.w) * bfhi(b.w);
     }
-    acc *= scale;
+    acc = l < Lk ? acc * scale : -INFINITY;
     sp[l] = acc;
     mx = fmaxf(mx, acc);
   }
@@ -595,14 +597,21 @@ extern "C" int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float*
   return bv_attn3_bwd(qkv, d_o, lse, delta, dqkv, dbias_rows, kv_len, n, L, H, stream);
 }
 
-extern "C" int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int L, int H,
-                               void* stream) {
+// kv_len (optional, int32 [n]): keys >= kv_len[i] get probability 0 - the pool mask of the NaFlex MAP
+// head (models/proj/image_text/naflex_vit.py:183-199).  The backward needs no mask: it works from the
+// saved probabilities, which are exactly 0 there.
+extern "C" int bv_map_attn_fwd_masked(const void* q, const void* kv, void* o, float* p, const int* kv_len,
+                                      int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0 && L <= 2048, "bv_map_attn_fwd: bad shape n=%d L=%d H=%d", n, L, H);
   const long pairs = (long)n * H;
   hipLaunchKernelGGL(map_attn_fwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256),
                      4 * L * sizeof(float), (hipStream_t)stream, (const bf16*)q, (const bf16*)kv, (bf16*)o, p,
-                     n, L, H, 0.125f);
+                     kv_len, n, L, H, 0.125f);
   return bv_check_launch("bv_map_attn_fwd");
+}
+extern "C" int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int L, int H,
+                               void* stream) {
+  return bv_map_attn_fwd_masked(q, kv, o, p, nullptr, n, L, H, stream);
 }
 
 extern "C" int bv_map_attn_bwd(const void* q, const void* kv, const float* p, const void* d_o, void* dq,

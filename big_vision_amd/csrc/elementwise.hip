@@ -266,6 +266,83 @@ __global__ __launch_bounds__(256) void pool_gap_bwd_kernel(const float* __restri
   }
 }
 
+// gap over the first len[b] rows only (NaFlex: padding excluded, naflex_vit.py:262-264)
+__global__ __launch_bounds__(256) void pool_gap_masked_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  const int* __restrict__ len, int n, int L, int D) {
+  const int D4 = D / 4;
+  const long total = (long)n * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / D4;
+    const int c = (int)(i - b * D4) * 4;
+    const int lb = min(len[b], L);
+    const float inv = 1.0f / (float)lb;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < lb; ++l) {
+      const float4 a = *reinterpret_cast<const float4*>(x + (b * L + l) * D + c);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    *reinterpret_cast<float4*>(y + b * D + c) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+__global__ __launch_bounds__(256) void pool_gap_masked_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  const int* __restrict__ len, int n, int L, int D) {
+  const int D4 = D / 4;
+  const long total = (long)n * L * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / D4;
+    const int c = (int)(i - row * D4) * 4;
+    const long b = row / L;
+    const int l = (int)(row - b * L), lb = min(len[b], L);
+    const float inv = l < lb ? 1.0f / (float)lb : 0.f;
+    const float4 a = *reinterpret_cast<const float4*>(dy + b * D + c);
+    *reinterpret_cast<float4*>(dx + row * D + c) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+  }
+}
+
+// ------------------------------------------------- NaFlex position embedding --
+// models/proj/image_text/naflex_vit.py:38-83 (`_pos_emb_resize`): every example resizes the learned
+// [P, P, D] grid to its own patch grid (h_e, w_e) = max coordinate + 1 with
+// jax.image.scale_and_translate(method="bilinear", antialias=True) and gathers one embedding per
+// token at (yabs, xabs).  Resize + gather are one linear map per token,
+//   emb[t] = sum_ij Wy_e[y_t, i] Wx_e[x_t, j] pos[i, j],
+// so the kernel below only writes the token weights W[t][i*P + j] (bf16, [n*N][P*P]); the product
+// with pos (and, in the backward, W^T dtok) runs on the MFMA GEMMs.  Weights as in
+// jax._src.image.scale.compute_weight_mat: sample position s = (y + 0.5) P / h - 0.5, triangle
+// kernel of width max(P / h, 1), normalised over the input index, zero when s leaves [-0.5, P - 0.5].
+__device__ __forceinline__ float naflex_w(int out_pos, int in_pos, int in_size, int out_size) {
+  const float inv_scale = (float)in_size / (float)out_size;
+  const float kscale = fmaxf(inv_scale, 1.f);
+  const float sf = ((float)out_pos + 0.5f) * inv_scale - 0.5f;
+  if (sf < -0.5f || sf > (float)in_size - 0.5f) return 0.f;
+  float total = 0.f;
+  for (int i = 0; i < in_size; ++i) total += fmaxf(0.f, 1.f - fabsf(sf - (float)i) / kscale);
+  const float w = fmaxf(0.f, 1.f - fabsf(sf - (float)in_pos) / kscale);
+  return fabsf(total) > 1000.f * 1.1920929e-07f ? w / total : 0.f;
+}
+__global__ __launch_bounds__(256) void naflex_posw_kernel(const int* __restrict__ yabs, const int* __restrict__ xabs,
+                                                          bf16* __restrict__ W, int N, int P) {
+  __shared__ int sh[8];
+  __shared__ float wy[64], wx[64];
+  const int e = blockIdx.x;
+  const int* ye = yabs + (long)e * N;
+  const int* xe = xabs + (long)e * N;
+  int my = 0, mx = 0;
+  for (int t = threadIdx.x; t < N; t += 256) { my = max(my, ye[t]); mx = max(mx, xe[t]); }
+  my = (int)wave_max((float)my); mx = (int)wave_max((float)mx);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = my; sh[4 + (threadIdx.x >> 6)] = mx; }
+  __syncthreads();
+  const int h = max(max(sh[0], sh[1]), max(sh[2], sh[3])) + 1;       // shapes = coords.max(axis=1) + 1
+  const int w = max(max(sh[4], sh[5]), max(sh[6], sh[7])) + 1;
+  for (int t = 0; t < N; ++t) {
+    __syncthreads();
+    if (threadIdx.x < P) wy[threadIdx.x] = naflex_w(ye[t], threadIdx.x, P, h);
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + P) wx[threadIdx.x - 64] = naflex_w(xe[t], threadIdx.x - 64, P, w);
+    __syncthreads();
+    bf16* row = W + ((long)e * N + t) * P * P;
+    for (int k = threadIdx.x; k < P * P; k += 256) row[k] = (bf16)(wy[k / P] * wx[k % P]);
+  }
+}
+
 // ------------------------------------------------------------------ l2norm --
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ z,
                                                          float* __restrict__ zn,
@@ -464,6 +541,25 @@ extern "C" int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, 
   hipLaunchKernelGGL(pool_gap_bwd_kernel, dim3(grid_for((long)n * L * D / 4, 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, n, L, D);
   return bv_check_launch("bv_pool_gap_bwd");
+}
+
+extern "C" int bv_pool_gap_masked_fwd(const float* x, float* y, const int* len, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0 && len != nullptr, "bv_pool_gap_masked_fwd: bad arguments");
+  hipLaunchKernelGGL(pool_gap_masked_fwd_kernel, dim3(grid_for((long)n * D / 4, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, len, n, L, D);
+  return bv_check_launch("bv_pool_gap_masked_fwd");
+}
+extern "C" int bv_pool_gap_masked_bwd(const float* dy, float* dx, const int* len, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D % 4 == 0 && len != nullptr, "bv_pool_gap_masked_bwd: bad arguments");
+  hipLaunchKernelGGL(pool_gap_masked_bwd_kernel, dim3(grid_for((long)n * L * D / 4, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, dy, dx, len, n, L, D);
+  return bv_check_launch("bv_pool_gap_masked_bwd");
+}
+// naflex_vit.py:38-83; W [n*N][P*P] bf16, P <= 64
+extern "C" int bv_naflex_posemb_weights(const int* yabs, const int* xabs, void* W, int n, int N, int P, void* stream) {
+  BV_REQUIRE(n > 0 && N > 0 && P > 0 && P <= 64, "bv_naflex_posemb_weights: bad shape n=%d N=%d P=%d", n, N, P);
+  hipLaunchKernelGGL(naflex_posw_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, yabs, xabs, (bf16*)W, N, P);
+  return bv_check_launch("bv_naflex_posemb_weights");
 }
 
 // models/proj/image_text/two_towers.py:60-61,73-74

@@ -230,14 +230,15 @@ class Block:
     self.bo = _W(store, f"{A}/out/bias")
     self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
 
-  def fwd(self, x, n, L, light=False):
-    """light: the saved context drops what the backward can re-derive cheaply - the two
+  def fwd(self, x, n, L, light=False, kv_len=None):
+    """kv_len (int32 [n], optional): key-padding length per sample (NaFlex, naflex_vit.py:84-113).
+    light: the saved context drops what the backward can re-derive cheaply - the two
     LayerNorm outputs (re-normalised from x / x1) and gelu(h) (re-emitted by the fc2 dX
     GEMM) - one third of the block's activation bytes."""
     T, D, H = n * L, self.D, self.H
     y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
-    o, lse = ops.attn_fwd(qkv, n, L, H)
+    o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
     x1 = linear_fwd(o, self.wo, self.bo, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=x)
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
     x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light)
@@ -245,7 +246,7 @@ class Block:
       y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
-  def bwd(self, saved, dx2, dx2_bf, n, L, b2_done=False, next_b2=None):
+  def bwd(self, saved, dx2, dx2_bf, n, L, b2_done=False, next_b2=None, kv_len=None):
     """b2_done: this block's MlpBlock Dense_1 bias gradient was fused into the producer of dx2;
     next_b2: gradient buffer of the PREVIOUS block's Dense_1 bias, to be fused into the
     LayerNorm_0 backward that produces that block's dx2 (bias grads = column sums of dx)."""
@@ -259,7 +260,7 @@ class Block:
     dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad)
     linear_bwd_w(o, dx1_bf, self.wo, None)      # out-proj bias grad = colsum(dx1): fused above
     d_o = linear_bwd_x(dx1_bf, self.wo)
-    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=self.bqkv.grad)   # q/k/v bias grads fused
+    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=self.bqkv.grad, kv_len=kv_len)   # q/k/v bias grads fused
     if y0 is None:
       y0 = self.ln0.fwd(x, T, D)[0]
     linear_bwd_w(y0, dqkv, self.wqkv, None)
@@ -279,11 +280,11 @@ class Encoder:
     self.norm = LN(store, f"{prefix}/encoder_norm")
     self.D = D
 
-  def fwd(self, x, n, L, save, out=None):
+  def fwd(self, x, n, L, save, out=None, kv_len=None):
     saved = []
     for i, blk in enumerate(self.blocks):
       x_in = x
-      x, s = blk.fwd(x, n, L, light=(save == "light"))
+      x, s = blk.fwd(x, n, L, light=(save == "light"), kv_len=kv_len)
       if save:
         saved.append(s)
       if out is not None:
@@ -299,7 +300,7 @@ class Encoder:
     encoder's incoming dx (encoder_norm backward) accumulates its column sums there."""
     return self.blocks[-1].mlp.b2.grad if self.blocks else None
 
-  def bwd(self, saved, dx, dx_bf, n, L, b2_done=False, on_block=None):
+  def bwd(self, saved, dx, dx_bf, n, L, b2_done=False, on_block=None, kv_len=None):
     """on_block(i): called after block i's backward is enqueued; the gradients of blocks >= i
     are final at that point (block i's Dense_1 bias was accumulated earlier, by the kernel
     that produced its incoming dx; block i's backward also finishes block i-1's Dense_1 bias)."""
@@ -307,7 +308,7 @@ class Encoder:
     for i in range(last, -1, -1):
       nb2 = self.blocks[i - 1].mlp.b2.grad if i > 0 else None
       dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L, b2_done=(b2_done if i == last else True),
-                                     next_b2=nb2)
+                                     next_b2=nb2, kv_len=kv_len)
       if on_block is not None:
         on_block(i)
     return dx, dx_bf
@@ -327,12 +328,12 @@ class MAPHead:
     self.ln = LN(store, f"{prefix}/LayerNorm_0")
     self.mlp = MLP(store, f"{prefix}/MlpBlock_0", D, M)
 
-  def fwd(self, y_bf, n, L):
+  def fwd(self, y_bf, n, L, kv_len=None):
     D, H = self.D, self.H
     probe_t = self.probe.bf.expand(n, D).contiguous()
     q = linear_fwd(probe_t, self.wq, self.bq, out_dtype=BF16)
     kv = linear_fwd(y_bf, self.wkv, self.bkv, out_dtype=BF16)
-    o, p = ops.map_attn_fwd(q, kv, n, L, H)
+    o, p = ops.map_attn_fwd(q, kv, n, L, H, kv_len=kv_len)
     a = linear_fwd(o, self.wo, self.bo, out_dtype=F32)
     yl, _, mean, rstd = self.ln.fwd(a, n, D)
     z, h, g = self.mlp.fwd(yl, a)

@@ -140,7 +140,8 @@ class Model:
   def init(self, rng, image, text=None, **kw):
     del kw
     from big_vision_amd.models.vit import _seed_of
-    store = self.make_store(tuple(image.shape), tuple(text.shape))
+    ishape = tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape)
+    store = self.make_store(ishape, tuple(text.shape))
     store.init_random(_seed_of(rng))
     store.refresh_shadow()
     return {"params": store.tree()}
@@ -161,13 +162,14 @@ class Model:
     else:
       if image is None or text is None:
         raise ValueError("ad-hoc parameter trees need both inputs to size the store")
-      ishape, tshape = tuple(image.shape), tuple(text.shape)
+      ishape = tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape)
+      tshape = tuple(text.shape)
       store = adhoc_store(self._execs, ("two_towers", ishape[1:], tshape[1:], torch.cuda.current_device()),
                           params, lambda: self.make_store(ishape, tshape))
       prefix = ""
     store.refresh_shadow()
-    ex = self.executor(store, prefix, None if image is None else tuple(image.shape),
-                       None if text is None else tuple(text.shape))
+    ishape = None if image is None else (tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape))
+    ex = self.executor(store, prefix, ishape, None if text is None else tuple(text.shape))
     zimg, ztxt, out, _ = ex.fwd(image, text, save=False, collect=collect)
     return zimg, ztxt, out
 

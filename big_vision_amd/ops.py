@@ -164,12 +164,17 @@ def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None, kv_len=None):
   return dqkv
 
 
-def map_attn_fwd(q, kv, n, L, H):
+def map_attn_fwd(q, kv, n, L, H, kv_len=None):
+  """kv_len (int32 [n], optional): valid keys per sample (NaFlex pool mask)."""
   _chk(q, BF16, "map_attn.q"); _chk(kv, BF16, "map_attn.kv")
   assert q.is_contiguous() and kv.is_contiguous()
   o = torch.empty((n, H * 64), device=q.device, dtype=BF16)
   p = torch.empty((n, H, L), device=q.device, dtype=F32)
-  _lib.call("bv_map_attn_fwd", _p(q), _p(kv), _p(o), _p(p), n, L, H, _stream())
+  if kv_len is not None:
+    _chk(kv_len, torch.int32, "map_attn.kv_len")
+    _lib.call("bv_map_attn_fwd_masked", _p(q), _p(kv), _p(o), _p(p), _p(kv_len), n, L, H, _stream())
+  else:
+    _lib.call("bv_map_attn_fwd", _p(q), _p(kv), _p(o), _p(p), n, L, H, _stream())
   return o, p
 
 
@@ -248,16 +253,33 @@ def concat_cls(cls, x, n, L, D):
   return y
 
 
-def pool_gap_fwd(x, n, L, D):
+def pool_gap_fwd(x, n, L, D, lens=None):
+  """lens (int32 [n], optional): average over the first lens[b] tokens only (NaFlex)."""
   y = torch.empty((n, D), device=x.device, dtype=F32)
-  _lib.call("bv_pool_gap_fwd", _p(x), _p(y), n, L, D, _stream())
+  if lens is not None:
+    _lib.call("bv_pool_gap_masked_fwd", _p(x), _p(y), _p(lens), n, L, D, _stream())
+  else:
+    _lib.call("bv_pool_gap_fwd", _p(x), _p(y), n, L, D, _stream())
   return y
 
 
-def pool_gap_bwd(dy, n, L, D):
+def pool_gap_bwd(dy, n, L, D, lens=None):
   dx = torch.empty((n * L, D), device=dy.device, dtype=F32)
-  _lib.call("bv_pool_gap_bwd", _p(dy), _p(dx), n, L, D, _stream())
+  if lens is not None:
+    _lib.call("bv_pool_gap_masked_bwd", _p(dy), _p(dx), _p(lens), n, L, D, _stream())
+  else:
+    _lib.call("bv_pool_gap_bwd", _p(dy), _p(dx), n, L, D, _stream())
   return dx
+
+
+def naflex_posemb_weights(yabs, xabs, P):
+  """[n*N, P*P] bf16 resize-and-gather weights of the NaFlex position embedding (bv_naflex_posemb_weights)."""
+  _chk(yabs, torch.int32, "naflex.yabs"); _chk(xabs, torch.int32, "naflex.xabs")
+  assert yabs.is_contiguous() and xabs.is_contiguous() and yabs.shape == xabs.shape
+  n, N = yabs.shape
+  W = torch.empty((n * N, P * P), device=yabs.device, dtype=BF16)
+  _lib.call("bv_naflex_posemb_weights", _p(yabs), _p(xabs), _p(W), n, N, P, _stream())
+  return W
 
 
 def l2norm_fwd(z, eps=1e-8):

@@ -29,6 +29,16 @@ from big_vision_amd import utils as u
 F32 = torch.float32
 
 
+def _img_shape(images):
+  """Shape that keys the image tower's layout: [n, H, W, 3] pixels, or - NaFlex
+  (models/proj/image_text/naflex_vit.py:227) - the patches of the (patches, ptype, yabs, xabs) tuple."""
+  return tuple(images[0].shape) if isinstance(images, (tuple, list)) else tuple(images.shape)
+
+
+def _img_slice(images, a, b):
+  return tuple(t[a:b] for t in images) if isinstance(images, (tuple, list)) else images[a:b]
+
+
 def sigmoid_loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm: dp.Comm):
   """Global-batch pairwise sigmoid loss (siglip.py:291-306) and its gradients.
 
@@ -105,8 +115,8 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     # marks the bf16 shadow dirty; forward and backward read the shadow (no-op when clean)
     store.refresh_shadow()
     store.zero_grad()
-    n = images.shape[0]
-    ex = model.executor(store, "", tuple(images.shape[:1]) + tuple(images.shape[1:]), tuple(labels.shape))
+    n = _img_shape(images)[0]
+    ex = model.executor(store, "", _img_shape(images), tuple(labels.shape))
     img_frozen = all(e in store.frozen for e in store.entries if e.startswith("img/"))
     txt_frozen = all(e in store.frozen for e in store.entries if e.startswith("txt/"))
     t_param = store.t("t")
@@ -123,7 +133,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
       # full contexts do not all fit, "light" contexts are kept instead (engine.Block.fwd:
       # LayerNorm outputs and gelu(h) are re-derived by the backward, 1/3 fewer bytes).
       starts = list(range(0, n, micro))
-      dev = images.device
+      dev = labels.device
       keep_cfg = config.get("microbatch_keep", "auto")
       keep_max = len(starts) if keep_cfg in ("all", "auto") else (0 if keep_cfg in (0, "none") else int(keep_cfg))
       light_cfg = config.get("microbatch_light", "auto")
@@ -145,7 +155,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         per_ctx = state_cache["per_ctx"].get(mode)
         keep = len(kept) < keep_max and (per_ctx is None or keep_cfg == "all" or fits(per_ctx, 1))
         before = torch.cuda.memory_allocated(dev)
-        a, b, o_, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=(mode if keep else False))
+        a, b, o_, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=(mode if keep else False))
         norms.append((o_.get("img/norm"), o_.get("txt/norm")))
         if keep and per_ctx is None:
           per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
@@ -156,7 +166,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
               del c
               mode = "light"
               before = torch.cuda.memory_allocated(dev)
-              a, b, _, c = ex.fwd(images[s:s + micro], labels[s:s + micro], save=mode)
+              a, b, _, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=mode)
               state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
         if keep:
           kept[s] = c
@@ -171,7 +181,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
       for s in starts:
         ctx = kept.pop(s, None)
         if ctx is None:
-          _, _, _, ctx = ex.fwd(images[s:s + micro], labels[s:s + micro],
+          _, _, _, ctx = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro],
                                 save=("light" if state_cache["light"] else True))
         ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
                None if txt_frozen else dztxt[s:s + micro].contiguous(),

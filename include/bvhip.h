@@ -182,6 +182,20 @@ int bv_map_attn_fwd(const void* q, const void* kv, void* o, float* p, int n, int
                     void* stream);
 int bv_map_attn_bwd(const void* q, const void* kv, const float* p, const void* d_o, void* dq,
                     void* dkv, int n, int L, int H, void* stream);
+/* The same with the NaFlex pool mask (naflex_vit.py:183-199, :262-263): keys >= kv_len[i] (int32 [n])
+ * get probability 0; bv_map_attn_bwd needs no mask (it works from the saved probabilities). */
+int bv_map_attn_fwd_masked(const void* q, const void* kv, void* o, float* p, const int* kv_len, int n, int L,
+                           int H, void* stream);
+/* Masked global average pooling of the NaFlex tower (naflex_vit.py:264-266): mean over the first
+ * len[b] tokens of [n][L][D] fp32; the backward writes dy / len[b] to those rows, 0 to the padding. */
+int bv_pool_gap_masked_fwd(const float* x, float* y, const int* len, int n, int L, int D, void* stream);
+int bv_pool_gap_masked_bwd(const float* dy, float* dx, const int* len, int n, int L, int D, void* stream);
+/* NaFlex position embedding (naflex_vit.py:38-83): per token t of example e the weights of
+ * jax.image.scale_and_translate(bilinear, antialias) from the learned [P][P] grid to the example's
+ * own patch grid (max coordinate + 1 per axis), gathered at (yabs, xabs):
+ * W[e*N + t][i*P + j] = Wy_e[yabs[t]][i] * Wx_e[xabs[t]][j] (bf16).  The embedding of a token is
+ * W[t] . pos[P*P][D] and d pos = W^T d tok: both run on bv_gemm_bf16.  P <= 64. */
+int bv_naflex_posemb_weights(const int* yabs, const int* xabs, void* W, int n, int N, int P, void* stream);
 
 /* ---------------------------------------------------------- Patch / embed --
  * NHWC fp32 image [n][Hi][Wi][3] -> bf16 patch matrix [n*h*w][P*P*3] in HWIO

@@ -129,11 +129,13 @@ def gelu_tanh(x):
   return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
 
 
-def mha(xq, xkv, p, num_heads):
+def mha(xq, xkv, p, num_heads, mask=None):
   """flax.linen.MultiHeadDotProductAttention (models/vit.py:93-98, :176-178).
 
   q/k/v kernels (D,H,Dh) + bias (H,Dh); out kernel (H,Dh,D) + bias (D).
-  query scaled by 1/sqrt(Dh) before the dot; softmax over keys; no mask.
+  query scaled by 1/sqrt(Dh) before the dot; softmax over keys.  mask (bool, broadcastable to
+  [n, heads, q, k], flax.linen.attention.dot_product_attention_weights): masked logits are replaced
+  by the most negative finite value, so a fully masked row attends uniformly (naflex_vit.py:96-104).
   """
   q = contract("nld,dhk->nlhk", xq, p["query"]["kernel"]) + p["query"]["bias"]
   k = contract("nld,dhk->nlhk", xkv, p["key"]["kernel"]) + p["key"]["bias"]
@@ -144,6 +146,8 @@ def mha(xq, xkv, p, num_heads):
   else:
     q = q / math.sqrt(dh)
     s = contract("nqhd,nkhd->nhqk", q, k)
+  if mask is not None:
+    s = torch.where(mask, s, torch.full_like(s, torch.finfo(s.dtype).min))
   a = torch.softmax(s, dim=-1)
   o = contract("nhqk,nkhd->nqhd", a, v)
   return contract("nlhk,hkd->nld", o, p["out"]["kernel"]) + p["out"]["bias"]
@@ -154,11 +158,12 @@ def mlp_block(x, p):
   return dense(gelu_tanh(dense(x, p["Dense_0"])), p["Dense_1"])
 
 
-def encoder_block(x, p, num_heads):
-  """models/vit.py:81-112 (Encoder1DBlock), dropout=0."""
+def encoder_block(x, p, num_heads, mask=None):
+  """models/vit.py:81-112 (Encoder1DBlock), dropout=0; mask [n, q, k] as naflex_vit.py:92-94."""
   out = {}
   y = layernorm(x, p["LayerNorm_0"])
-  y = out["sa"] = mha(y, y, p["MultiHeadDotProductAttention_0"], num_heads)
+  y = out["sa"] = mha(y, y, p["MultiHeadDotProductAttention_0"], num_heads,
+                      mask=None if mask is None else mask[:, None])
   x = out["+sa"] = x + y
   y = layernorm(x, p["LayerNorm_1"])
   y = out["mlp"] = mlp_block(y, p["MlpBlock_0"])
@@ -166,28 +171,101 @@ def encoder_block(x, p, num_heads):
   return x, out
 
 
-def encoder(x, p, depth, num_heads):
+def encoder(x, p, depth, num_heads, mask=None):
   """models/vit.py:115-160 (Encoder); accepts loop and scan param layouts."""
   out = {}
   if "encoderblock" in p:  # scan layout: leading depth axis (vit.py:129-148)
     for lyr in range(depth):
       pl = tree_map(lambda t, l=lyr: t[l], p["encoderblock"])
-      x, out[f"block{lyr:02d}"] = encoder_block(x, pl, num_heads)
+      x, out[f"block{lyr:02d}"] = encoder_block(x, pl, num_heads, mask)
   else:
     for lyr in range(depth):
-      x, out[f"block{lyr:02d}"] = encoder_block(x, p[f"encoderblock_{lyr}"], num_heads)
+      x, out[f"block{lyr:02d}"] = encoder_block(x, p[f"encoderblock_{lyr}"], num_heads, mask)
     out["pre_ln"] = x
   return layernorm(x, p["encoder_norm"]), out
 
 
-def map_head(x, p, num_heads):
-  """models/vit.py:163-183 (MAPHead)."""
+def map_head(x, p, num_heads, mask=None):
+  """models/vit.py:163-183 (MAPHead); mask [n, k] = pool mask of naflex_vit.py:183-199."""
   n = x.shape[0]
   probe = p["probe"].expand(n, -1, -1)
-  x = mha(probe, x, p["MultiHeadDotProductAttention_0"], num_heads)
+  x = mha(probe, x, p["MultiHeadDotProductAttention_0"], num_heads,
+          mask=None if mask is None else mask[:, None, None, :])
   y = layernorm(x, p["LayerNorm_0"])
   x = x + mlp_block(y, p["MlpBlock_0"])
   return x[:, 0]
+
+
+def scale_and_translate_weights(input_size, output_size, scale, translation=0.0, antialias=True,
+                                dtype=torch.float64):
+  """jax._src.image.scale.compute_weight_mat for the triangle ("bilinear") kernel: [input_size,
+  output_size] (jax is an un-vendored dependency of the reference; this restates its published
+  algorithm, pinned in tests against torch's antialiased bilinear interpolate)."""
+  inv_scale = 1.0 / scale
+  kernel_scale = max(inv_scale, 1.0) if antialias else 1.0
+  sample_f = (torch.arange(output_size, dtype=dtype) + 0.5) * inv_scale - translation * inv_scale - 0.5
+  x = (sample_f[None, :] - torch.arange(input_size, dtype=dtype)[:, None]).abs() / kernel_scale
+  w = torch.clamp(1.0 - x, min=0.0)
+  total = w.sum(0, keepdim=True)
+  w = torch.where(total.abs() > 1000.0 * 1.1920929e-07, w / torch.where(total != 0, total, torch.ones_like(total)),
+                  torch.zeros_like(w))
+  ok = (sample_f >= -0.5) & (sample_f <= input_size - 0.5)
+  return torch.where(ok[None, :], w, torch.zeros_like(w))
+
+
+def naflex_pos_emb_resize(pos_emb, yabs, xabs, l=64):
+  """models/proj/image_text/naflex_vit.py:38-83: per example resize the [P, P, D] grid to its patch
+  grid (coords.max + 1) inside an l x l canvas and gather at (yabs, xabs)."""
+  P = pos_emb.shape[0]
+  outs = []
+  for e in range(yabs.shape[0]):
+    h, w = int(yabs[e].max()) + 1, int(xabs[e].max()) + 1
+    wy = scale_and_translate_weights(P, l, h / P, dtype=pos_emb.dtype)
+    wx = scale_and_translate_weights(P, l, w / P, dtype=pos_emb.dtype)
+    emb = torch.einsum("iy,jx,ijd->yxd", wy, wx, pos_emb)
+    outs.append(emb[yabs[e].long(), xabs[e].long()])
+  return torch.stack(outs)
+
+
+def naflex_vit_forward(params, image, *, num_classes=None, width=768, depth=12, mlp_dim=None, num_heads=12,
+                       rep_size=False, pool_type="gap", posemb="learn_2d(64)", nposemb=None, patchln_pre=False,
+                       patchln_post=False, variant=None, **unused):
+  """models/proj/image_text/naflex_vit.py:200-285 (_Model.__call__), dropout 0."""
+  del unused, mlp_dim, nposemb
+  if variant is not None:
+    dv = decode_variant(variant)
+    width, depth, num_heads = dv["width"], dv["depth"], dv["num_heads"]
+  patches, ptype, yabs, xabs = image
+  out = {}
+  x = patches
+  if patchln_pre:
+    x = layernorm(x, params["patchln_pre"])
+  tokens = out["stem"] = dense(x, params["embedding"])
+  if patchln_post:
+    tokens = layernorm(tokens, params["patchln_post"])
+  grid = int(posemb[len("learn_2d("):-1]) if posemb.startswith("learn_2d(") else 64
+  x = out["with_posemb"] = tokens + naflex_pos_emb_resize(params["pos_embedding"], yabs, xabs, grid)
+  valid = ptype == 1
+  sa_mask = valid[:, :, None] & valid[:, None, :]
+  x, out["encoder"] = encoder(x, params["Transformer"], depth, num_heads, mask=sa_mask)
+  out["encoded"] = x
+  if pool_type == "map":
+    x = map_head(x, params["MAPHead_0"], num_heads, mask=valid)
+  elif pool_type == "gap":
+    pm = valid[..., None].to(x.dtype)
+    x = (x * pm).sum(1) / pm.sum(1)
+  elif pool_type == "max":
+    pm = valid[..., None]
+    x = torch.where(pm, x, torch.full_like(x, torch.finfo(x.dtype).min)).max(dim=1).values
+  elif pool_type != "none":
+    raise ValueError(pool_type)
+  out["head_input"] = x
+  if rep_size:
+    x = torch.tanh(dense(x, params["pre_logits"]))
+  out["pre_logits"] = x
+  if num_classes:
+    x = out["logits"] = dense(x, params["head"])
+  return x, out
 
 
 def posemb_sincos_2d(h, w, width, temperature=10_000.0, dtype=torch.float32):

@@ -63,7 +63,7 @@ def test_loaded_checkpoint_reaches_the_kernels(dev, tmp_path, scan):
   assert torch.equal(names[k].cpu(), ref)
 
 
-def test_train_state_roundtrip_resumes_bit_exactly(dev, tmp_path):
+def test_train_state_roundtrip_resumes(dev, tmp_path):
   import bv_oracle as O
   from big_vision_amd import utils as u
   from big_vision_amd.compat.ml_collections import ConfigDict
@@ -79,12 +79,22 @@ def test_train_state_roundtrip_resumes_bit_exactly(dev, tmp_path):
   state, _ = fn(state, None, batch)
   f = str(tmp_path / "state.npz")
   u.save_train_state(f, state)
+  saved = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
+  saved_mu, saved_nu, saved_count = state["opt"].mu.clone(), state["opt"].nu.clone(), state["opt"].count
   state, m2 = fn(state, None, batch)
   after = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
-  # fresh state, resumed from the file: the next step must reproduce step 2 exactly
+  # fresh state (other seed), resumed from the file: parameters, both Adam moments and the step count
+  # come back bit for bit
   state_b, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=5, total_steps=10)
   u.load_train_state(f, state_b)
+  for k, v in u.tree_flatten_with_names(state_b["params"])[0]:
+    assert torch.equal(v, saved[k]), k
+  assert torch.equal(state_b["opt"].mu, saved_mu) and torch.equal(state_b["opt"].nu, saved_nu)
+  assert state_b["opt"].count == saved_count == 1
+  # ... and the next step is the step the original run took: identical loss (the forward is
+  # deterministic); parameters equal up to the fp32-atomic bias-gradient sums, which may flip the
+  # sign of an Adam update of a near-zero gradient (one update = lr * schedule = 5e-4 here)
   state_b, m2b = siglip.make_update_fn(model, c)(state_b, None, batch)
   assert m2["training_loss"].item() == m2b["training_loss"].item()
-  for k, v in u.tree_flatten_with_names(state_b["params"])[0]:
-    assert torch.equal(v, after[k]), k
+  worst = max((v - after[k]).abs().max().item() for k, v in u.tree_flatten_with_names(state_b["params"])[0])
+  assert worst <= 2 * 5e-4 + 1e-6, worst

@@ -1,0 +1,133 @@
+"""NaFlex ViT tower (models/proj/image_text/naflex_vit.py:200-293) on the GPU against the fp64 oracle:
+variable patch grids per example, padding at the end of the sequence, learned 2-D position grid
+resized per example (bilinear antialias) and gathered at the patch coordinates, key-padding mask in
+every attention, masked MAP / gap pooling.  Checked: pooled output, every parameter gradient
+(tests/_parity.py bounds), zero influence of the padding tokens' CONTENT, and a SigLIP step with the
+NaFlex tower as the image model of two_towers."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PATCH = 8                      # 8 x 8 x 3 = 192 values per patch
+GRIDS = [(4, 6), (6, 6), (3, 5), (6, 2), (5, 5), (1, 6)]      # (h, w) patches per example, N = 36 slots
+
+
+def _batch(seed, grids=GRIDS, N=36):
+  g = torch.Generator().manual_seed(seed)
+  n = len(grids)
+  patches = torch.zeros((n, N, PATCH * PATCH * 3))
+  ptype = torch.zeros((n, N), dtype=torch.int32)
+  yabs = torch.zeros((n, N), dtype=torch.int32)
+  xabs = torch.zeros((n, N), dtype=torch.int32)
+  for e, (h, w) in enumerate(grids):
+    k = h * w
+    patches[e, :k] = torch.rand((k, PATCH * PATCH * 3), generator=g) * 2 - 1
+    ptype[e, :k] = 1
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    yabs[e, :k], xabs[e, :k] = yy.flatten().int(), xx.flatten().int()
+  return patches, ptype, yabs, xabs
+
+
+def _case(dev, cfg, case):
+  import bv_oracle as O
+  import _parity
+  from big_vision_amd import utils as u
+  from big_vision_amd.models.proj.image_text import naflex_vit
+  from big_vision_amd.params import ParamStore
+  model = naflex_vit.Model(None, **cfg)
+  image = _batch(3)
+  n = image[0].shape[0]
+  pd = image[0].shape[-1]
+  store = ParamStore(model.entries("", pd), dev)
+  store.init_random(0)
+  g = torch.Generator().manual_seed(11)
+  for name in store.leaf_names():
+    if name.endswith(("bias", "scale")):
+      leaf = store.leaf(name)
+      leaf.add_((0.05 * torch.randn(leaf.shape, generator=g)).to(dev))
+  store.mark_dirty(); store.refresh_shadow()
+  store.want_grads = True
+  store.zero_grad()
+  params64 = O.recover_tree([(k, v.detach().cpu().double().clone().requires_grad_(True))
+                             for k, v in u.tree_flatten_with_names(store.tree())[0]])
+  img64 = (image[0].double(),) + image[1:]
+
+  def loss_of(p):
+    z, _ = O.naflex_vit_forward(p, img64, **cfg)
+    return 0.5 * (z ** 2).sum() / n, z
+
+  loss_ref, z_ref = loss_of(params64)
+  ex = model.executor(store, "", pd)
+  img_d = tuple(t.to(dev) for t in image)
+  z, _, ctx = ex.fwd(img_d, save=True)
+  scale = max(1.0, z_ref.abs().max().item())
+  assert (z.cpu().double() - z_ref.detach()).abs().max().item() <= 2e-2 * scale
+  ex.bwd(ctx, (z / n).contiguous())
+  torch.cuda.synchronize()
+  loss_ref.backward()
+  gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0]}
+  gours = {k: v.detach().cpu().double() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
+  fl = _parity.bf16_floor(lambda p: loss_of(p)[0], params64)
+  _parity.compare_grads(case, gref, gours, floor=fl)
+  # the CONTENT of padding slots must not matter: garbage there, same pooled output
+  junk = image[0].clone()
+  junk[image[1] == 0] = 37.0
+  z2, _, _ = ex.fwd((junk.to(dev),) + img_d[1:], save=False)
+  assert torch.equal(z2, z) or (z2 - z).abs().max().item() <= 1e-6 * scale
+
+
+def test_naflex_map_pooling(dev):
+  _case(dev, dict(width=128, depth=2, mlp_dim=256, num_heads=2, pool_type="map", nposemb=8, posemb="learn_2d(16)"),
+        "NaFlex tiny MAP n=6 ragged grids")
+
+
+def test_naflex_gap_patchln_head(dev):
+  _case(dev, dict(width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="gap", nposemb=8, posemb="learn_2d(16)",
+                  patchln_pre=True, patchln_post=True, rep_size=True),
+        "NaFlex tiny gap + patchln + pre_logits")
+
+
+def test_naflex_mask_must_be_a_prefix(dev):
+  from big_vision_amd.models.proj.image_text import naflex_vit
+  from big_vision_amd.params import ParamStore
+  model = naflex_vit.Model(None, width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="gap", nposemb=8)
+  patches, ptype, yabs, xabs = _batch(1)
+  store = ParamStore(model.entries("", patches.shape[-1]), dev)
+  store.init_random(0); store.refresh_shadow()
+  ptype[0, 0] = 0          # a hole at the front
+  with pytest.raises(NotImplementedError, match="prefix"):
+    model.executor(store, "", patches.shape[-1]).fwd(tuple(t.to(dev) for t in (patches, ptype, yabs, xabs)))
+
+
+def test_siglip_step_with_naflex_image_tower(dev):
+  """two_towers(image_model='proj.image_text.naflex_vit') through the SigLIP trainer: loss vs the oracle,
+  finite measurements, text tower and NaFlex tower both updated."""
+  import bv_oracle as O
+  from big_vision_amd import utils as u
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  icfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="map", nposemb=8, posemb="learn_2d(16)")
+  tcfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, vocab_size=64)
+  model = two_towers.Model(image=icfg, text=tcfg, image_model="proj.image_text.naflex_vit", out_dim=(None, 128),
+                           temperature_init=10.0, bias_init=-10.0)
+  c = ConfigDict(dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
+                      schedule=dict(decay_type="cosine", warmup_steps=2)))
+  image = _batch(5)
+  n = image[0].shape[0]
+  _, text = O.synthetic_batch(2, n, 32, 8, 64)
+  state, _ = siglip.make_train_state(model, c, tuple(image[0].shape), tuple(text.shape), rng=0, total_steps=10)
+  p64 = O.recover_tree([(k, v.detach().cpu().double()) for k, v in u.tree_flatten_with_names(state["params"])[0]])
+  zi, _ = O.naflex_vit_forward(p64["img"], (image[0].double(),) + image[1:], num_classes=None, **icfg)
+  zt, _ = O.text_forward(p64["txt"], text, num_classes=128, **tcfg)
+  zi, zt = zi / (zi.norm(dim=-1, keepdim=True) + 1e-8), zt / (zt.norm(dim=-1, keepdim=True) + 1e-8)
+  ref, _ = O.siglip_loss_global(zi, zt, torch.exp(p64["t"][0]), p64["b"][0])
+  state, meas = siglip.make_update_fn(model, c)(state, None, {"image": tuple(t.to(dev) for t in image), "labels": text.to(dev)})
+  assert abs(meas["training_loss"].item() - ref.item()) <= 1e-2 * abs(ref.item())
+  siglip.check_finite(meas)
+  grads = dict(u.tree_flatten_with_names(state["params"].store.tree("grad"))[0])      # (step 0 of the warm-up has lr 0)
+  for k in ("img/pos_embedding", "img/embedding/kernel", "img/MAPHead_0/probe", "txt/Embed_0/embedding"):
+    assert grads[k].abs().max().item() > 0, k
