@@ -23,16 +23,22 @@ import torch.distributed as dist
 
 
 class Comm:
-  def __init__(self, group=None):
+  def __init__(self, group=None, force=None):
+    """force (default: env BV_DP_FORCE_COLLECTIVES=1): issue the collectives even in a group of ONE
+    rank - a one-GPU box can then run the whole RCCL call path (all_gather_into_tensor,
+    reduce_scatter_tensor, bucketed all-reduce on the side stream) that N > 1 takes."""
     self.enabled = dist.is_available() and dist.is_initialized()
     self.group = group
     self.rank = dist.get_rank(group) if self.enabled else 0
     self.size = dist.get_world_size(group) if self.enabled else 1
+    if force is None:
+      force = os.environ.get("BV_DP_FORCE_COLLECTIVES", "0") == "1"
+    self.active = self.enabled and (self.size > 1 or bool(force))
 
   # ------------------------------------------------------------ embeddings --
   def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
     """[n, E] on every rank -> [size*n, E], rank r's rows at [r*n, (r+1)*n)."""
-    if self.size == 1:
+    if not self.active:
       return x
     out = torch.empty((self.size * x.shape[0],) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
     dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
@@ -40,7 +46,7 @@ class Comm:
 
   def reduce_scatter_rows(self, x: torch.Tensor) -> torch.Tensor:
     """[size*n, E] partial sums -> this rank's [n, E] block of the total."""
-    if self.size == 1:
+    if not self.active:
       return x
     n = x.shape[0] // self.size
     out = torch.empty((n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
@@ -59,18 +65,18 @@ class Comm:
     xGMI is point-to-point (7 links/GPU); RCCL picks its own ring/tree/direct
     algorithm per message, large messages amortise launch latency.
     """
-    if self.size == 1:
+    if not self.active:
       return
     step = max(1, bucket_bytes // flat.element_size())
     for off in range(0, flat.numel(), step):
       dist.all_reduce(flat[off:off + step], group=self.group)
 
   def all_reduce_scalars_(self, t: torch.Tensor):
-    if self.size > 1:
+    if self.active:
       dist.all_reduce(t, group=self.group)
 
   def barrier(self):
-    if self.size > 1:
+    if self.active:
       dist.barrier(group=self.group)
 
 
@@ -88,11 +94,11 @@ class GradSync:
   def __init__(self, comm: Comm, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
     self.comm, self.flat, self.bucket_bytes = comm, flat, bucket_bytes
     self.done = []   # disjoint [lo, hi) already handed to the collective
-    self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and comm.size > 1) else None
+    self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and comm.active) else None
 
   def launch(self, lo: int, hi: int):
     lo, hi = max(0, int(lo)), min(int(hi), self.flat.numel())
-    if self.comm.size == 1 or hi <= lo:
+    if not self.comm.active or hi <= lo:
       return
     for a, b in self.done:
       assert hi <= a or lo >= b, f"gradient range [{lo},{hi}) overlaps an already reduced range [{a},{b})"
@@ -106,9 +112,25 @@ class GradSync:
       self.stream.wait_event(ready)
       self.comm.all_reduce_sum_(self.flat[lo:hi], self.bucket_bytes)
 
+  def launch_gaps(self, lo: int, hi: int):
+    """Hands every not yet launched part of [lo, hi) to the collective (e.g. what is left of a tower
+    once its backward is enqueued: embeddings, final norm, head)."""
+    lo, hi = max(0, int(lo)), min(int(hi), self.flat.numel())
+    pos = lo
+    for a, b in sorted(self.done) + [(hi, hi)]:
+      if b <= pos:
+        continue
+      if a >= hi:
+        a = hi
+      if a > pos:
+        self.launch(pos, a)
+      pos = max(pos, b)
+      if pos >= hi:
+        break
+
   def finish(self):
     """Reduces the complement of the launched ranges, then joins the side stream."""
-    if self.comm.size == 1:
+    if not self.comm.active:
       return
     pos = 0
     for a, b in sorted(self.done) + [(self.flat.numel(), self.flat.numel())]:
@@ -123,7 +145,8 @@ class GradSync:
 def init_from_env(backend: str | None = None) -> Comm:
   """Initialises torch.distributed from torchrun-style env vars (if present)."""
   world = int(os.environ.get("WORLD_SIZE", "1"))
-  if world > 1 and not dist.is_initialized():
+  force = os.environ.get("BV_DP_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
+  if (world > 1 or force) and not dist.is_initialized():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -28,6 +28,7 @@ class TwoTowersExec:
     self.m, self.store = m, store
     self.img = m.image_tower.executor(store, f"{prefix}img/", hw) if hw is not None else None
     self.txt = m.text_tower.executor(store, f"{prefix}txt/", seq_len) if seq_len is not None else None
+    self.prefix, self._ranges = prefix, {}
     self.t = E._W(store, f"{prefix}t")
     self.b = E._W(store, f"{prefix}b") if m.bias_init is not None else None
 
@@ -54,33 +55,54 @@ class TwoTowersExec:
       out["b"] = self.b.f32
     return zimg, ztxt, out, (ctx if save else None)
 
+  def _block_ranges(self, tower, enc):
+    """{block index: [lo, hi) of its gradients in the flat buffer} for `tower` ('img/' | 'txt/')."""
+    key = (tower, enc)
+    if key not in self._ranges:
+      tw = self.m.image_tower if tower.endswith("img/") else self.m.text_tower
+      out = {}
+      for i in range(getattr(tw, "depth", 0)):
+        r = self.store.grad_range(lambda n, p=f"{tower}{enc}/encoderblock_{i}/": n.startswith(p))
+        if r is not None:
+          out[i] = r
+      self._ranges[key] = out
+    return self._ranges[key]
+
   def bwd(self, ctx, dzimg, dztxt, sync=None):
     """dzimg / dztxt: gradients w.r.t. the NORMALISED embeddings (None = tower skipped).
     sync (dp.GradSync, last backward of a step on N > 1 ranks): gradient ranges are handed to
-    the all-reduce as soon as they are final - the whole text tower once its backward is
-    enqueued, the upper half of the image tower (blocks depth/2.., encoder_norm, MAP head)
-    half-way through the image backward - so RCCL overlaps the remaining GEMMs."""
+    the all-reduce as soon as they are final - every encoder block right after its backward is
+    enqueued (28 MB per B/16 block: 24 + 24 messages that RCCL runs next to the remaining
+    GEMMs), the rest of the text tower (embedding table, final norm, head) when the text backward
+    is done, the image tower's final norm / MAP head together with its last block; what is left
+    (stem, position embedding, t, b) is reduced by sync.finish()."""
     store = self.store
     if dztxt is not None and "txt" in ctx:
       c, z, norm = ctx["txt"]
-      self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt))
+      on_block = None
       if sync is not None:
-        r = store.grad_range(lambda n: n.startswith("txt/"))
+        rt = self._block_ranges(f"{self.prefix}txt/", "Encoder_0")
+        on_block = lambda i, rt=rt: sync.launch(*rt[i]) if i in rt else None
+      self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt), on_block=on_block)
+      if sync is not None:
+        r = store.grad_range(lambda n: n.startswith(f"{self.prefix}txt/"))
         if r is not None:
-          sync.launch(*r)
+          sync.launch_gaps(*r)
     if dzimg is not None and "img" in ctx:
       c, z, norm = ctx["img"]
       on_block = None
-      half = getattr(self.m.image_tower, "depth", 0) // 2
-      if sync is not None and half > 0:
-        def upper(n, half=half):
-          if not n.startswith("img/") or n.startswith(("img/embedding", "img/pos_embedding", "img/cls")):
-            return False
-          k = n.split("encoderblock_")
-          return len(k) == 1 or int(k[1].split("/")[0]) >= half
-        rng = store.grad_range(upper)
-        if rng is not None:
-          on_block = lambda i, rng=rng, half=half: sync.launch(*rng) if i == half else None
+      if sync is not None:
+        ri = self._block_ranges(f"{self.prefix}img/", "Transformer")
+        stem = tuple(f"{self.prefix}img/{k}" for k in ("embedding", "pos_embedding", "cls", "patchln_pre", "patchln_post"))
+        tail = store.grad_range(lambda n: n.startswith(f"{self.prefix}img/") and "/encoderblock_" not in n
+                                and not n.startswith(stem))
+        last = max(ri) if ri else None
+
+        def on_block(i, ri=ri, tail=tail, last=last):
+          if i == last and tail is not None:
+            sync.launch(*tail)          # final norm + pooling head: final before the first block's backward
+          if i in ri:
+            sync.launch(*ri[i])
       self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg), on_block=on_block)
 
 

@@ -1,0 +1,88 @@
+"""The N > 1 path over RCCL (torch.distributed backend "nccl"), which the gloo tests cannot reach:
+  * ONE rank on one GPU with the collectives forced on (BV_DP_FORCE_COLLECTIVES=1): every RCCL call of
+    the step is issued for real - all_gather_into_tensor / reduce_scatter_tensor of the embeddings, the
+    per-block gradient all-reduces on dp.GradSync's side stream, the scalar all-reduce - and the
+    result must be the plain single-process step (sums over one rank are the identity);
+  * TWO ranks on two GPUs when the box has them (skipped otherwise): must match the single-process
+    step on the whole batch, like tests/test_dp_two_ranks_gpu.py does over gloo."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out, force):
+  sys.path.insert(0, ROOT)
+  sys.path.insert(0, os.path.join(ROOT, "oracle"))
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+  if force:
+    os.environ["BV_DP_FORCE_COLLECTIVES"] = "1"
+  import bv_oracle as O
+  import test_dp_two_ranks_gpu as T
+  from big_vision_amd import dp
+  torch.cuda.set_device(rank)
+  comm = dp.init_from_env(backend="nccl")
+  assert comm.active and comm.size == world
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  n = 8 // world
+  dev = torch.device("cuda", rank)
+  loss, gn, grads, params = T._step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev))
+  digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
+  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest))
+  comm.barrier()
+  torch.distributed.destroy_process_group()
+
+
+def _run(world, force):
+  import torch.multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import test_dp_two_ranks_gpu as T
+  ctx = mp.get_context("spawn")
+  out = ctx.Queue()
+  port = T._free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, out, force)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = {}
+  for _ in range(world):
+    r = out.get(timeout=600)
+    res[r[0]] = r[1:]
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
+  return res
+
+
+def _check(res, dev):
+  import bv_oracle as O
+  import test_dp_two_ranks_gpu as T
+  from big_vision_amd import dp
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  loss1, gn1, g1, _ = T._step(dp.Comm(), image.to(dev), text.to(dev))
+  loss2, gn2, g2, _ = res[0]
+  assert abs(loss2 - loss1) <= 1e-4 * abs(loss1), (loss1, loss2)
+  assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
+  gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
+  for k, v in g1.items():
+    assert (v - torch.from_numpy(g2[k])).norm().item() <= 2e-2 * max(v.norm().item(), 1e-2 * gnorm), k
+  for r in res:
+    assert res[r][3] == res[0][3], "replicated parameters diverged between the ranks after the update"
+
+
+def test_rccl_call_path_on_one_gpu(dev):
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  _check(_run(1, force=True), dev)
+
+
+def test_two_ranks_over_rccl(dev):
+  if torch.cuda.device_count() < 2:
+    pytest.skip("needs two GPUs (the driver's multi-GPU box); the one-GPU test above issues the same RCCL calls")
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  _check(_run(2, force=False), dev)

@@ -110,7 +110,7 @@ class _FakeComm(dp.Comm):
   """Two 'ranks' without a process group: collectives are recorded, data is passed through."""
 
   def __init__(self, log):
-    self.enabled, self.group, self.rank, self.size, self.log = False, None, 1, 2, log
+    self.enabled, self.group, self.rank, self.size, self.log, self.active = False, None, 1, 2, log, True
 
   def all_gather_rows(self, x):
     self.log.append("all_gather")
@@ -138,13 +138,24 @@ def test_gradient_ranges_are_reduced_in_backward_order_on_two_ranks(dry):
   store = state["params"].store
   log.clear()
   fn(state, None, batch)
-  reds = [e for e in log if isinstance(e, tuple)]
+  reds = [(a, a + b) for e in log if isinstance(e, tuple) for _, a, b in [e]]
   txt = store.grad_range(lambda n: n.startswith("txt/"))
-  assert log.index("all_gather") < log.index("reduce_scatter") < log.index(reds[0])
-  assert (reds[0][1], reds[0][1] + reds[0][2]) == txt           # text tower first (its backward runs first)
-  lo, n = reds[1][1], reds[1][2]
-  assert lo + n == txt[0] and lo > store.entries["img/Transformer/encoderblock_0/LayerNorm_0/scale"].offset
-  covered = sorted((a, a + b) for _, a, b in reds)
+  assert log.index("all_gather") < log.index("reduce_scatter") < log.index(next(e for e in log if isinstance(e, tuple)))
+  blk = lambda tower, enc, i: store.grad_range(lambda n: n.startswith(f"{tower}/{enc}/encoderblock_{i}/"))
+  # text tower first (its backward runs first): its blocks last-to-first, one message per block,
+  # then whatever is left of the tower (embedding table, final norm, head) ...
+  assert reds[0] == blk("txt", "Encoder_0", TXT["depth"] - 1) and reds[TXT["depth"] - 1] == blk("txt", "Encoder_0", 0)
+  k = TXT["depth"]
+  rest_txt = []
+  while reds[k][0] >= txt[0] and reds[k][1] <= txt[1]:
+    rest_txt.append(reds[k]); k += 1
+  assert rest_txt and sum(b - a for a, b in reds[:k]) == txt[1] - txt[0]         # the whole text tower, exactly once
+  # ... then the image tower: final norm + MAP head together with its last block, blocks last-to-first
+  tail = store.grad_range(lambda n: n.startswith("img/") and "/encoderblock_" not in n
+                          and not n.startswith(("img/embedding", "img/pos_embedding")))
+  assert reds[k] == tail and reds[k + 1] == blk("img", "Transformer", IMG["depth"] - 1)
+  assert reds[k + IMG["depth"]] == blk("img", "Transformer", 0)
+  covered = sorted(reds)
   assert covered[0][0] == 0 and covered[-1][1] == store.trainable_count      # every element exactly once
   assert all(x[1] == y[0] for x, y in zip(covered, covered[1:]))
   # with the overlap switched off it is one plain all-reduce of the whole buffer
