@@ -730,7 +730,10 @@ __device__ __forceinline__ void vm_tie8(f32x4& a0, f32x4& a1, f32x4& a2, f32x4& 
   asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
 }
 
-template <int EPI, bool OUTF32>
+// STM = 1 (bf16 outputs): the stores of a quadrant are issued INSIDE the MFMA segment of the phase (one
+// store behind every 4th / 2nd MFMA via sched_group_barrier) instead of in its load segment: the wave
+// pushes store data while its own MFMAs execute.
+template <int EPI, bool OUTF32, int STM = 0>
 __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
   static_assert(EPI == BV_EPI_NONE || EPI == BV_EPI_GELU || EPI == BV_EPI_RESIDUAL, "epilogue");
   static_assert(OUTF32 == (EPI == BV_EPI_RESIDUAL), "fp32 output only with the residual epilogue");
@@ -911,6 +914,62 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
     }
   };
 
+  // STM: the same epilogue split in two - VALU part (load segment) and the stores (MFMA segment)
+  u32x4 pk[4], pk2[4];
+  char* st_c = nullptr;
+  char* st_g = nullptr;
+  auto chunk_prep = [&](auto IHc, auto JHc, int m0, int n0) {
+    constexpr int IH = decltype(IHc)::value, JH = decltype(JHc)::value;
+    if constexpr (!OUTF32) {
+      const long mrow = m0 + wr * 128 + IH * 64;
+      st_c = reinterpret_cast<char*>(reinterpret_cast<bf16*>(p.C) + mrow * p.ldc + ucol(n0, JH * 2));
+      st_g = reinterpret_cast<char*>(reinterpret_cast<bf16*>(p.C2) + mrow * p.ldc + ucol(n0, JH * 2));
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = IH * 4 + ii;
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[jj * 4 + r] = acc[i][JH * 2 + jj][r] * p.alpha + bq[JH * 2 + jj][r];
+        uint32_t hw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hw[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+        pk[ii] = u32x4{hw[0], hw[1], hw[2], hw[3]};
+        if constexpr (EPI == BV_EPI_GELU) {
+          uint32_t gw[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gw[e] = pack_bf2(gelu_tanh_f(bflo(hw[e])), gelu_tanh_f(bfhi(hw[e])));
+          pk2[ii] = u32x4{gw[0], gw[1], gw[2], gw[3]};
+        }
+      }
+    }
+  };
+  auto chunk_store = [&]() {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      *reinterpret_cast<u32x4*>(st_c + (long)ii * 32 * p.ldc + lane_c) = pk[ii];
+      if constexpr (EPI == BV_EPI_GELU) *reinterpret_cast<u32x4*>(st_g + (long)ii * 32 * p.ldc + lane_c) = pk2[ii];
+    }
+  };
+
+// 16 MFMAs with NS stores spread between them: [16/NS MFMAs][1 store] x NS
+#define BVR_MFMA_QUAD_ST(I0, J0, ZERO)                                                         \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+          acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
+              bfg[(J0) + j][ks], af[i][ks],                                                    \
+              ((ZERO) && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[(I0) + i][(J0) + j], 0, 0, 0); \
+    chunk_store();                                                                             \
+    _Pragma("unroll") for (int g_ = 0; g_ < NS; ++g_) {                                        \
+      __builtin_amdgcn_sched_group_barrier(0x008, 16 / NS, 0);                                 \
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                                       \
+    }                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
 #define BVR_MFMA_QUAD(I0, J0, ZERO)                                                            \
   do {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                             \
@@ -1007,7 +1066,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
     if (moreA) issueA(ca, (gk + 1) & 1, 1);
     BVR_PIN();
     if constexpr (LAST) {
-      chunk(I0{}, I0{}, em0, en0);
+      if constexpr (STM) chunk_prep(I0{}, I0{}, em0, en0); else chunk(I0{}, I0{}, em0, en0);
       BVR_PIN();
       if (have_next) xload(I0{}, I0{}, xm0, xn0);
     }
@@ -1021,14 +1080,14 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
       }
     }
     BVR_MID();
-    BVR_MFMA_QUAD(0, 2, ZERO);
+    if constexpr (LAST && STM) BVR_MFMA_QUAD_ST(0, 2, ZERO); else BVR_MFMA_QUAD(0, 2, ZERO);
     BVR_END();
     // -------- phase 2: quadrant (1,1)
     readA(sa, 1);
     if (moreB) issueB(cb, bs2, 0);
     BVR_PIN();
     if constexpr (LAST) {
-      chunk(I0{}, I1{}, em0, en0);
+      if constexpr (STM) chunk_prep(I0{}, I1{}, em0, en0); else chunk(I0{}, I1{}, em0, en0);
       BVR_PIN();
       if (have_next) xload(I0{}, I1{}, xm0, xn0);
     }
@@ -1038,7 +1097,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
       vm_tie8(acc[4][2], acc[4][3], acc[5][2], acc[5][3], acc[6][2], acc[6][3], acc[7][2], acc[7][3]);
     }
     BVR_MID();
-    BVR_MFMA_QUAD(4, 2, ZERO);
+    if constexpr (LAST && STM) BVR_MFMA_QUAD_ST(4, 2, ZERO); else BVR_MFMA_QUAD(4, 2, ZERO);
     BVR_END();
     // -------- phase 3: quadrant (1,0); retire K-tile gk+1's loads for the next iteration
     if (moreB) issueB(cb, bs2, 1);
@@ -1047,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
       if (full) vm_wait<W_A>();
       else vm_wait<0>();
       BVR_PIN();
-      chunk(I1{}, I1{}, em0, en0);
+      if constexpr (STM) chunk_prep(I1{}, I1{}, em0, en0); else chunk(I1{}, I1{}, em0, en0);
       BVR_PIN();
       if (have_next) xload(I1{}, I1{}, xm0, xn0);
     } else if constexpr (FIRST) {
@@ -1065,7 +1124,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     BVR_MID();
-    BVR_MFMA_QUAD(4, 0, ZERO);
+    if constexpr (LAST && STM) BVR_MFMA_QUAD_ST(4, 0, ZERO); else BVR_MFMA_QUAD(4, 0, ZERO);
     BVR_END();
     if (moreA) advance(ca);
     if (moreB) advance(cb);
@@ -1091,6 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
   chunk(I1{}, I0{}, em0, en0);   // quadrant (1,0) of the last tile
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef BVR_MFMA_QUAD
+#undef BVR_MFMA_QUAD_ST
 #undef BVR_MID
 #undef BVR_END
 #undef BVR_PIN
@@ -1276,7 +1336,9 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
                      ((g_roll & 1) && epilogue == BV_EPI_RESIDUAL && out_f32 && alpha == 1.0f));
   if (roll) {
     if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
+    else if (epilogue == BV_EPI_GELU && (g_roll & 8)) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_GELU, false, 1>), grid, block, 0, s, p);
     else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_GELU, false>), grid, block, 0, s, p);
+    else if (g_roll & 8) hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_NONE, false, 1>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm256r_kernel<BV_EPI_NONE, false>), grid, block, 0, s, p);
     return 1;
   }

@@ -62,7 +62,13 @@ static float time_ms(F launch, int iters) {
 }
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  bool quick = false;
+  int mask = 7;                      // bv_gemm_roll bits: 1 RESIDUAL, 2 NONE, 4 GELU, 8 stores in the MFMA segment
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "quick")) quick = true;
+    if (!strncmp(argv[i], "mask=", 5)) mask = atoi(argv[i] + 5);
+  }
+  printf("roll mask %d\n", mask);
   struct Shape { const char* name; int M, N, K, epi; } shapes[] = {
       {"check 256x256x128 (1 tile, 2 K-tiles)", 256, 256, 128, BV_EPI_NONE},
       {"check 512x256x192 none", 512, 256, 192, BV_EPI_NONE},
@@ -108,7 +114,7 @@ int main(int argc, char** argv) {
     const bool f32 = s.epi == BV_EPI_RESIDUAL;
     const size_t cbytes = (size_t)s.M * s.N * (f32 ? 4 : 2);
     auto run = [&](int roll, void* c, void* c2) {
-      bv_gemm_roll(roll ? 7 : 0);
+      bv_gemm_roll(roll ? mask : 0);
       const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c, s.N, f32 ? 1 : 0, s.M, s.N, s.K, s.epi, bias,
                                     f32 ? aux : nullptr, s.N, 0, s.epi == BV_EPI_GELU ? c2 : nullptr, 1.0f, 0,
                                     nullptr, nullptr);
