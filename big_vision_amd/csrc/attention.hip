@@ -526,8 +526,8 @@ int bv_attn2_bwd(const void* qkv, const void* o, const void* d_o, const float* l
 // attention3.hip: one query fragment per wave iteration, 8 waves, prefetched fragments, exact delta,
 // optional key-padding length per sample (the default fast path)
 int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream);
-int bv_attn3_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
-                 const int* kv_len, int n, int L, int H, void* stream);
+int bv_attn3_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                 float* dbias, const int* kv_len, int n, int L, int H, void* stream);
 int bv_fast_path_enabled();
 static int g_attn_impl = 3;
 // diagnostics / A-B benchmarking: 3 = attention3.hip (default), 2 = attention2.hip.  impl < 0 only
@@ -557,7 +557,7 @@ extern "C" int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_bwd: L=%d > 576 not supported", L);
   if (bv_fast_path_enabled())
-    return g_attn_impl == 3 ? bv_attn3_bwd(qkv, d_o, lse, delta, dqkv, dbias_rows, nullptr, n, L, H, stream)
+    return g_attn_impl == 3 ? bv_attn3_bwd(qkv, o, d_o, lse, delta, dqkv, dbias_rows, nullptr, n, L, H, stream)
                             : bv_attn2_bwd(qkv, o, d_o, lse, delta, dqkv, dbias_rows, n, L, H, stream);
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)n * L * H;
@@ -594,7 +594,7 @@ extern "C" int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float*
                                   float* delta, void* dqkv, float* dbias_rows, int n, int L, int H, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && H > 0, "bv_attn_bwd_masked: bad shape n=%d L=%d H=%d", n, L, H);
   BV_REQUIRE(L <= 576, "bv_attn_bwd_masked: L=%d > 576 not supported", L);
-  return bv_attn3_bwd(qkv, d_o, lse, delta, dqkv, dbias_rows, kv_len, n, L, H, stream);
+  return bv_attn3_bwd(qkv, nullptr, d_o, lse, delta, dqkv, dbias_rows, kv_len, n, L, H, stream);
 }
 
 // kv_len (optional, int32 [n]): keys >= kv_len[i] get probability 0 - the pool mask of the NaFlex MAP

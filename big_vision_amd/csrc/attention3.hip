@@ -31,8 +31,22 @@
 // MFMA plan as attention2: S^T[key][q] = K Q^T and dP^T = V dO^T put P^T / dS^T straight into the
 // B-operand layout of O^T += V^T P^T and dQ^T += K^T dS^T; the key-owned pass computes S = Q K^T,
 // dP = dO V^T and accumulates dV^T += dO^T P, dK^T += Q^T dS.
+#include <type_traits>
 #include "attn_common.h"
 #include "bvhip_internal.h"
+#ifndef A3_PROBE
+#define A3_PROBE 0   // != 0 only in tools/probes/attn3_probe.hip (ablations of the forward kernel)
+#endif
+#if A3_PROBE == 3    // s_memtime stamps of waves 0 and NW-1 of a few mid-launch workgroups
+__device__ long* g_a3_stamps;
+#define A3_STAMP(k)                                                                              \
+  do {                                                                                           \
+    if (lane == 0 && (wave == 0 || wave == NW - 1) && blockIdx.x >= 12000 && blockIdx.x < 12004) \
+      g_a3_stamps[((blockIdx.x - 12000) * 2 + (wave != 0)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define A3_STAMP(k)
+#endif
 
 namespace {
 using namespace bvattn;
@@ -46,7 +60,11 @@ __device__ __forceinline__ void mfma_drain(f32x4& a, f32x4& b, f32x4& c, f32x4& 
 }
 
 // ------------------------------------------------------------------ forward --
-template <int KF, int NW, int WPS>
+// TAIL: the host guarantees Lk > (KF - 1) * 16 for every sample (no kv_len, L in the last fragment), so
+// only the last key fragment is masked.  (With a runtime straddling fragment hipcc if-converts the
+// mask of ALL KF x 4 scores: 52 compares hoisted out of the loop into SGPR pairs that spill to VGPR
+// lanes, 107 v_cndmask + 50 v_readlane per query fragment - a third of the loop's VALU work.)
+template <int KF, int NW, int WPS, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __restrict__ qkv,
                                                                  bf16* __restrict__ o,
                                                                  float* __restrict__ lse,
@@ -64,12 +82,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
   const bf16* kb_ = qb_ + (long)H * DH;
   const bf16* vb_ = qb_ + 2L * H * DH;
   int qf = wave;
+  A3_STAMP(0);
   bf16x8 q0 = gfrag(qb_, ld, qf * 16 + lr, L, lg * 8), q1 = gfrag(qb_, ld, qf * 16 + lr, L, 32 + lg * 8);
+#if A3_PROBE == 2   // probe: no K/V staging (LDS holds garbage)
+#else
   t64_stage2<KF * 16, NW * 64>(Kt, kb_, ld, Vt, vb_, ld, Lk, tid);
+#endif
   __syncthreads();
+  A3_STAMP(1);
   const float c = scale * LOG2E;
+#if A3_PROBE == 1     // probe: staging only
+  if (L > 0) return;
+#endif
+  int it_ = 0;
 
-  for (; qf * 16 < L; qf += NW) {
+  for (; qf * 16 < L; qf += NW, ++it_) {
+    A3_STAMP(2 + it_ * 5);
     f32x4 s[KF];
 #pragma unroll
     for (int f = 0; f < KF; ++f) {
@@ -89,31 +117,63 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       q0 = gfrag(qb_, ld, qn, L, lg * 8);
       q1 = gfrag(qb_, ld, qn, L, 32 + lg * 8);
     }
+    A3_STAMP(3 + it_ * 5);
     float mx = -INFINITY;
+    if constexpr (TAIL) {
+      const int lim = Lk - (KF - 1) * 16 - lg * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[KF - 1][r] = r < lim ? s[KF - 1][r] : -INFINITY;
+    }
 #pragma unroll
     for (int f = 0; f < KF; ++f) {
-      if (f * 16 + 16 > Lk) {   // wave-uniform: fragment straddles / lies beyond the last valid key
+      if constexpr (!TAIL) {
+        if (f * 16 + 16 > Lk) {   // wave-uniform: fragment straddles / lies beyond the last valid key
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (f * 16 + lg * 4 + r >= Lk) s[f][r] = -INFINITY;
+          for (int r = 0; r < 4; ++r)
+            if (f * 16 + lg * 4 + r >= Lk) s[f][r] = -INFINITY;
+        }
       }
-      mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+      if constexpr (TAIL) {
+        mx = fmaxf(fmaxf(mx, s[f][0]), s[f][1]);   // v_max3_f32
+        mx = fmaxf(fmaxf(mx, s[f][2]), s[f][3]);
+      } else {
+        mx = fmaxf(mx, fmaxf(fmaxf(s[f][0], s[f][1]), fmaxf(s[f][2], s[f][3])));
+      }
     }
     mx = xmax4(mx);
     const float mc = mx * c;
-    float sum = 0.f;
+    float sum;
+    if constexpr (TAIL) {
+      // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two elements per VALU slot) around the exp2
+      const f32x2 c2 = f32x2{c, c}, nmc2 = f32x2{-mc, -mc};
+      f32x2 sum2 = f32x2{0.f, 0.f};
 #pragma unroll
-    for (int f = 0; f < KF; ++f)
+      for (int f = 0; f < KF; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc));
-        s[f][r] = p;
-        sum += p;
-      }
+        for (int hp = 0; hp < 2; ++hp) {
+          const f32x2 a = __builtin_elementwise_fma(f32x2{s[f][2 * hp], s[f][2 * hp + 1]}, c2, nmc2);
+          const f32x2 p = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          s[f][2 * hp] = p[0];
+          s[f][2 * hp + 1] = p[1];
+          sum2 += p;
+        }
+      sum = sum2[0] + sum2[1];
+    } else {
+      sum = 0.f;
+#pragma unroll
+      for (int f = 0; f < KF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[f][r], c, -mc));
+          s[f][r] = p;
+          sum += p;
+        }
+    }
     sum = xsum4(sum);
     const float inv = 1.0f / sum;
     const float lsev = mx * scale + __logf(sum);
     f32x4 oa[4];
+    A3_STAMP(4 + it_ * 5);
 #pragma unroll
     for (int d = 0; d < 4; ++d) oa[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -132,6 +192,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       for (int d = 0; d < 4; ++d) oa[d] = mfma16k16(t64_tr(Vt, (KF - 1) * 16 + 4 * lg, d, lr), pf, oa[d]);
     }
     mfma_drain(oa[0], oa[1], oa[2], oa[3]);
+    A3_STAMP(5 + it_ * 5);
     if (qrow < L) {
       bf16* orow = o + ((long)i * L + qrow) * H * DH + h * DH;
 #pragma unroll
@@ -143,6 +204,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       }
       if (lg == 0) lse[((long)i * H + h) * L + qrow] = lsev;
     }
+    A3_STAMP(6 + it_ * 5);
   }
 }
 
@@ -273,6 +335,174 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq_kernel(const bf16* 
     q0 = nq0; q1 = nq1; g0 = ng0; g1 = ng1; lse2 = nlse;
   }
   if (dbias) {   // per-(sample, head) column sums of dQ -> dbias[i][0][h][:]; the host sums over samples
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 64 + tid];
+      dbias[((long)i * 3 * H + h) * DH + tid] = t;
+    }
+  }
+}
+
+// ------------------------------------------- backward: dQ, one sweep (with O) --
+// When the forward output O is at hand (the training step keeps it: it is the operand of the
+// out-projection's dW), one sweep over the keys is enough and delta stays exact:
+//   delta~_i = rowsum(dO_i o O_i)               (bf16 O: off by eps_i = delta_i - delta~_i, ~2^-9 |dO||O|)
+//   dS~ = P o (dP - delta~)                      fp32, then bf16 for the MFMA - as accurate as dS itself
+//   eps_i = rowsum_j dS~_ij = delta_i - delta~_i (rows of P sum to 1), fp32, exact
+//   dQ_i = sum_j dS~_ij K_j - eps_i * sum_j P_ij K_j
+// The correction term is second order (eps times a bf16-rounded P K), so nothing is lost against the
+// two-sweep kernel above, which recomputes S, dP and the exponentials a second time: per key pair
+// 16 MFMAs and ~40 VALU slots instead of 20 and ~110.  delta = delta~ + eps is written for the
+// key-owned pass.  TAIL as in the forward: only the last key fragment can hold masked keys.
+template <int KF, int NW, int WPS, bool TAIL>
+__global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq1_kernel(const bf16* __restrict__ qkv,
+                                                                     const bf16* __restrict__ o,
+                                                                     const bf16* __restrict__ d_o,
+                                                                     const float* __restrict__ lse,
+                                                                     float* __restrict__ delta,
+                                                                     bf16* __restrict__ dqkv,
+                                                                     float* __restrict__ dbias,
+                                                                     const int* __restrict__ kv_len, int L,
+                                                                     int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + KF * 16 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x / H, h = blockIdx.x % H;
+  const int Lk = kv_len ? min(kv_len[i], L) : L;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
+  const bf16* kb_ = qb_ + (long)H * DH;
+  const bf16* vb_ = qb_ + 2L * H * DH;
+  const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+  const bf16* ob_ = o + (long)i * L * ldo + h * DH;
+  const float* lse_ = lse + ((long)i * H + h) * L;
+  float* red = reinterpret_cast<float*>(smem + 2 * KF * 16 * 128);   // [NW waves][64] column sums of dQ
+  int qf = wave;
+  bf16x8 q0 = gfrag(qb_, ld, qf * 16 + lr, L, lg * 8), q1 = gfrag(qb_, ld, qf * 16 + lr, L, 32 + lg * 8);
+  bf16x8 g0 = gfrag(dob_, ldo, qf * 16 + lr, L, lg * 8), g1 = gfrag(dob_, ldo, qf * 16 + lr, L, 32 + lg * 8);
+  bf16x8 o0 = gfrag(ob_, ldo, qf * 16 + lr, L, lg * 8), o1 = gfrag(ob_, ldo, qf * 16 + lr, L, 32 + lg * 8);
+  float lse2 = qf * 16 + lr < L ? lse_[qf * 16 + lr] * LOG2E : INFINITY;
+  t64_stage2<KF * 16, NW * 64>(Kt, kb_, ld, Vt, vb_, ld, Lk, tid);
+  if (dbias && tid < NW * 64) red[tid] = 0.f;
+  __syncthreads();
+  const float c = scale * LOG2E;
+
+  for (; qf * 16 < L; qf += NW) {
+    // delta~ of this lane's query row (the row's 64 products are spread over its 4 lane groups)
+    float dt = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dt = __builtin_fmaf((float)g0[e], (float)o0[e], dt);
+      dt = __builtin_fmaf((float)g1[e], (float)o1[e], dt);
+    }
+    dt = xsum4(dt);
+    const int qn = (qf + NW) * 16 + lr;
+    o0 = gfrag(ob_, ldo, qn, L, lg * 8);      // next fragment's O goes into the registers just consumed
+    o1 = gfrag(ob_, ldo, qn, L, 32 + lg * 8);
+    const f32x2 c2 = f32x2{c, c}, nl2 = f32x2{-lse2, -lse2}, dt2 = f32x2{dt, dt};
+    f32x2 eps2 = f32x2{0.f, 0.f};
+
+    // P^T and dS~^T of key fragment f for this query fragment (MASK: keys >= Lk get p = 0)
+    auto pds = [&](int f, auto maskc, f32x4& p, f32x4& ds) {
+      constexpr bool MASK = decltype(maskc)::value;
+      const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg), k1 = t64_row(Kt, f * 16 + lr, 4 + lg);
+      const bf16x8 v0 = t64_row(Vt, f * 16 + lr, lg), v1 = t64_row(Vt, f * 16 + lr, 4 + lg);
+      f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      st = mfma16(k0, q0, st);
+      st = mfma16(k1, q1, st);
+      dp = mfma16(v0, g0, dp);
+      dp = mfma16(v1, g1, dp);
+      const int lim = Lk - f * 16 - lg * 4;
+#pragma unroll
+      for (int hp = 0; hp < 2; ++hp) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{st[2 * hp], st[2 * hp + 1]}, c2, nl2);
+        f32x2 e = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        if constexpr (MASK) {   // branch-free (see the hazard note in the two-sweep kernel)
+          e[0] = 2 * hp < lim ? e[0] : 0.f;
+          e[1] = 2 * hp + 1 < lim ? e[1] : 0.f;
+        }
+        const f32x2 t = e * (f32x2{dp[2 * hp], dp[2 * hp + 1]} - dt2);
+        eps2 += t;
+        p[2 * hp] = e[0]; p[2 * hp + 1] = e[1];
+        ds[2 * hp] = t[0]; ds[2 * hp + 1] = t[1];
+      }
+    };
+    using NoMask = std::integral_constant<bool, !TAIL>;   // general path masks every fragment
+    using Mask = std::integral_constant<bool, true>;
+
+    f32x4 dq[4], bq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto pair = [&](int fp, auto mask_hi) {
+      f32x4 p[2], ds[2];
+      pds(2 * fp, NoMask{}, p[0], ds[0]);
+      pds(2 * fp + 1, mask_hi, p[1], ds[1]);
+      const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(p[0], p[1]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 kt = t64_trpair(Kt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
+        dq[d] = mfma16(kt, dsf, dq[d]);
+        bq[d] = mfma16(kt, pf, bq[d]);
+      }
+    };
+    constexpr int NPAIR = KF / 2, NLOOP = (KF & 1) ? NPAIR : NPAIR - 1;   // even KF: the last pair holds the tail
+#pragma unroll 1
+    for (int fp = 0; fp < NLOOP; ++fp) pair(fp, NoMask{});
+    if constexpr (KF & 1) {
+      f32x4 p, ds;
+      pds(KF - 1, Mask{}, p, ds);
+      const s16x4 dsf = pack4(ds), pf = pack4(p);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const s16x4 kt = t64_tr(Kt, (KF - 1) * 16 + 4 * lg, d, lr);
+        dq[d] = mfma16k16(kt, dsf, dq[d]);
+        bq[d] = mfma16k16(kt, pf, bq[d]);
+      }
+    } else {
+      pair(NPAIR - 1, Mask{});
+    }
+    mfma_drain(dq[0], dq[1], dq[2], dq[3]);
+    mfma_drain(bq[0], bq[1], bq[2], bq[3]);
+    // the NEXT fragment's q / dO rows go into the registers of the finished one (no second set: the
+    // kernel sits at the 128-VGPR line of 4 waves per SIMD); the epilogue below covers part of the latency
+    q0 = gfrag(qb_, ld, qn, L, lg * 8); q1 = gfrag(qb_, ld, qn, L, 32 + lg * 8);
+    g0 = gfrag(dob_, ldo, qn, L, lg * 8); g1 = gfrag(dob_, ldo, qn, L, 32 + lg * 8);
+    lse2 = qn < L ? lse_[qn] * LOG2E : INFINITY;
+    const float eps = xsum4(eps2[0] + eps2[1]);
+    const int qrow = qf * 16 + lr;
+    if (lg == 0 && qrow < L) delta[((long)i * H + h) * L + qrow] = dt + eps;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq[d][r] = __builtin_fmaf(-eps, bq[d][r], dq[d][r]);
+    if (dbias) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = rowsum16(dq[d][r]);
+          if (lr == 0) red[wave * 64 + d * 16 + lg * 4 + r] += t * scale;
+        }
+    }
+    if (qrow < L) {
+      bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint2 w;
+        w.x = pack_bf2(dq[d][0] * scale, dq[d][1] * scale);
+        w.y = pack_bf2(dq[d][2] * scale, dq[d][3] * scale);
+        *reinterpret_cast<uint2*>(row + d * 16 + lg * 4) = w;
+      }
+    }
+  }
+  if (dbias) {
     __syncthreads();
     if (tid < 64) {
       float t = 0.f;
@@ -429,6 +659,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dkv_kernel(const bf16*
   }
 }
 
+int g_a3_one_sweep = 1;   // 0: always the two-sweep dQ kernel (A/B, bv_attn_tune bit 16)
+
 template <typename K>
 void set_lds(K kernel, size_t bytes) {
   if (bytes > 65536)
@@ -439,18 +671,38 @@ void set_lds(K kernel, size_t bytes) {
 template <int KF, int NW, int WPS>
 int launch_fwd3(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, hipStream_t s) {
   const size_t sh = (size_t)KF * 4096;
-  set_lds(attn3_fwd_kernel<KF, NW, WPS>, sh);
-  hipLaunchKernelGGL((attn3_fwd_kernel<KF, NW, WPS>), dim3(n * H), dim3(NW * 64), sh, s, (const bf16*)qkv,
-                     (bf16*)o, lse, kv_len, L, H, 0.125f);
+  if (!kv_len && L > (KF - 1) * 16) {
+    set_lds(attn3_fwd_kernel<KF, NW, WPS, true>, sh);
+    hipLaunchKernelGGL((attn3_fwd_kernel<KF, NW, WPS, true>), dim3(n * H), dim3(NW * 64), sh, s, (const bf16*)qkv,
+                       (bf16*)o, lse, kv_len, L, H, 0.125f);
+  } else {
+    set_lds(attn3_fwd_kernel<KF, NW, WPS, false>, sh);
+    hipLaunchKernelGGL((attn3_fwd_kernel<KF, NW, WPS, false>), dim3(n * H), dim3(NW * 64), sh, s, (const bf16*)qkv,
+                       (bf16*)o, lse, kv_len, L, H, 0.125f);
+  }
   return bv_check_launch("bv_attn_fwd");
 }
 template <int KF, int NW, int WPS, int WPS2>
-int launch_bwd3(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
-                const int* kv_len, int n, int L, int H, hipStream_t s) {
+int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                float* dbias, const int* kv_len, int n, int L, int H, hipStream_t s) {
   const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
-  set_lds(attn3_bwd_dq_kernel<KF, NW, WPS>, sh1);
-  hipLaunchKernelGGL((attn3_bwd_dq_kernel<KF, NW, WPS>), dim3(n * H), dim3(NW * 64), sh1, s, (const bf16*)qkv,
-                     (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+  if (o && g_a3_one_sweep) {
+    if (!kv_len && L > (KF - 1) * 16) {
+      set_lds(attn3_bwd_dq1_kernel<KF, NW, WPS, true>, sh1);
+      hipLaunchKernelGGL((attn3_bwd_dq1_kernel<KF, NW, WPS, true>), dim3(n * H), dim3(NW * 64), sh1, s,
+                         (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len,
+                         L, H, 0.125f);
+    } else {
+      set_lds(attn3_bwd_dq1_kernel<KF, NW, WPS, false>, sh1);
+      hipLaunchKernelGGL((attn3_bwd_dq1_kernel<KF, NW, WPS, false>), dim3(n * H), dim3(NW * 64), sh1, s,
+                         (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len,
+                         L, H, 0.125f);
+    }
+  } else {
+    set_lds(attn3_bwd_dq_kernel<KF, NW, WPS>, sh1);
+    hipLaunchKernelGGL((attn3_bwd_dq_kernel<KF, NW, WPS>), dim3(n * H), dim3(NW * 64), sh1, s, (const bf16*)qkv,
+                       (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+  }
   int rc = bv_check_launch("bv_attn_bwd(dq)");
   if (rc) return rc;
   const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)NW * 128 * 4;
@@ -465,21 +717,37 @@ int launch_bwd3(const void* qkv, const void* d_o, const float* lse, float* delta
 // Entry points used by bv_attn_fwd / bv_attn_bwd (attention.hip).  Key fragments = ceil(L/16) for
 // the common sequence lengths (64 text tokens; 196/197 at 224 px; 256/257; 441 at 336 px; 576 at
 // 384 px), the next instantiated size otherwise.
+static int g_a3cfg = 0;
+// experiments: waves per workgroup of the L <= 208 kernels (0 = default)
+extern "C" int bv_attn_tune(int cfg) {
+  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16);
+  if (cfg >= 0) { g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); }
+  return old;
+}
+
 int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (L <= 64) return launch_fwd3<4, 4, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 1) return launch_fwd3<13, 5, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 2) return launch_fwd3<13, 7, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 3) return launch_fwd3<13, 13, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 4) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 208) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 448) return launch_fwd3<28, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
   return launch_fwd3<36, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
 }
 
-int bv_attn3_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias,
-                 const int* kv_len, int n, int L, int H, void* stream) {
+int bv_attn3_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                 float* dbias, const int* kv_len, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  return launch_bwd3<36, 8, 2, 2>(qkv, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 1) return launch_bwd3<13, 5, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 2) return launch_bwd3<13, 7, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 3) return launch_bwd3<13, 13, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208 && g_a3cfg == 4) return launch_bwd3<13, 4, 3, 3>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  return launch_bwd3<36, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
 }

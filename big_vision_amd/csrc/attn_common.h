@@ -8,6 +8,7 @@ namespace bvattn {
 constexpr int DH = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 // LDS tile layout ("T64"): row r = 8 chunks of 16 B, chunk c stored at position

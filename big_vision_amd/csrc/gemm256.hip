@@ -156,6 +156,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
   if (nmy == 0) return;
   const int nk_all = p.K >> 6;
+  if (PROBE != 0 && p.skew_mode >= 2) {   // probe: only a subset of the workgroups runs (its usual work list)
+    const int m = p.skew_mode;
+    const bool on = m == 2 ? xcd == 0 : m == 3 ? (idx & 7) == 0 : m == 4 ? bid == 0 : m == 5 ? idx == 0
+                  : m == 6 ? (xcd == 0 && idx < 8) : m == 7 ? xcd < 4 : true;
+    if (!on) return;
+  }
   if (PROBE != 0 && p.dbg && tid == 0) {
     p.dbg[bid * 4 + 0] = __builtin_amdgcn_s_memtime();
     p.dbg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();

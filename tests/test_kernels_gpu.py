@@ -242,7 +242,9 @@ def test_attention_key_padding_mask(dev, n, L, H):
   # no mask given == plain attention
   o2, lse2 = ops.attn_fwd(qkv, n, L, H, kv_len=torch.full((n,), L, device=dev, dtype=torch.int32))
   o3, lse3 = ops.attn_fwd(qkv, n, L, H)
-  assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
+  # (the unmasked launch takes the tail-only instantiation: same values, another summation order)
+  assert_close(lse2, lse3, 1e-6, 1e-5, "full-length mask lse")
+  assert_close(o2, o3, 8e-3, 1e-3, "full-length mask out")
 
 
 def test_attention_delta_is_exact_for_near_uniform_rows(dev):

@@ -1,0 +1,57 @@
+// Ablation of attn3_fwd_kernel (compile with -DA3_PROBE=0/1/2): 0 full, 1 staging only, 2 no staging.
+//   for p in 0 1 2; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DA3_PROBE=$p -I big_vision_amd/csrc -I include \
+//     tools/probes/attn3_probe.hip big_vision_amd/csrc/c_api.cpp -o tools/probes/attn3_probe$p.out; done
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../big_vision_amd/csrc/attention3.hip"
+
+__global__ void fill(unsigned short* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned s = (unsigned)i * 2654435761u + seed;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
+    float f = ((s & 0xffff) / 65536.0f - 0.5f) * 2.0f;
+    unsigned u; memcpy(&u, &f, 4);
+    p[i] = (unsigned short)(u >> 16);
+  }
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 2048, L = 196, H = 12;
+  unsigned short *qkv, *o; float* lse;
+  (void)hipMalloc(&qkv, (size_t)n * L * 3 * H * 64 * 2);
+  (void)hipMalloc(&o, (size_t)n * L * H * 64 * 2);
+  (void)hipMalloc(&lse, (size_t)n * H * L * 4);
+  fill<<<2048, 256>>>(qkv, (size_t)n * L * 3 * H * 64, 1u);
+  (void)hipDeviceSynchronize();
+#if A3_PROBE == 3
+  long* st; (void)hipMalloc(&st, 8 * 32 * 8); (void)hipMemset(st, 0, 8 * 32 * 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a3_stamps), &st, sizeof(st));
+#endif
+  for (int cfg : {0, 4}) {
+    bv_attn_tune(cfg);
+    for (int i = 0; i < 3; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 10; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("A3_PROBE=%d cfg %d n=%d: fwd %.1f us  (%s)\n", A3_PROBE, cfg, n, ms * 100.f, hipGetErrorString(hipGetLastError()));
+#if A3_PROBE == 3
+    long h[8 * 32];
+    (void)hipMemcpy(h, st, sizeof(h), hipMemcpyDeviceToHost);
+    printf("  stamps (cycles since kernel entry of the wave): start->staged | per iteration: S-MFMA, softmax, PV, stores | ...\n");
+    for (int b = 0; b < 4; ++b)
+      for (int w = 0; w < 2; ++w) {
+        const long* q = h + (b * 2 + w) * 32;
+        printf("  wg %d wave %s: staged +%ld |", 12000 + b, w ? "last" : "0", (q[1] - q[0]) * 1);
+        for (int it = 0; it < 4 && q[2 + it * 5]; ++it)
+          printf(" it%d (+%ld): %ld %ld %ld %ld |", it, q[2 + it * 5] - q[0], q[3 + it * 5] - q[2 + it * 5], q[4 + it * 5] - q[3 + it * 5],
+                 q[5 + it * 5] - q[4 + it * 5], q[6 + it * 5] - q[5 + it * 5]);
+        printf("\n");
+      }
+    (void)hipMemset(st, 0, 8 * 32 * 8);
+#endif
+  }
+  return 0;
+}

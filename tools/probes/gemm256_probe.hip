@@ -126,6 +126,16 @@ int main() {
           }
         }
       }
+      {
+        const char* names[] = {"", "", "XCD 0 only (32 WGs)", "every 8th WG of each XCD (32 WGs)", "WG 0 alone", "one WG per XCD (8)",
+                               "8 WGs of XCD 0", "XCDs 0-3 (128 WGs)"};
+        for (int m = 2; m <= 7; ++m) {
+          p.skew_mode = m;
+          float ta = run<true, 8>(p, grid, 3), tb = run<true, 5>(p, grid, 3);
+          printf("      subset %-36s: full %.3f ms | no stores %.3f ms | stores cost %.3f ms\n", names[m], ta, tb, ta - tb);
+        }
+        p.skew_mode = 0;
+      }
       run<true, 5>(p, grid, 5); report_clock("no stores");
       run<true, 3>(p, grid, 5); report_clock("no DMA");
       run<true, 1>(p, grid, 5); report_clock("no LDS reads");

@@ -63,12 +63,14 @@ static float time_ms(F launch, int iters) {
 
 int main(int argc, char** argv) {
   bool quick = false;
+  int pad = 0;
   int mask = 7;                      // bv_gemm_roll bits: 1 RESIDUAL, 2 NONE, 4 GELU, 8 stores in the MFMA segment
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "quick")) quick = true;
     if (!strncmp(argv[i], "mask=", 5)) mask = atoi(argv[i] + 5);
+    if (!strncmp(argv[i], "pad=", 4)) pad = atoi(argv[i] + 4);       // extra elements in the C row pitch
   }
-  printf("roll mask %d\n", mask);
+  printf("roll mask %d, C row pitch N + %d\n", mask, pad);
   struct Shape { const char* name; int M, N, K, epi; } shapes[] = {
       {"check 256x256x128 (1 tile, 2 K-tiles)", 256, 256, 128, BV_EPI_NONE},
       {"check 512x256x192 none", 512, 256, 192, BV_EPI_NONE},
@@ -93,7 +95,7 @@ int main(int argc, char** argv) {
       {"n512 fc1 fwd  (gelu)", 100352, 3072, 768, BV_EPI_GELU},
       {"n512 out fwd  (+resid)", 100352, 768, 768, BV_EPI_RESIDUAL}};
   const size_t maxM = 401408;
-  const size_t nA = maxM * 3072, nB = (size_t)3072 * 3072, nC = maxM * 3072;
+  const size_t nA = maxM * 3072, nB = (size_t)3072 * 3072, nC = maxM * 3328;
   unsigned short *a, *b;
   void *c0, *c1, *g0, *g1;
   float *bias, *aux;
@@ -112,16 +114,17 @@ int main(int argc, char** argv) {
   for (auto& s : shapes) {
     if (quick && s.M > 70000) continue;
     const bool f32 = s.epi == BV_EPI_RESIDUAL;
-    const size_t cbytes = (size_t)s.M * s.N * (f32 ? 4 : 2);
+    const int ldc = s.N + pad;
+    const size_t cbytes = (size_t)s.M * ldc * (f32 ? 4 : 2);
     auto run = [&](int roll, void* c, void* c2) {
       bv_gemm_roll(roll ? mask : 0);
-      const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c, s.N, f32 ? 1 : 0, s.M, s.N, s.K, s.epi, bias,
+      const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c, ldc, f32 ? 1 : 0, s.M, s.N, s.K, s.epi, bias,
                                     f32 ? aux : nullptr, s.N, 0, s.epi == BV_EPI_GELU ? c2 : nullptr, 1.0f, 0,
                                     nullptr, nullptr);
       if (!ok) { printf("%s: not dispatched to the 256x256 path\n", s.name); exit(1); }
     };
-    (void)hipMemset(c0, 0xff, cbytes); (void)hipMemset(c1, 0xee, cbytes);
-    (void)hipMemset(g0, 0xff, cbytes); (void)hipMemset(g1, 0xee, cbytes);
+    (void)hipMemset(c0, 0xff, cbytes); (void)hipMemset(c1, pad ? 0xff : 0xee, cbytes);
+    (void)hipMemset(g0, 0xff, cbytes); (void)hipMemset(g1, pad ? 0xff : 0xee, cbytes);
     run(0, c0, g0);
     run(1, c1, g1);
     (void)hipDeviceSynchronize();
@@ -144,7 +147,7 @@ int main(int argc, char** argv) {
     // race screen: the new kernel twice more, bitwise against its first run
     unsigned long long bad_rr = 0;
     for (int rep = 0; rep < 2; ++rep) {
-      (void)hipMemset(c0, 0x11, cbytes);
+      (void)hipMemset(c0, pad ? 0xff : 0x11, cbytes);
       run(1, c0, g0);
       (void)hipMemset(res, 0, 16);
       cmp_words<<<2048, 256>>>((const unsigned*)c0, (const unsigned*)c1, cbytes / 4, 0, res);
