@@ -718,7 +718,7 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
 // the common sequence lengths (64 text tokens; 196/197 at 224 px; 256/257; 441 at 336 px; 576 at
 // 384 px), the next instantiated size otherwise.
 static int g_a3cfg = 0;
-// experiments: waves per workgroup of the L <= 208 kernels (0 = default)
+// A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel
 extern "C" int bv_attn_tune(int cfg) {
   const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16);
   if (cfg >= 0) { g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); }
@@ -728,11 +728,10 @@ extern "C" int bv_attn_tune(int cfg) {
 int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (L <= 64) return launch_fwd3<4, 4, 4>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 1) return launch_fwd3<13, 5, 4>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 2) return launch_fwd3<13, 7, 4>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 3) return launch_fwd3<13, 13, 4>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 4) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 208) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  // 13 key fragments: 4 waves per workgroup and 3 workgroups per CU (the third one computes while
+  // another stages its K/V: 605-650 us instead of 670-730 at n = 2048); 8 waves x 2 under bv_attn_tune(8)
+  if (L <= 208 && g_a3cfg == 8) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 448) return launch_fwd3<28, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
   return launch_fwd3<36, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
@@ -742,10 +741,6 @@ int bv_attn3_bwd(const void* qkv, const void* o, const void* d_o, const float* l
                  float* dbias, const int* kv_len, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 1) return launch_bwd3<13, 5, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 2) return launch_bwd3<13, 7, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 3) return launch_bwd3<13, 13, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208 && g_a3cfg == 4) return launch_bwd3<13, 4, 3, 3>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
   if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
   if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
   if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);

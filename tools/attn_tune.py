@@ -1,4 +1,4 @@
-"""Sweep of bv_attn_tune configurations (waves per workgroup) at the image tower's shape. GPU only."""
+"""A/B of the bv_attn_tune switches at the image tower's shape. GPU only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from attn_bench import timeit, dev, BF16
 
 def main():
   lib = _lib.load()
-  cfgs = [int(a) for a in sys.argv[1:]] or [16, 0, 4, 20]   # +16: two-sweep dQ kernel
+  cfgs = [int(a) for a in sys.argv[1:]] or [16, 0, 8]   # +16: two-sweep dQ kernel, 8: forward with 8 waves x 2 workgroups
   for name, n, L, H in (("img n=2048 L=196", 2048, 196, 12), ("img n=512 L=196", 512, 196, 12)):
     qkv = torch.randn(n * L, 3 * H * 64, device=dev).to(BF16)
     d_o = torch.randn(n * L, H * 64, device=dev).to(BF16)
