@@ -45,10 +45,15 @@ PROTOTYPES = {
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_fwd_masked": [P, P, P, P, P, c_int, c_int, c_int, P],
+    "bv_attn_fwd_dh": [P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_attn_bwd_dh": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_map_attn_fwd_dh": [P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "bv_map_attn_bwd_dh": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bv_pool_gap_masked_fwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_masked_bwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_naflex_posemb_weights": [P, P, P, c_int, c_int, c_int, P],
     "bv_patchify": [P, P, c_int, c_int, c_int, c_int, P],
+    "bv_patchify_ld": [P, P, c_int, c_int, c_int, c_int, c_int, P],
     "bv_embed_fwd": [P, P, P, P, c_int, c_int, c_int, c_int, P],
     "bv_embed_bwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_colsum": [P, c_int, c_long, P, c_int, c_int, P],

@@ -44,14 +44,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // generic (any P): one thread per output element
 __global__ __launch_bounds__(256) void patchify_scalar_kernel(const float* __restrict__ img,
                                                               bf16* __restrict__ out, int n, int Hi,
-                                                              int Wi, int P, int h, int w) {
+                                                              int Wi, int P, int h, int w, int ldo) {
+  // ldo >= K: row pitch of the output; columns [K, ldo) are written as zeros (patch sizes whose K is
+  // not a multiple of 8, e.g. 14 x 14 x 3 = 588, are padded for the GEMM's 16-byte operand loads)
   const int K = P * P * 3;
   const int P3 = P * 3;
-  const long total = (long)n * h * w * K;
+  const long total = (long)n * h * w * ldo;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
        o += (long)gridDim.x * blockDim.x) {
-    const long row = o / K;
-    const int within = (int)(o - row * K);
+    const long row = o / ldo;
+    const int within = (int)(o - row * ldo);
+    if (within >= K) { out[o] = f2bf(0.f); continue; }
     const int r = within / P3, cc = within - r * P3;
     const int px = (int)(row % w);
     const long t = row / w;
@@ -443,18 +446,23 @@ extern "C" int bv_transpose_bf16(const void* src, void* dst, int rows, int cols,
 }
 
 // models/vit.py:212-217 — im2col of the stride-P VALID patch conv.
-extern "C" int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream) {
+extern "C" int bv_patchify_ld(const float* image, void* patches, int n, int Hi, int Wi, int P, int ldo,
+                              void* stream) {
   BV_REQUIRE(n > 0 && Hi >= P && Wi >= P && P > 0, "bv_patchify: bad shape n=%d Hi=%d Wi=%d P=%d", n, Hi, Wi, P);
+  BV_REQUIRE(ldo >= P * P * 3, "bv_patchify: row pitch %d < P*P*3 = %d", ldo, P * P * 3);
   const int h = Hi / P, w = Wi / P;
   const long total = (long)n * h * w * P * P * 3;
-  if ((P * 3) % 8 == 0 && (Wi * 3) % 4 == 0 && ((uintptr_t)image % 16 == 0)) {
+  if (ldo == P * P * 3 && (P * 3) % 8 == 0 && (Wi * 3) % 4 == 0 && ((uintptr_t)image % 16 == 0)) {
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total / 8, 256, 8192)), dim3(256), 0,
                        (hipStream_t)stream, image, (bf16*)patches, n, Hi, Wi, P, h, w);
   } else {
-    hipLaunchKernelGGL(patchify_scalar_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0,
-                       (hipStream_t)stream, image, (bf16*)patches, n, Hi, Wi, P, h, w);
+    hipLaunchKernelGGL(patchify_scalar_kernel, dim3(grid_for((long)n * h * w * ldo, 256, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, image, (bf16*)patches, n, Hi, Wi, P, h, w, ldo);
   }
   return bv_check_launch("bv_patchify");
+}
+extern "C" int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream) {
+  return bv_patchify_ld(image, patches, n, Hi, Wi, P, P * P * 3, stream);
 }
 
 // models/proj/image_text/text_transformer.py:63-70

@@ -142,6 +142,11 @@ class _W:
     self.bf, self.f32, self.grad = sh, ma, g
     self.store = store
     self._t, self._t_ver = None, -1
+    # input width not a multiple of 8 (the 14 x 14 x 3 = 588 stem of So400m/14): the GEMM operands are
+    # padded to kpad columns / rows of zeros (16-byte operand loads); the activations arrive padded
+    self.kpad = None
+    if self.bf.dim() == 2 and self.bf.shape[0] % 8:
+      self.kpad = (self.bf.shape[0] + 7) // 8 * 8
 
   def bf_t(self):
     """[out][in] bf16 image of a 2-D (in,out) kernel, re-transposed only when the
@@ -149,7 +154,12 @@ class _W:
     on the k-major ("NT") GEMM path."""
     ver = self.store.shadow_version
     if self._t_ver != ver:
-      self._t = ops.transpose_bf16(self.bf, self._t)
+      if self.kpad:
+        if self._t is None:
+          self._t = torch.zeros((self.bf.shape[1], self.kpad), device=self.bf.device, dtype=BF16)
+        ops.transpose_bf16(self.bf, self._t[:, :self.bf.shape[0]])
+      else:
+        self._t = ops.transpose_bf16(self.bf, self._t)
       self._t_ver = ver
     return self._t
 
@@ -160,7 +170,14 @@ def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
 
 def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
   """dW += x^T dy (split-K atomics into the grad buffer), db += colsum(dy)."""
-  if w.grad is not None:
+  if w.grad is not None and w.kpad:
+    # padded input width: the product lands in a [kpad][out] scratch (its last rows are exactly 0: the
+    # pad columns of x are) and the real rows are added to the gradient
+    K, N = w.grad.shape
+    tmp = torch.zeros((w.kpad, N), device=w.grad.device, dtype=F32)
+    ops.gemm(x_bf, dy_bf, a_kmajor=False, b_kmajor=False, out=tmp, epilogue=ops.EPI_ATOMIC)
+    ops.batchsum(tmp, w.grad, 1, K, N)
+  elif w.grad is not None:
     ops.gemm(x_bf, dy_bf, a_kmajor=False, b_kmajor=False, out=w.grad, epilogue=ops.EPI_ATOMIC)
   if b is not None and b.grad is not None:
     ops.colsum(dy_bf if dy_for_bias is None else dy_for_bias, b.grad)

@@ -212,8 +212,9 @@ class _Model:
       raise NotImplementedError("nposemb > 64")
     if pool_type not in ("map", "gap", "max", "none"):
       raise ValueError(f"Unknown pool type: '{pool_type}'")
-    if width % num_heads or width // num_heads != 64:
-      raise NotImplementedError(f"attention kernels need head_dim 64, got {width}/{num_heads}")
+    if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
+      raise NotImplementedError(f"attention kernels need a head_dim that is a multiple of 8 and <= 128 (64 is the "
+                                f"fast path), got {width}/{num_heads}")
     self.num_classes, self.width, self.depth = num_classes, width, depth
     self.mlp_dim, self.num_heads, self.rep_size = mlp_dim or 4 * width, num_heads, rep_size
     self.pool_type, self.head_zeroinit, self.scan = pool_type, head_zeroinit, scan

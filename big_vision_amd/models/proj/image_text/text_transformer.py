@@ -123,8 +123,9 @@ class _Model:
       raise NotImplementedError("dropout > 0 is not on the accelerated path")
     if pool_type not in ("last", "first", "mean", "gap", "map"):
       raise NotImplementedError(f"Cannot do pooling '{pool_type}'")
-    if width % num_heads or width // num_heads != 64:
-      raise NotImplementedError(f"attention kernels need head_dim 64, got {width}/{num_heads}")
+    if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
+      raise NotImplementedError(f"attention kernels need a head_dim that is a multiple of 8 and <= 128 (64 is the "
+                                f"fast path), got {width}/{num_heads}")
     self.num_classes, self.width, self.depth, self.mlp_dim = num_classes, width, depth, mlp_dim
     self.num_heads, self.vocab_size, self.pool_type, self.scan = num_heads, vocab_size, pool_type, scan
     self.name = name

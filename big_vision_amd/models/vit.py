@@ -233,8 +233,9 @@ class _Model:
       raise ValueError(f"Unknown pool type: '{pool_type}'")
     if dropout:
       raise NotImplementedError("dropout > 0 is not on the accelerated path (all in-scope configs use 0)")
-    if width % num_heads or width // num_heads != 64:
-      raise NotImplementedError(f"attention kernels need head_dim 64, got {width}/{num_heads}")
+    if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
+      raise NotImplementedError(f"attention kernels need a head_dim that is a multiple of 8 and <= 128 (64 is the "
+                                f"fast path), got {width}/{num_heads}")
     self.num_classes, self.patch_size = num_classes, tuple(patch_size)
     self.width, self.depth, self.mlp_dim = width, depth, mlp_dim or 4 * width
     self.num_heads, self.posemb, self.rep_size = num_heads, posemb, rep_size

@@ -126,15 +126,27 @@ def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_b
 
 
 # --------------------------------------------------------------- Attention --
+def _head_dim(numel, rows, parts, H, what):
+  Dh, rem = divmod(numel, rows * parts * H)
+  assert rem == 0 and Dh % 8 == 0 and 8 <= Dh <= 128, f"{what}: head dim {numel}/({rows}*{parts}*{H}) unsupported"
+  return Dh
+
+
 def attn_fwd(qkv, n, L, H, kv_len=None):
-  """kv_len (int32 [n], optional): valid keys per sample (key-padding mask of the NaFlex tower)."""
+  """qkv [n*L, 3*H*Dh] (Dh inferred; 64 takes the LDS-resident kernels, other multiples of 8 up to 128
+  and sequences longer than 576 the general ones).  kv_len (int32 [n], optional): valid keys per sample
+  (key-padding mask of the NaFlex tower)."""
   _chk(qkv, BF16, "attn.qkv")
-  assert qkv.is_contiguous() and qkv.numel() == n * L * 3 * H * 64, qkv.shape
-  o = torch.empty((n * L, H * 64), device=qkv.device, dtype=BF16)
+  assert qkv.is_contiguous()
+  Dh = _head_dim(qkv.numel(), n * L, 3, H, "attn_fwd")
+  o = torch.empty((n * L, H * Dh), device=qkv.device, dtype=BF16)
   lse = torch.empty((n, H, L), device=qkv.device, dtype=F32)
   if kv_len is not None:
     _chk(kv_len, torch.int32, "attn.kv_len")
     assert kv_len.is_contiguous() and kv_len.numel() == n
+  if Dh != 64 or L > 576:
+    _lib.call("bv_attn_fwd_dh", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, Dh, _stream())
+  elif kv_len is not None:
     _lib.call("bv_attn_fwd_masked", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, _stream())
   else:
     _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream())
@@ -142,18 +154,23 @@ def attn_fwd(qkv, n, L, H, kv_len=None):
 
 
 def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None, kv_len=None):
-  """dbias (fp32, 3*H*64 elements): += column sums of dqkv (the q/k/v bias gradients)."""
+  """dbias (fp32, 3*H*Dh elements): += column sums of dqkv (the q/k/v bias gradients)."""
   _chk(qkv, BF16, "attn.qkv"); _chk(o, BF16, "attn.o"); _chk(d_o, BF16, "attn.do")
   assert d_o.is_contiguous() and o.is_contiguous()
+  Dh = _head_dim(qkv.numel(), n * L, 3, H, "attn_bwd")
   if dqkv is None:
     dqkv = torch.empty_like(qkv)
   if dbias is not None:
     _chk(dbias, F32, "attn.dbias")
-    assert dbias.is_contiguous() and dbias.numel() == 3 * H * 64
+    assert dbias.is_contiguous() and dbias.numel() == 3 * H * Dh
   delta = torch.empty((n, H, L), device=qkv.device, dtype=F32)
-  rows = torch.empty((n, 3 * H * 64), device=qkv.device, dtype=F32) if dbias is not None else None
+  rows = torch.empty((n, 3 * H * Dh), device=qkv.device, dtype=F32) if dbias is not None else None
   if kv_len is not None:
     _chk(kv_len, torch.int32, "attn.kv_len")
+  if Dh != 64 or L > 576:
+    _lib.call("bv_attn_bwd_dh", _p(qkv), _p(d_o), _p(lse), _p(kv_len), _p(delta), _p(dqkv), _p(rows),
+              n, L, H, Dh, _stream())
+  elif kv_len is not None:
     _lib.call("bv_attn_bwd_masked", _p(qkv), _p(d_o), _p(lse), _p(kv_len), _p(delta), _p(dqkv), _p(rows),
               n, L, H, _stream())
   else:
@@ -165,13 +182,17 @@ def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None, kv_len=None):
 
 
 def map_attn_fwd(q, kv, n, L, H, kv_len=None):
-  """kv_len (int32 [n], optional): valid keys per sample (NaFlex pool mask)."""
+  """q [n, H*Dh], kv [n*L, 2*H*Dh].  kv_len (int32 [n], optional): valid keys per sample (NaFlex pool mask)."""
   _chk(q, BF16, "map_attn.q"); _chk(kv, BF16, "map_attn.kv")
   assert q.is_contiguous() and kv.is_contiguous()
-  o = torch.empty((n, H * 64), device=q.device, dtype=BF16)
+  Dh = _head_dim(q.numel(), n, 1, H, "map_attn_fwd")
+  o = torch.empty((n, H * Dh), device=q.device, dtype=BF16)
   p = torch.empty((n, H, L), device=q.device, dtype=F32)
   if kv_len is not None:
     _chk(kv_len, torch.int32, "map_attn.kv_len")
+  if Dh != 64 or L > 2048:
+    _lib.call("bv_map_attn_fwd_dh", _p(q), _p(kv), _p(o), _p(p), _p(kv_len), n, L, H, Dh, _stream())
+  elif kv_len is not None:
     _lib.call("bv_map_attn_fwd_masked", _p(q), _p(kv), _p(o), _p(p), _p(kv_len), n, L, H, _stream())
   else:
     _lib.call("bv_map_attn_fwd", _p(q), _p(kv), _p(o), _p(p), n, L, H, _stream())
@@ -181,9 +202,13 @@ def map_attn_fwd(q, kv, n, L, H, kv_len=None):
 def map_attn_bwd(q, kv, p, d_o, n, L, H):
   _chk(d_o, BF16, "map_attn.do")
   assert d_o.is_contiguous()
+  Dh = _head_dim(q.numel(), n, 1, H, "map_attn_bwd")
   dq = torch.empty_like(q)
   dkv = torch.empty_like(kv)
-  _lib.call("bv_map_attn_bwd", _p(q), _p(kv), _p(p), _p(d_o), _p(dq), _p(dkv), n, L, H, _stream())
+  if Dh != 64 or L > 2048:
+    _lib.call("bv_map_attn_bwd_dh", _p(q), _p(kv), _p(p), _p(d_o), _p(dq), _p(dkv), n, L, H, Dh, _stream())
+  else:
+    _lib.call("bv_map_attn_bwd", _p(q), _p(kv), _p(p), _p(d_o), _p(dq), _p(dkv), n, L, H, _stream())
   return dq, dkv
 
 
@@ -193,8 +218,10 @@ def patchify(image, P):
   assert image.is_contiguous() and image.dim() == 4 and image.shape[3] == 3, image.shape
   n, Hi, Wi, _ = image.shape
   h, w = Hi // P, Wi // P
-  out = torch.empty((n * h * w, P * P * 3), device=image.device, dtype=BF16)
-  _lib.call("bv_patchify", _p(image), _p(out), n, Hi, Wi, P, _stream())
+  K = P * P * 3
+  Kp = (K + 7) // 8 * 8    # rows padded with zero columns when K is not a multiple of 8 (14 x 14 x 3 = 588 -> 592)
+  out = torch.empty((n * h * w, Kp), device=image.device, dtype=BF16)
+  _lib.call("bv_patchify_ld", _p(image), _p(out), n, Hi, Wi, P, Kp, _stream())
   return out, (h, w)
 
 

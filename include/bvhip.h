@@ -186,6 +186,21 @@ int bv_map_attn_bwd(const void* q, const void* kv, const float* p, const void* d
  * get probability 0; bv_map_attn_bwd needs no mask (it works from the saved probabilities). */
 int bv_map_attn_fwd_masked(const void* q, const void* kv, void* o, float* p, const int* kv_len, int n, int L,
                            int H, void* stream);
+/* Head dims other than 64 (Dh % 8 == 0, Dh <= 128) and any sequence length: So400m (1152 / 16 = 72),
+ * `mu` (32 / 2 = 16, the variant of the reference's own tests), Ti / S at other widths
+ * (models/vit.py:284-303 decode_variant; nn.MultiHeadDotProductAttention models/vit.py:93-98, MAP head
+ * :176-178).  Same tensors as bv_attn_fwd / bv_attn_bwd_masked / bv_map_attn_* with 64 -> Dh:
+ * qkv [n*L][3][H][Dh], o [n*L][H][Dh], lse / delta [n][H][L], dbias_rows [n][3][H][Dh] (optional),
+ * kv_len optional (int32 [n], >= 1).  Flash-style kernels (attention_dh.hip); the Dh = 64 entry points
+ * above stay the fast path of every BASELINE model. */
+int bv_attn_fwd_dh(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, int Dh,
+                   void* stream);
+int bv_attn_bwd_dh(const void* qkv, const void* d_o, const float* lse, const int* kv_len, float* delta,
+                   void* dqkv, float* dbias_rows, int n, int L, int H, int Dh, void* stream);
+int bv_map_attn_fwd_dh(const void* q, const void* kv, void* o, float* p, const int* kv_len, int n, int L, int H,
+                       int Dh, void* stream);
+int bv_map_attn_bwd_dh(const void* q, const void* kv, const float* p, const void* d_o, void* dq, void* dkv, int n,
+                       int L, int H, int Dh, void* stream);
 /* Masked global average pooling of the NaFlex tower (naflex_vit.py:264-266): mean over the first
  * len[b] tokens of [n][L][D] fp32; the backward writes dy / len[b] to those rows, 0 to the padding. */
 int bv_pool_gap_masked_fwd(const float* x, float* y, const int* len, int n, int L, int D, void* stream);
@@ -202,6 +217,10 @@ int bv_naflex_posemb_weights(const int* yabs, const int* xabs, void* W, int n, i
  * flattening order (row, col, channel), the im2col of the stride-P VALID conv
  * of models/vit.py:212-217. */
 int bv_patchify(const float* image, void* patches, int n, int Hi, int Wi, int P, void* stream);
+/* The same with a row pitch ldo >= P*P*3 (elements); columns [P*P*3, ldo) are written as zeros.  Patch
+ * sizes whose P*P*3 is not a multiple of 8 (So400m/14: 588) pad their rows to the next multiple for the
+ * 16-byte operand loads of bv_gemm_bf16. */
+int bv_patchify_ld(const float* image, void* patches, int n, int Hi, int Wi, int P, int ldo, void* stream);
 /* x[(i*L+l)] = table[ids[i*L+l]] + pos[l]  (nn.Embed + pos_embedding,
  * models/proj/image_text/text_transformer.py:63-70).  fp32 in/out. */
 int bv_embed_fwd(const int* ids, const float* table, const float* pos, float* x, int n, int L,

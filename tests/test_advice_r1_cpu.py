@@ -68,7 +68,7 @@ def test_update_fn_refreshes_a_dirty_shadow(dry):
   names = [n for n, _ in dry]
   cast_full = [i for i, (n, a) in enumerate(dry) if n == "bv_cast_bf16" and a[2] == store.count]
   assert cast_full, "update_fn did not refresh the bf16 shadow of the loaded weights"
-  first_fwd = min(i for i, n in enumerate(names) if n in ("bv_patchify", "bv_embed_fwd", "bv_gemm_bf16"))
+  first_fwd = min(i for i, n in enumerate(names) if n in ("bv_patchify", "bv_patchify_ld", "bv_embed_fwd", "bv_gemm_bf16"))
   assert cast_full[0] < first_fwd
   assert not store._shadow_dirty
 

@@ -37,7 +37,7 @@ def _resources(src, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["gemm256.hip", "attention2.hip", "attention3.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
+@pytest.mark.parametrize("src", ["gemm256.hip", "attention2.hip", "attention3.hip", "attention_dh.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
                                  "elementwise.hip", "loss_optim.hip"])
 def test_no_spills_no_scratch(src, tmp_path):
   res = _resources(src, tmp_path)
@@ -70,7 +70,7 @@ def test_asm_loads_are_not_touched_before_their_wait(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["attention3.hip", "gemm256.hip"])
+@pytest.mark.parametrize("src", ["attention3.hip", "attention_dh.hip", "gemm256.hip"])
 def test_no_mfma_result_is_read_straight_across_a_branch(src, tmp_path):
   """hipcc (ROCm 7.2) pads the MFMA-write -> VALU-read hazard inside a basic block, but emitted no wait
   states when the reader was the first instruction of a block entered by a taken branch right behind

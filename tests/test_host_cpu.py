@@ -128,7 +128,9 @@ def test_error_conventions():
   with pytest.raises(ValueError):
     vit.Model(num_classes=None, variant="B/16", posemb="nope")
   with pytest.raises(NotImplementedError):
-    vit.Model(num_classes=None, width=96, num_heads=3)   # head_dim 32: not on the kernel path
+    vit.Model(num_classes=None, width=100, num_heads=2)   # head_dim 50: not a multiple of 8
+  vit.Model(num_classes=None, width=96, num_heads=3)     # head_dim 32: the general attention kernels
+  assert vit.Model(num_classes=None, variant="So400m/14").width // 16 == 72
 
 
 def test_posemb_sincos_2d_matches_oracle():

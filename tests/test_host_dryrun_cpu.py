@@ -64,7 +64,7 @@ def test_single_pass_launch_counts(dry):
   state, meas = fn(state, None, batch)
   assert calls["bv_attn_fwd"] == BLOCKS and calls["bv_attn_bwd"] == BLOCKS
   assert calls["bv_siglip_loss"] == 1 and calls["bv_adam_step"] == 1 and calls["bv_sqnorm"] == 1
-  assert calls["bv_embed_fwd"] == 1 and calls["bv_embed_bwd"] == 1 and calls["bv_patchify"] == 1
+  assert calls["bv_embed_fwd"] == 1 and calls["bv_embed_bwd"] == 1 and calls["bv_patchify_ld"] == 1
   assert calls["bv_gemm_bf16_colsum"] == BLOCKS + 1            # fc2 dX with fused Dense_0 bias sums (+ MAP head MLP)
   assert set(meas) == {"training_loss", "l2_grads", "l2_params", "l2_updates"}
 

@@ -335,6 +335,68 @@ def test_map_attention(dev, n, L, H):
   assert_close(dkv, kvr.grad, 2e-2, 2e-2 * kvr.grad.abs().max().item(), "map dkv")
 
 
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("n,L,H,Dh", [(2, 256, 2, 72), (3, 64, 2, 16), (1, 300, 1, 128), (2, 729, 1, 72),
+                                       (3, 33, 2, 32), (2, 196, 3, 80), (2, 5, 1, 8), (1, 1000, 1, 64),
+                                       (2, 100, 2, 104)])
+def test_attention_other_head_dims(dev, n, L, H, Dh, masked):
+  """bv_attn_fwd_dh / bv_attn_bwd_dh (attention_dh.hip): head dims of So400m (72), `mu` (16), H (80),
+  G (104) ... and sequences beyond the LDS-resident kernels' 576 (Dh = 64 at L = 1000), with and without
+  key-padding lengths, vs fp64 torch attention; per-sample bias-gradient rows through the colsum."""
+  from big_vision_amd import ops
+  qkv = rnd((n * L, 3 * H * Dh), dev, 11, 1.5, dtype=BF16)
+  lens = [L, max(1, L // 3), L - 1][:n] if masked else [L] * n
+  kv_len = torch.tensor(lens, device=dev, dtype=torch.int32) if masked else None
+  qr = qkv.double().requires_grad_(True)
+  q, k, v = qr.view(n, L, 3, H, Dh).unbind(2)
+  s = torch.einsum("nqhd,nkhd->nhqk", q / Dh ** 0.5, k)
+  mask = torch.arange(L, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]
+  s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+  p = torch.softmax(s, -1)
+  o_ref = torch.einsum("nhqk,nkhd->nqhd", p, v).reshape(n * L, H * Dh)
+  o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
+  assert o.shape == (n * L, H * Dh)
+  assert_close(lse, torch.logsumexp(s, -1), 1e-4, 1e-3, "lse")
+  assert_close(o, o_ref, 2e-2, 2e-2, "attn out")
+  d_o = rnd((n * L, H * Dh), dev, 12, dtype=BF16)
+  o_ref.backward(d_o.double())
+  db = torch.full((3 * H * Dh,), 0.25, device=dev)
+  dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, kv_len=kv_len, dbias=db)
+  g = qr.grad
+  assert_close(dqkv, g, 3e-2, 3e-2 * g.abs().max().item(), "dqkv")
+  assert_close(db, 0.25 + g.sum(0), 2e-2, 2e-2 * g.abs().sum(0).max().item(), "qkv bias grad")
+  dkv = dqkv.view(n, L, 3, H, Dh)[:, :, 1:]
+  for i, ln in enumerate(lens):
+    assert (dkv[i, ln:] == 0).all(), "masked keys must get zero dK / dV"
+  # run-to-run bit-equality of everything but the atomically summed bias rows
+  o2, lse2 = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
+  assert torch.equal(o, o2) and torch.equal(lse, lse2)
+  assert torch.equal(dqkv, ops.attn_bwd(qkv, o, d_o, lse, n, L, H, kv_len=kv_len))
+
+
+@pytest.mark.parametrize("n,L,H,Dh", [(4, 256, 2, 72), (3, 16, 2, 16), (2, 70, 1, 128), (2, 3000, 1, 64)])
+def test_map_attention_other_head_dims(dev, n, L, H, Dh):
+  from big_vision_amd import ops
+  q = rnd((n, H * Dh), dev, 1, dtype=BF16)
+  kv = rnd((n * L, 2 * H * Dh), dev, 2, dtype=BF16)
+  lens = torch.tensor([L, max(1, L // 2), L - 1, 1][:n], device=dev, dtype=torch.int32)
+  qr = q.double().requires_grad_(True); kvr = kv.double().requires_grad_(True)
+  k, v = kvr.view(n, L, 2, H, Dh).unbind(2)
+  s = torch.einsum("nhd,nkhd->nhk", qr.view(n, H, Dh) / Dh ** 0.5, k)
+  mask = torch.arange(L, device=dev)[None, :] < lens[:, None].long()
+  s = s.masked_fill(~mask[:, None, :], float("-inf"))
+  p = torch.softmax(s, -1)
+  o_ref = torch.einsum("nhk,nkhd->nhd", p, v).reshape(n, H * Dh)
+  o, pp = ops.map_attn_fwd(q, kv, n, L, H, kv_len=lens)
+  assert_close(pp, p, 1e-3, 1e-5, "map p")
+  assert_close(o, o_ref, 1e-2, 1e-2, "map o")
+  d_o = rnd((n, H * Dh), dev, 3, dtype=BF16)
+  o_ref.backward(d_o.double())
+  dq, dkv = ops.map_attn_bwd(q, kv, pp, d_o, n, L, H)
+  assert_close(dq, qr.grad, 2e-2, 2e-2 * qr.grad.abs().max().item(), "map dq")
+  assert_close(dkv, kvr.grad, 2e-2, 2e-2 * kvr.grad.abs().max().item(), "map dkv")
+
+
 # ----------------------------------------------------------- data movers -----
 @pytest.mark.parametrize("P,res", [(16, 64), (8, 32), (14, 28)])
 def test_patchify(dev, P, res):
@@ -344,7 +406,10 @@ def test_patchify(dev, P, res):
   ref, (h, w) = O.extract_patches(img.cpu(), (P, P))
   out, hw = ops.patchify(img, P)
   assert hw == (h, w)
-  assert torch.equal(out.cpu(), ref.reshape(-1, P * P * 3).to(BF16))
+  K = P * P * 3   # rows are padded with zeros to a multiple of 8 columns (14 x 14 x 3 = 588 -> 592)
+  assert out.shape[1] == (K + 7) // 8 * 8
+  assert torch.equal(out.cpu()[:, :K], ref.reshape(-1, K).to(BF16))
+  assert (out[:, K:] == 0).all()
 
 
 def test_embed(dev):

@@ -147,6 +147,26 @@ def test_tiny_tok_pooling(dev):
   _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71, floor=True, rel_max=4e-2)
 
 
+def test_mu_variant_step(dev):
+  """`mu/16` (models/vit.py:297-300: width 32, depth 1, mlp 128, 2 heads -> head dim 16), the variant the
+  reference's own tests and the SURVEY's golden-vector plan use: the general attention kernels
+  (attention_dh.hip) inside the full step."""
+  image_cfg = dict(variant="mu/16", pool_type="map")
+  text_cfg = dict(variant="mu")
+  _run_case(dev, image_cfg, text_cfg, E=32, n=8, res=64, seq=16, vocab=100, floor=True, case="siglip mu/16 n=8")
+
+
+def test_so400m_shapes_step(dev):
+  """So400m/14 (width 1152, 16 heads -> head dim 72, mlp 4304, 14 x 14 patches: K = 588 padded to 592,
+  256 tokens at 224 px) + text So400m, the flagship SigLIP size, cut to 2 blocks per tower for the CPU
+  oracle: head dim 72 self-attention and MAP head, ragged GEMM shapes (N = 4304, 1152 = 4.5 x 256),
+  the zero-padded stem and its gradient."""
+  image_cfg = dict(variant="So400m/14", pool_type="map", depth=2)
+  text_cfg = dict(variant="So400m", depth=2)
+  _run_case(dev, image_cfg, text_cfg, E=1152, n=4, res=224, seq=16, vocab=32_000, floor=True,
+            case="siglip So400m/14 depth2 n=4")
+
+
 LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]
 
 
