@@ -42,6 +42,7 @@ PROTOTYPES = {
     "bv_attn_fwd_masked": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_attn_bwd_masked": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_attn_impl": [c_int],
+    "bv_attn_tune": [c_int],
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_fwd_masked": [P, P, P, P, P, c_int, c_int, c_int, P],

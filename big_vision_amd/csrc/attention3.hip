@@ -107,7 +107,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       a = mfma16(k0, q0, a);
       a = mfma16(k1, q1, a);
       s[f] = a;
-      if (KF > 13 || (f & 1)) __builtin_amdgcn_sched_barrier(0);   // bound load hoisting (register pressure)
+      // bound load hoisting (register pressure): 2 fragments' operands in flight at 128 VGPRs, 4 at 168
+      if (KF > 13 || (WPS >= 4 ? (f & 1) : (f & 3) == 3)) __builtin_amdgcn_sched_barrier(0);
     }
     // the NEXT fragment of this wave goes straight into the registers the scores no longer need
     // (rows >= L load nothing); its latency hides behind the softmax and the P V products
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
         const bf16x8 vf = t64_trpair(Vt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
         oa[d] = mfma16(vf, pf, oa[d]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (WPS >= 4 || (fp & 1)) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (KF & 1) {
       const s16x4 pf = pack4(s[KF - 1]);

@@ -220,7 +220,16 @@ class VitExec:
 
 
 class _Model:
-  """ViT model (configuration holder + Flax-like init/apply)."""
+  """ViT model (configuration holder + Flax-like init/apply).
+
+  Two reference arguments are accepted for config compatibility and have no effect here, by design:
+  `remat_policy` (models/vit.py:129-148: XLA rematerialisation of scanned blocks) - what the backward
+  keeps or re-derives is decided by the trainer's explicit contexts (full / light, DESIGN.md section 3);
+  `dtype_mm` (models/vit.py:209: the dtype matmul inputs are cast to) - the contractions always run
+  on bf16 MFMA operands with fp32 accumulation, the precision `dtype_mm="bfloat16"` asks for and
+  what `float32` + XLA's default TPU matmul precision amounts to; parameters, residual stream,
+  LayerNorm, softmax and the loss stay fp32 in both.
+  """
 
   def __init__(self, num_classes: Optional[int] = None, patch_size: Sequence[int] = (16, 16),
                width: int = 768, depth: int = 12, mlp_dim: Optional[int] = None, num_heads: int = 12,

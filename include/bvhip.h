@@ -174,6 +174,10 @@ int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float* lse, const
  * prefetched fragments, exact delta), 2 = attention2.hip.  impl < 0 only queries; returns the
  * old value. */
 int bv_attn_impl(int impl);
+/* A/B switches of attention3.hip (default 0): 8 = the forward of the 13-key-fragment shapes (L = 196 / 197)
+ * with 8 waves x 2 workgroups per CU instead of 4 x 3; +16 = always the two-sweep dQ kernel.  cfg < 0 only
+ * queries; returns the old value. */
+int bv_attn_tune(int cfg);
 
 /* Single-query attention of the MAP head (models/vit.py:176-178): q [n][H][64]
  * bf16, kv packed [n*L][2][H][64] bf16 -> o [n][H][64] bf16, probabilities p
