@@ -205,6 +205,13 @@ def main():
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     return spawn_ranks(args.gpus)   # plain `python bench.py --gpus N`: one process per GPU, started here
 
+  # stdout carries exactly ONE line (rank 0's JSON).  Libraries write to fd 1 too (RCCL prints its
+  # version banner there when a communicator is created): from here on fd 1 points at stderr and the
+  # JSON line goes to the saved descriptor.
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
+
   from big_vision_amd import _lib, dp
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
@@ -301,8 +308,13 @@ def main():
                         "share_of_step_time": ms / (1e3 * dt)}
   if world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-  print(json.dumps(line), flush=True)
+  sys.stdout.flush()
+  os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":
-  main()
+  try:
+    main()
+  finally:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+      torch.distributed.destroy_process_group()

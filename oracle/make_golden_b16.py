@@ -21,11 +21,19 @@ CFG = dict(width=768, depth=12, mlp_dim=3072, num_heads=12, patch=16, res=224, v
            temperature_init=10.0, bias_init=-10.0, seed=0, perturb_seed=123, batch_seed=1)
 IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=32_000)
+# second fixture: the So400m/14 shapes (width 1152, 16 heads -> head dim 72, mlp 4304, 14 x 14 patches, 256
+# tokens), cut to 2 blocks per tower: pins the oracle where the general attention kernels and the padded
+# stem are checked against it (tests/test_siglip_step_gpu.py::test_so400m_shapes_step)
+CFG_SO = dict(width=1152, depth=2, mlp_dim=4304, num_heads=16, patch=14, res=224, vocab=32_000, seq=16, n=2,
+              temperature_init=10.0, bias_init=-10.0, seed=3, perturb_seed=321, batch_seed=2)
+IMAGE_CFG_SO = dict(variant="So400m/14", pool_type="map", depth=2)
+TEXT_CFG_SO = dict(variant="So400m", depth=2, vocab_size=32_000)
+FIXTURES = {"b16": (CFG, IMAGE_CFG, TEXT_CFG), "so400m_d2": (CFG_SO, IMAGE_CFG_SO, TEXT_CFG_SO)}
 
 
-def make_inputs(dtype=torch.float32):
+def make_inputs(dtype=torch.float32, tag="b16"):
   """Seeded weights (Flax layout, biases / scales perturbed) and batch - shared with the test."""
-  c = CFG
+  c, IMAGE_CFG, TEXT_CFG = FIXTURES[tag]
   params = O.init_two_towers(c["seed"], (c["res"], c["res"]), c["seq"], image_cfg=IMAGE_CFG, text_cfg=TEXT_CFG,
                              out_dim=(None, c["width"]), temperature_init=c["temperature_init"],
                              bias_init=c["bias_init"], dtype=dtype)
@@ -36,10 +44,10 @@ def make_inputs(dtype=torch.float32):
   return O.recover_tree(flat), image, text
 
 
-def main():
+def main(tag="b16"):
   from transformers import SiglipConfig, SiglipModel
-  c = CFG
-  params, image, text = make_inputs()
+  c, IMAGE_CFG, TEXT_CFG = FIXTURES[tag]
+  params, image, text = make_inputs(tag=tag)
   hf_cfg = SiglipConfig(
       text_config=dict(hidden_size=c["width"], intermediate_size=c["mlp_dim"], num_hidden_layers=c["depth"],
                        num_attention_heads=c["num_heads"], vocab_size=c["vocab"], max_position_embeddings=c["seq"],
@@ -62,7 +70,7 @@ def main():
     err = (a - b).abs().max().item()
     print(f"oracle(fp64) vs HF(fp64) {name}: max abs err {err:.3e}")
     assert err < 1e-6, name
-  dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "siglip_hf_b16.npz")
+  dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", f"siglip_hf_{tag}.npz")
   np.savez_compressed(dst, hf_zimg=res.image_embeds.numpy(), hf_ztxt=res.text_embeds.numpy(),
                       hf_logits=res.logits_per_image.numpy(), hf_loss=res.loss.numpy(),
                       param_checksum=np.asarray(sum(float(v.double().sum()) for _, v in O.tree_flatten_with_names(params))),
@@ -71,4 +79,5 @@ def main():
 
 
 if __name__ == "__main__":
-  main()
+  for t in (sys.argv[1:] or list(FIXTURES)):
+    main(t)
