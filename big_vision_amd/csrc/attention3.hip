@@ -683,7 +683,8 @@ int launch_fwd3(const void* qkv, void* o, float* lse, const int* kv_len, int n, 
   }
   return bv_check_launch("bv_attn_fwd");
 }
-template <int KF, int NW, int WPS, int WPS2>
+// NW / WPS: the dQ kernel, NW2 / WPS2: the dK,dV kernel (waves per workgroup / per SIMD)
+template <int KF, int NW, int WPS, int WPS2, int NW2 = NW>
 int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                 float* dbias, const int* kv_len, int n, int L, int H, hipStream_t s) {
   const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
@@ -706,9 +707,9 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
   }
   int rc = bv_check_launch("bv_attn_bwd(dq)");
   if (rc) return rc;
-  const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)NW * 128 * 4;
-  set_lds(attn3_bwd_dkv_kernel<KF, NW, WPS2>, sh2);
-  hipLaunchKernelGGL((attn3_bwd_dkv_kernel<KF, NW, WPS2>), dim3(n * H), dim3(NW * 64), sh2, s, (const bf16*)qkv,
+  const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)NW2 * 128 * 4;
+  set_lds(attn3_bwd_dkv_kernel<KF, NW2, WPS2>, sh2);
+  hipLaunchKernelGGL((attn3_bwd_dkv_kernel<KF, NW2, WPS2>), dim3(n * H), dim3(NW2 * 64), sh2, s, (const bf16*)qkv,
                      (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
   return bv_check_launch("bv_attn_bwd(dkv)");
 }

@@ -86,3 +86,22 @@ def test_two_ranks_over_rccl(dev):
     pytest.skip("needs two GPUs (the driver's multi-GPU box); the one-GPU test above issues the same RCCL calls")
   sys.path.insert(0, os.path.join(ROOT, "tests"))
   _check(_run(2, force=False), dev)
+
+
+def test_bench_stdout_is_one_json_line_with_rccl_in_the_loop():
+  """bench.py contract: rank 0 prints ONE JSON line.  RCCL writes a version banner to stdout when a
+  communicator is created; bench.py points fd 1 at stderr and writes its line to the saved descriptor.
+  Runs the real benchmark command (small batch) on a one-rank RCCL group with the collectives forced on."""
+  import json
+  import subprocess
+  import test_dp_two_ranks_gpu as T
+  env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+             MASTER_PORT=str(T._free_port()), BV_DP_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--global-batch", "32", "--steps", "1",
+                      "--warmup", "1", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True,
+                     text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, r.stdout
+  line = json.loads(lines[0])
+  assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 32 and math.isfinite(line["value"])
