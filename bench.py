@@ -96,6 +96,11 @@ def pmc_traffic(world, micro):
     return None, None
 
 
+# Activations between the encoder blocks: "float32" is the reference's arithmetic (models/vit.py keeps
+# them in fp32), "bfloat16" the measured option of DESIGN.md section 3 (parity inside SURVEY 8c's bounds).
+RESIDUAL_STREAM = "float32"
+
+
 def make_config(total_steps):
   from big_vision_amd.compat.ml_collections import ConfigDict
   c = ConfigDict()
@@ -200,6 +205,8 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--cpu-sample", type=int, default=16)
   ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
+  ap.add_argument("--residual-stream", default=RESIDUAL_STREAM, choices=("float32", "bfloat16"),
+                  help="dtype of the activations between the encoder blocks (config.residual_stream)")
   args = ap.parse_args()
 
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -232,6 +239,7 @@ def main():
   total_steps = max(20_000, args.steps + args.warmup)
   config = make_config(total_steps)
   config.microbatch = args.microbatch
+  config.residual_stream = args.residual_stream
   image, text = synthetic_batch(n, dev, seed=1 + comm.rank)
   state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,
                                      total_steps=total_steps, device=dev)
@@ -285,6 +293,7 @@ def main():
       "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
                              "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
                  "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
+                 "residual_stream": args.residual_stream,
                  "recompute": (f"{max(0, n // args.microbatch - update_fn.state_cache['keep_n'])} of "
                                f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
                                f"(the others keep {'light' if update_fn.state_cache['light'] else 'full'} "

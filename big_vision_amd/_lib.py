@@ -36,7 +36,9 @@ PROTOTYPES = {
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
+    "bv_layernorm_fwd_bf16x": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
+    "bv_layernorm_bwd_bf16x": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_attn_fwd_masked": [P, P, P, P, c_int, c_int, c_int, P],
@@ -60,6 +62,7 @@ PROTOTYPES = {
     "bv_colsum": [P, c_int, c_long, P, c_int, c_int, P],
     "bv_batchsum": [P, P, c_int, c_int, c_int, P],
     "bv_cast_bf16": [P, P, c_long, P],
+    "bv_cast_f32": [P, P, c_long, P],
     "bv_transpose_bf16": [P, P, c_int, c_int, c_long, c_long, P],
     "bv_concat_cls": [P, P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_fwd": [P, P, c_int, c_int, c_int, P],

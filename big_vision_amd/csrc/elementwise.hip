@@ -501,6 +501,24 @@ extern "C" int bv_batchsum(const float* x, float* out, int n, int L, int D, void
   return bv_check_launch("bv_batchsum");
 }
 
+// bf16 -> fp32 (the boundary of a bf16 residual stream: embedding / posemb gradients are summed in fp32)
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16* __restrict__ x, float* __restrict__ y, long count) {
+  const long n8 = count / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const uint4 u = *reinterpret_cast<const uint4*>(x + i * 8);
+    *reinterpret_cast<float4*>(y + i * 8) = make_float4(bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y));
+    *reinterpret_cast<float4*>(y + i * 8 + 4) = make_float4(bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < count - n8 * 8) y[n8 * 8 + threadIdx.x] = bf2f(x[n8 * 8 + threadIdx.x]);
+}
+extern "C" int bv_cast_f32(const void* x_bf16, float* y, long count, void* stream) {
+  BV_REQUIRE(count > 0, "bv_cast_f32: empty");
+  BV_REQUIRE((uintptr_t)x_bf16 % 16 == 0 && (uintptr_t)y % 16 == 0, "bv_cast_f32: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(count / 8 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x_bf16, y, count);
+  return bv_check_launch("bv_cast_f32");
+}
+
 extern "C" int bv_cast_bf16(const float* x, void* y, long count, void* stream) {
   BV_REQUIRE(count > 0, "bv_cast_bf16: empty");
   BV_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "bv_cast_bf16: pointers must be 16-byte aligned");

@@ -502,12 +502,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     const bool nts = (p.nt & 1) || PROBE == 6, ntl = p.nt & 2;
     // row fragments per batch of auxiliary loads (GELU': 2, the variant is at the VGPR limit)
     constexpr bool GBWD = EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT;
+    constexpr bool RESBF = EPI == BV_EPI_RESIDUAL && !OUTF32;   // bf16 residual stream: aux bf16, C bf16
     constexpr int IB = GBWD ? 2 : 4;
 #pragma unroll
     for (int ib = 0; ib < 8; ib += IB) {
       float4 ax[IB][4];
       uint4 hx[IB][2];
-      if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
+      if constexpr ((EPI == BV_EPI_RESIDUAL && OUTF32) || EPI == BV_EPI_POS) {
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
           const int m = mrow0 + (ib + ii) * 16;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) ax[ii][j] = __builtin_bit_cast(float4, ld16(x + nc[j], ntl));
         }
-      } else if constexpr (GBWD) {
+      } else if constexpr (GBWD || RESBF) {
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
           const int m = mrow0 + (ib + ii) * 16;
@@ -534,11 +535,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha + bv[j * 4 + r];
-        if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
+        if constexpr ((EPI == BV_EPI_RESIDUAL && OUTF32) || EPI == BV_EPI_POS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             v[j * 4 + 0] += ax[ii][j].x; v[j * 4 + 1] += ax[ii][j].y;
             v[j * 4 + 2] += ax[ii][j].z; v[j * 4 + 3] += ax[ii][j].w;
+          }
+        } else if constexpr (RESBF) {
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[hh * 8 + e * 2 + 0] += bflo(w[e]);
+              v[hh * 8 + e * 2 + 1] += bfhi(w[e]);
+            }
           }
         } else if constexpr (EPI == BV_EPI_GELU_BWD) {
 #pragma unroll
@@ -1349,6 +1360,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
     return 1;
   }
   if (!km) hipLaunchKernelGGL((gemm256_kernel<false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_RESIDUAL && !out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_RESIDUAL, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_POS) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_POS, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU, false>), grid, block, 0, s, p);

@@ -221,7 +221,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      if (epi == BV_EPI_RESIDUAL) {
+      if (epi == BV_EPI_RESIDUAL && !p.out_f32) {   // bf16 residual stream: aux has C's dtype
+        const uint2 x = *reinterpret_cast<const uint2*>(
+            reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + n);
+        v[0] += bflo(x.x); v[1] += bfhi(x.x); v[2] += bflo(x.y); v[3] += bfhi(x.y);
+      } else if (epi == BV_EPI_RESIDUAL) {
         const float4 x = *reinterpret_cast<const float4*>(
             reinterpret_cast<const float*>(p.aux) + (long)m * p.ldaux + n);
         v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
@@ -317,7 +321,7 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
   if (epilogue == BV_EPI_POS) BV_REQUIRE(aux_rows > 0, "bv_gemm_bf16: POS epilogue needs aux_rows > 0");
   if (epilogue == BV_EPI_GELU || epilogue == BV_EPI_GELU_BWD_EMIT)
     BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: epilogue %d needs bf16 C and C2", epilogue);
-  if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)
+  if (epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)   // RESIDUAL: aux and C share one dtype (fp32 or bf16)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
   if (epilogue == BV_EPI_GELU_BWD)
     BV_REQUIRE(!out_f32, "bv_gemm_bf16: epilogue GELU_BWD writes bf16 (out_f32 must be 0)");

@@ -127,6 +127,30 @@ def map_entries(prefix, D, H, M):
 
 
 # ------------------------------------------------------------- helpers -------
+# Residual-stream dtype of the encoder stacks (trainer option config.residual_stream).  fp32 is the
+# reference's arithmetic (models/vit.py keeps activations in fp32; only matmul inputs are cast).  bf16
+# halves the LayerNorm traffic and the +residual GEMM epilogues; measured against the parity bounds
+# by tools/bf16_residual_budget.py (oracle) and the -m gpu step tests.  Everything outside
+# Encoder.fwd / Encoder.bwd sees fp32 tensors in both modes.
+_STREAM = F32
+
+
+def set_residual_stream(dtype):
+  """dtype: torch.float32 / torch.bfloat16 or their names; returns the previous setting."""
+  global _STREAM
+  old = _STREAM
+  if isinstance(dtype, str):
+    dtype = {"float32": F32, "fp32": F32, "f32": F32, "bfloat16": BF16, "bf16": BF16}[dtype]
+  if dtype not in (F32, BF16):
+    raise ValueError(f"residual_stream must be float32 or bfloat16, got {dtype}")
+  _STREAM = dtype
+  return old
+
+
+def residual_stream():
+  return _STREAM
+
+
 class _W:
   """A weight tensor resolved against a store: bf16 shadow (2-D), fp32 master,
   and the fp32 grad view (None if frozen)."""
@@ -210,7 +234,7 @@ class MLP:
     """resid + fc2(gelu(fc1(y))) ; returns (out f32, h_pre bf16, g bf16 or None)."""
     g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
     h = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
-    out = linear_fwd(g, self.w2, self.b2, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=resid)
+    out = linear_fwd(g, self.w2, self.b2, out_dtype=resid.dtype, epilogue=ops.EPI_RESIDUAL, aux=resid)
     return out, h, (g if keep_g else None)
 
   def bwd(self, dout_f32, dout_bf, y_bf, h, g, bias2_done=False):
@@ -256,7 +280,7 @@ class Block:
     y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
     o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
-    x1 = linear_fwd(o, self.wo, self.bo, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=x)
+    x1 = linear_fwd(o, self.wo, self.bo, out_dtype=x.dtype, epilogue=ops.EPI_RESIDUAL, aux=x)   # fp32 or bf16 stream
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
     x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light)
     if light:
@@ -271,6 +295,8 @@ class Block:
     T, D, H = n * L, self.D, self.H
     if y1 is None:   # light context: same kernel, same input -> the forward's y1 bit for bit
       y1 = self.ln1.fwd(x1, T, D)[0]
+    if x.dtype == BF16:   # bf16 residual stream: the gradient stream IS the GEMM operand
+      dx2 = dx2_bf
     dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g, bias2_done=b2_done)
     del y1
     dx1_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
@@ -298,7 +324,11 @@ class Encoder:
     self.D = D
 
   def fwd(self, x, n, L, save, out=None, kv_len=None):
+    """x: fp32 [n*L, D].  Returns the last block's output in the stream dtype (the callers hand it to
+    encoder_norm, whose kernel takes either) and the saved contexts."""
     saved = []
+    if _STREAM == BF16 and x.dtype == F32:
+      x = ops.cast_bf16(x)
     for i, blk in enumerate(self.blocks):
       x_in = x
       x, s = blk.fwd(x, n, L, light=(save == "light"), kv_len=kv_len)
@@ -322,12 +352,15 @@ class Encoder:
     are final at that point (block i's Dense_1 bias was accumulated earlier, by the kernel
     that produced its incoming dx; block i's backward also finishes block i-1's Dense_1 bias)."""
     last = len(self.blocks) - 1
+    bf_stream = bool(saved) and saved[0][0].dtype == BF16   # the contexts remember the stream they were built on
     for i in range(last, -1, -1):
       nb2 = self.blocks[i - 1].mlp.b2.grad if i > 0 else None
       dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L, b2_done=(b2_done if i == last else True),
                                      next_b2=nb2, kv_len=kv_len)
       if on_block is not None:
         on_block(i)
+    if bf_stream:   # callers (stem / embedding / posemb gradients) take the fp32 tensor and its bf16 copy
+      dx = ops.cast_f32(dx_bf)
     return dx, dx_bf
 
 

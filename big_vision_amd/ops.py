@@ -99,14 +99,16 @@ def sgemm(a, sam, sak, b, sbk, sbn, out, M, N, K, alpha=1.0, beta=0.0, log_alpha
 # --------------------------------------------------------------- LayerNorm --
 def layernorm_fwd(x, scale, bias, *, rows, D, row_stride=1, row_offset=0, want_bf16=True,
                   want_f32=False, eps=1e-6):
-  _chk(x, F32, "layernorm.x"); _chk(scale, F32, "layernorm.scale"); _chk(bias, F32, "layernorm.bias")
+  """x fp32, or bf16 on a bf16 residual stream (bv_layernorm_fwd_bf16x)."""
+  _chk(x, x.dtype if x.dtype in (F32, BF16) else F32, "layernorm.x")
+  _chk(scale, F32, "layernorm.scale"); _chk(bias, F32, "layernorm.bias")
   dev = x.device
   y_bf = torch.empty((rows, D), device=dev, dtype=BF16) if want_bf16 else None
   y_f = torch.empty((rows, D), device=dev, dtype=F32) if want_f32 else None
   mean = torch.empty((rows,), device=dev, dtype=F32)
   rstd = torch.empty((rows,), device=dev, dtype=F32)
-  _lib.call("bv_layernorm_fwd", _p(x), _p(scale), _p(bias), _p(y_bf), _p(y_f), _p(mean), _p(rstd),
-            rows, D, row_stride, row_offset, float(eps), _stream())
+  _lib.call("bv_layernorm_fwd_bf16x" if x.dtype == BF16 else "bv_layernorm_fwd", _p(x), _p(scale), _p(bias),
+            _p(y_bf), _p(y_f), _p(mean), _p(rstd), rows, D, row_stride, row_offset, float(eps), _stream())
   return y_bf, y_f, mean, rstd
 
 
@@ -115,6 +117,18 @@ def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_b
   """dx = dres + LN_bwd(dy); dscale/dbias (and dx_colsum += column sums of dx) accumulated in place."""
   if dy.dtype not in (BF16, F32):
     raise TypeError("layernorm_bwd.dy must be bf16 or fp32")
+  if x.dtype == BF16:
+    # bf16 residual stream: dres and dx are bf16 and dx IS the bf16 copy the next GEMM reads; `dx`
+    # (the fp32 stream of the other mode) is not written.  Strided calls start from zeros.
+    _chk(x, BF16, "layernorm_bwd.x")
+    if dres is not None:
+      _chk(dres, BF16, "layernorm_bwd.dres")
+    if dx_bf16 is None:
+      dx_bf16 = torch.empty_like(x) if row_stride == 1 else torch.zeros_like(x)
+    _lib.call("bv_layernorm_bwd_bf16x", _p(dy), int(dy.dtype == F32), _p(x), _p(scale), _p(mean), _p(rstd),
+              _p(dres), _p(dx_bf16), _p(dscale), _p(dbias), _p(dx_colsum), rows, D, row_stride, row_offset,
+              _stream())
+    return dx_bf16
   _chk(x, F32, "layernorm_bwd.x")
   if dx is None:
     dx = torch.empty_like(x) if row_stride == 1 else torch.zeros_like(x)
@@ -259,6 +273,15 @@ def cast_bf16(x, out=None):
   if out is None:
     out = torch.empty(x.shape, device=x.device, dtype=BF16)
   _lib.call("bv_cast_bf16", _p(x), _p(out), x.numel(), _stream())
+  return out
+
+
+def cast_f32(x, out=None):
+  _chk(x, BF16, "cast_f32.x")
+  assert x.is_contiguous()
+  if out is None:
+    out = torch.empty(x.shape, device=x.device, dtype=F32)
+  _lib.call("bv_cast_f32", _p(x), _p(out), x.numel(), _stream())
   return out
 
 

@@ -22,6 +22,7 @@ import importlib
 import torch
 
 from big_vision_amd import dp
+from big_vision_amd import engine as E
 from big_vision_amd import ops
 from big_vision_amd import optax as bv_optax
 from big_vision_amd import utils as u
@@ -214,6 +215,17 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     measurements.update(opt.step())
     return {"params": params, "opt": opt}, measurements
 
+  # config.residual_stream ("float32" = the reference's arithmetic, "bfloat16"): set for the duration of
+  # each step and restored afterwards, so model.apply / other trainers in the process keep their own
+  stream = config.get("residual_stream", "float32")
+  inner = update_fn
+
+  def update_fn(train_state, rng, batch):
+    old = E.set_residual_stream(stream)
+    try:
+      return inner(train_state, rng, batch)
+    finally:
+      E.set_residual_stream(old)
   update_fn.state_cache = state_cache   # diagnostics: how many micro-batches keep their activations
   return update_fn
 

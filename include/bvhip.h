@@ -55,7 +55,8 @@ int bv_version(void);
  * epilogue (applied after alpha, then + bias[N] if bias != NULL):
  */
 #define BV_EPI_NONE 0
-#define BV_EPI_RESIDUAL 1 /* C(f32) += aux(f32)[m,n]           (x + f(x), vit.py:101,110)   */
+#define BV_EPI_RESIDUAL 1 /* C += aux[m,n], aux has C's dtype: fp32 (out_f32 = 1) or bf16 (out_f32 = 0,
+                             bf16 residual stream)               (x + f(x), vit.py:101,110)   */
 #define BV_EPI_POS 2      /* C(f32) += aux(f32)[m % aux_rows,n] (posemb add, vit.py:220-221) */
 #define BV_EPI_GELU 3     /* C(bf16)=pre-activation h, C2(bf16)=gelu_tanh(h) (vit.py:75); the
                              activation is applied to the bf16-rounded h that is stored     */
@@ -143,6 +144,16 @@ int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float*
                      const float* mean, const float* rstd, const float* dres, float* dx,
                      void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows, int D,
                      long row_stride, long row_offset, void* stream);
+/* The same on a bf16 RESIDUAL STREAM (trainer option config.residual_stream = "bfloat16": the activations
+ * between the blocks, their gradients and the saved block inputs are bf16; statistics, scale / bias
+ * gradients, dx_colsum and all arithmetic stay fp32).  x, dres and dx are bf16 here; there is no separate
+ * fp32 dx (the bf16 dx IS the gradient stream and the GEMM operand).  D % 8 == 0, D <= 2048. */
+int bv_layernorm_fwd_bf16x(const void* x_bf16, const float* scale, const float* bias, void* y_bf16, float* y_f32,
+                           float* mean, float* rstd, int rows, int D, long row_stride, long row_offset, float eps,
+                           void* stream);
+int bv_layernorm_bwd_bf16x(const void* dy, int dy_is_f32, const void* x_bf16, const float* scale, const float* mean,
+                           const float* rstd, const void* dres_bf16, void* dx_bf16, float* dscale, float* dbias,
+                           float* dx_colsum, int rows, int D, long row_stride, long row_offset, void* stream);
 
 /* ------------------------------------------------------------ Attention ----
  * Self-attention core of nn.MultiHeadDotProductAttention (models/vit.py:93-98):
@@ -240,6 +251,8 @@ int bv_colsum(const void* x, int x_is_f32, long ldx, float* out, int rows, int c
 int bv_batchsum(const float* x, float* out, int n, int L, int D, void* stream);
 /* fp32 -> bf16 cast of a flat buffer (bf16 weight shadows). */
 int bv_cast_bf16(const float* x, void* y, long count, void* stream);
+/* bf16 -> fp32 (the boundary of a bf16 residual stream). */
+int bv_cast_f32(const void* x_bf16, float* y, long count, void* stream);
 /* dst[cols][rows] = src[rows][cols]^T, bf16 (row strides in elements): the
  * [out][in] image of a Flax (in,out) kernel, consumed by the forward
  * projections (models/vit.py:72,77,93-98) on the k-major GEMM path. */

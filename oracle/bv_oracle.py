@@ -90,6 +90,36 @@ def _rb(t):
   return t.to(torch.bfloat16).to(t.dtype)
 
 
+# `with bf16_residual():` additionally rounds the RESIDUAL STREAM to bfloat16 after every residual add
+# (forward value and backward cotangent): the arithmetic a bf16 residual stream would have.  Only used by
+# tools/bf16_residual_budget.py to measure what that design option costs against the parity bounds.
+_BF16_RESIDUAL = False
+
+
+class bf16_residual:
+  def __enter__(self):
+    global _BF16_RESIDUAL
+    self.prev, _BF16_RESIDUAL = _BF16_RESIDUAL, True
+
+  def __exit__(self, *exc):
+    global _BF16_RESIDUAL
+    _BF16_RESIDUAL = self.prev
+
+
+class _RoundStream(torch.autograd.Function):
+  @staticmethod
+  def forward(ctx, x):
+    return _rb(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    return _rb(g)
+
+
+def _stream(x):
+  return _RoundStream.apply(x) if _BF16_RESIDUAL else x
+
+
 class _Bf16Contract(torch.autograd.Function):
   """einsum(eq, a, b) with operands (forward) and cotangent (backward) rounded to bf16.  Every
   index of an operand appears in the output or in the other operand (true for all contractions of
@@ -164,16 +194,17 @@ def encoder_block(x, p, num_heads, mask=None):
   y = layernorm(x, p["LayerNorm_0"])
   y = out["sa"] = mha(y, y, p["MultiHeadDotProductAttention_0"], num_heads,
                       mask=None if mask is None else mask[:, None])
-  x = out["+sa"] = x + y
+  x = out["+sa"] = _stream(x + y)
   y = layernorm(x, p["LayerNorm_1"])
   y = out["mlp"] = mlp_block(y, p["MlpBlock_0"])
-  x = out["+mlp"] = x + y
+  x = out["+mlp"] = _stream(x + y)
   return x, out
 
 
 def encoder(x, p, depth, num_heads, mask=None):
   """models/vit.py:115-160 (Encoder); accepts loop and scan param layouts."""
   out = {}
+  x = _stream(x)
   if "encoderblock" in p:  # scan layout: leading depth axis (vit.py:129-148)
     for lyr in range(depth):
       pl = tree_map(lambda t, l=lyr: t[l], p["encoderblock"])

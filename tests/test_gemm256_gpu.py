@@ -74,6 +74,11 @@ def test_nt_epilogues(dev, fast):
   kw = dict(a_kmajor=True, b_kmajor=True)
   y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
   close(y, pre + res, 1e-4, 2e-3, "residual")
+  # bf16 residual stream: aux and C are bf16 (same epilogue id, out_f32 = 0)
+  resb = res.to(BF16)
+  yb = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_RESIDUAL, aux=resb, **kw)
+  close(yb, pre + resb.float(), 1e-2, 1e-2, "residual (bf16 stream)")
+  assert torch.equal(yb, ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_RESIDUAL, aux=resb, **kw))
   pos = rnd((L, N), dev, 12)
   y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L, **kw)
   close(y, pre + pos.repeat(M // L, 1), 1e-4, 2e-3, "pos")

@@ -79,6 +79,9 @@ def test_gemm_epilogues(dev):
   res = rnd((M, N), dev, 11)
   y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res)
   assert_close(y, pre + res, 1e-4, 1e-3, "residual")
+  resb = res.to(BF16)   # bf16 residual stream: aux and C bf16
+  yb = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_RESIDUAL, aux=resb)
+  assert_close(yb, pre + resb.float(), 1e-2, 1e-2, "residual (bf16 stream)")
   pos = rnd((L, N), dev, 12)
   y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L)
   assert_close(y, pre + pos.repeat(M // L, 1), 1e-4, 1e-3, "pos")
@@ -163,6 +166,56 @@ def test_layernorm(dev, rows, D):
   xr.grad = None
   torch.nn.functional.layer_norm(xr, (D,), sr, br, eps=1e-6).backward(dyb.double())
   assert_close(dx2, xr.grad, 1e-4, 1e-4, "ln dx (bf16 dy)")
+
+
+@pytest.mark.parametrize("rows,D", [(1568, 768), (37, 128), (64, 1024), (9, 384), (5, 1152), (3, 2048)])
+def test_layernorm_bf16_stream(dev, rows, D):
+  """bv_layernorm_fwd_bf16x / bv_layernorm_bwd_bf16x: x, dres, dx in bf16 (config.residual_stream =
+  "bfloat16"), arithmetic and statistics fp32 - against fp64 LayerNorm of the same bf16 inputs."""
+  from big_vision_amd import ops
+  x = (rnd((rows, D), dev, 1, 2.0) + 0.5).to(BF16)
+  scale = 1 + 0.1 * rnd((D,), dev, 2); bias = 0.1 * rnd((D,), dev, 3)
+  xr = x.double().requires_grad_(True); sr = scale.double().requires_grad_(True)
+  br = bias.double().requires_grad_(True)
+  ref = torch.nn.functional.layer_norm(xr, (D,), sr, br, eps=1e-6)
+  y_bf, y_f, mean, rstd = ops.layernorm_fwd(x, scale, bias, rows=rows, D=D, want_f32=True)
+  assert_close(y_f, ref, 1e-5, 1e-5, "ln fwd f32 (bf16 x)")
+  assert_close(y_bf, ref, 1e-2, 1e-2, "ln fwd bf16 (bf16 x)")
+  assert_close(mean, xr.mean(-1), 1e-5, 1e-5, "mean")
+  for dy in (rnd((rows, D), dev, 4), rnd((rows, D), dev, 4).to(BF16)):
+    dres = rnd((rows, D), dev, 5).to(BF16)
+    xr.grad = sr.grad = br.grad = None
+    torch.nn.functional.layer_norm(xr, (D,), sr, br, eps=1e-6).backward(dy.double())
+    dscale = torch.zeros(D, device=dev); dbias = torch.zeros(D, device=dev)
+    dxsum = torch.ones(D, device=dev)
+    dx = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=rows, D=D, dres=dres, dscale=dscale, dbias=dbias,
+                           dx_colsum=dxsum)
+    assert dx.dtype == BF16
+    want = xr.grad + dres.double()
+    assert_close(dx, want, 1e-2, 1e-2, "ln dx (bf16 stream)")
+    assert_close(dxsum, 1.0 + want.sum(0), 1e-4, 1e-3, "ln dx colsum is summed in fp32, before the rounding")
+    assert_close(dscale, sr.grad, 1e-4, 1e-3, "ln dscale")
+    assert_close(dbias, br.grad, 1e-4, 1e-3, "ln dbias")
+  # no residual gradient, strided rows (encoder_norm on the pooled token)
+  n, L = 3, rows // 3 if rows >= 3 else 1
+  if L >= 1 and n * L <= rows:
+    _, y, mean, rstd = ops.layernorm_fwd(x, scale, bias, rows=n, D=D, row_stride=L, row_offset=L - 1,
+                                         want_bf16=False, want_f32=True)
+    sel = x[:n * L].view(n, L, D)[:, -1].double()
+    assert_close(y, torch.nn.functional.layer_norm(sel, (D,), scale.double(), bias.double(), eps=1e-6), 1e-5, 1e-5,
+                 "strided ln (bf16 x)")
+    dy = rnd((n, D), dev, 6)
+    dxs = ops.layernorm_bwd(dy, x[:n * L].contiguous(), scale, mean, rstd, rows=n, D=D, row_stride=L, row_offset=L - 1)
+    xq = x[:n * L].double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xq.view(n, L, D)[:, -1], (D,), scale.double(), bias.double(), eps=1e-6).backward(dy.double())
+    assert_close(dxs, xq.grad, 1e-2, 1e-2, "strided ln bwd (bf16 stream): other rows stay 0")
+
+
+def test_cast_f32(dev):
+  from big_vision_amd import ops
+  for count in (8, 4096, 1000003 // 8 * 8, 24):
+    x = rnd((count,), dev, 9).to(BF16)
+    assert torch.equal(ops.cast_f32(x), x.float())
 
 
 def test_layernorm_strided_rows(dev):

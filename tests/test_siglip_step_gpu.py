@@ -25,6 +25,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]
+
+
 def _cfg(total_steps=10, **kw):
   from big_vision_amd.compat.ml_collections import ConfigDict
   c = ConfigDict()
@@ -80,14 +83,19 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
   p_before = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(train_state["params"])[0]}
 
   def forward_parity():
-    zimg, ztxt, out = model.apply({"params": train_state["params"]}, image_d, text_d, collect=False)
-    assert (zimg.cpu().double() - zi_ref).abs().max() <= tol_z
-    assert (ztxt.cpu().double() - zt_ref).abs().max() <= tol_z
-    t = math.exp(store.leaf("t").item()); b = store.leaf("b").item()
-    logits = (zimg.double() @ ztxt.double().T * t + b).cpu()
-    assert (logits - logits_ref).abs().max() <= tol_logit
-    loss_fwd = siglip.loss_fn(model, train_state["params"], image_d, text_d)
-    assert abs(loss_fwd.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
+    from big_vision_amd import engine as E
+    old_stream = E.set_residual_stream(config.get("residual_stream", "float32"))   # the stream the step will use
+    try:
+      zimg, ztxt, out = model.apply({"params": train_state["params"]}, image_d, text_d, collect=False)
+      assert (zimg.cpu().double() - zi_ref).abs().max() <= tol_z
+      assert (ztxt.cpu().double() - zt_ref).abs().max() <= tol_z
+      t = math.exp(store.leaf("t").item()); b = store.leaf("b").item()
+      logits = (zimg.double() @ ztxt.double().T * t + b).cpu()
+      assert (logits - logits_ref).abs().max() <= tol_logit
+      loss_fwd = siglip.loss_fn(model, train_state["params"], image_d, text_d)
+      assert abs(loss_fwd.item() - loss_ref.item()) <= 1e-2 * abs(loss_ref.item())
+    finally:
+      E.set_residual_stream(old_stream)
 
   if not dirty_step:
     forward_parity()
@@ -147,6 +155,32 @@ def test_tiny_tok_pooling(dev):
   _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71, floor=True, rel_max=4e-2)
 
 
+@pytest.mark.parametrize("which", ["tiny", "tiny_tok_lit", "b16"])
+def test_bf16_residual_stream_step(dev, which):
+  """config.residual_stream = "bfloat16": the activations between the blocks and their gradients are
+  bf16 (LayerNorm inputs, +residual GEMM epilogues, saved block inputs); everything else as before.
+  Same bounds as the fp32-stream cases; the measured bf16-operand floor of each case is reported next
+  to it (tools/bf16_residual_budget.py predicts +10-25 % on the worst tensors)."""
+  if which == "tiny":
+    image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+    text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2)
+    _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100, floor=True,
+              config=_cfg(residual_stream="bfloat16"), case="bf16 stream: siglip tiny n=8")
+  elif which == "tiny_tok_lit":
+    image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok",
+                     head_zeroinit=False)
+    text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2)
+    _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100, bias_init=-2.71,
+              config=_cfg(schedule=LIT_SCHEDULE, residual_stream="bfloat16"), frozen=("img/",), floor=True,
+              case="bf16 stream: LiT tiny frozen img")
+  else:
+    image_cfg = dict(variant="B/16", pool_type="map")
+    text_cfg = dict(variant="B")
+    _run_case(dev, image_cfg, text_cfg, E=768, n=8, res=224, seq=64, vocab=32_000, floor=True,
+              config=_cfg(residual_stream="bfloat16", microbatch=4, microbatch_keep="all", microbatch_light=True),
+              case="bf16 stream: siglip B/16 n=8 microbatch=4 light")
+
+
 def test_mu_variant_step(dev):
   """`mu/16` (models/vit.py:297-300: width 32, depth 1, mlp 128, 2 heads -> head dim 16), the variant the
   reference's own tests and the SURVEY's golden-vector plan use: the general attention kernels
@@ -167,7 +201,6 @@ def test_so400m_shapes_step(dev):
             case="siglip So400m/14 depth2 n=4")
 
 
-LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]
 
 
 def test_lit_frozen_image_tower_step_tiny(dev):
