@@ -96,9 +96,14 @@ def pmc_traffic(world, micro):
     return None, None
 
 
-# Activations between the encoder blocks: "float32" is the reference's arithmetic (models/vit.py keeps
-# them in fp32), "bfloat16" the measured option of DESIGN.md section 3 (parity inside SURVEY 8c's bounds).
-RESIDUAL_STREAM = "float32"
+# Activations between the encoder blocks (config.residual_stream).  The trainers default to "float32", the
+# reference's arithmetic (models/vit.py keeps activations in fp32, only matmul inputs are cast).  The
+# benchmark opts into "bfloat16": LayerNorm inputs, the +residual GEMM epilogues, the saved block inputs and
+# the gradient stream are bf16, statistics / softmax / loss / optimizer stay fp32.  Its parity cost is
+# measured, not assumed: worst per-tensor gradient rel-L2 vs the fp64 oracle 0.014 -> 0.017 on this model
+# (tools/bf16_residual_budget.py), the -m gpu step tests run B/16 in this mode inside SURVEY 8c's bounds
+# (cosine >= 0.999, rel-L2 <= 3e-2); `--residual-stream float32` reproduces the other arithmetic.
+RESIDUAL_STREAM = "bfloat16"
 
 
 def make_config(total_steps):

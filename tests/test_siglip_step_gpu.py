@@ -155,7 +155,7 @@ def test_tiny_tok_pooling(dev):
   _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71, floor=True, rel_max=4e-2)
 
 
-@pytest.mark.parametrize("which", ["tiny", "tiny_tok_lit", "b16"])
+@pytest.mark.parametrize("which", ["tiny", "tiny_tok_lit", "b16", "b16_n32", "lit_b16"])
 def test_bf16_residual_stream_step(dev, which):
   """config.residual_stream = "bfloat16": the activations between the blocks and their gradients are
   bf16 (LayerNorm inputs, +residual GEMM epilogues, saved block inputs); everything else as before.
@@ -173,12 +173,24 @@ def test_bf16_residual_stream_step(dev, which):
     _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=64, seq=16, vocab=100, bias_init=-2.71,
               config=_cfg(schedule=LIT_SCHEDULE, residual_stream="bfloat16"), frozen=("img/",), floor=True,
               case="bf16 stream: LiT tiny frozen img")
-  else:
+  elif which == "b16":
     image_cfg = dict(variant="B/16", pool_type="map")
     text_cfg = dict(variant="B")
     _run_case(dev, image_cfg, text_cfg, E=768, n=8, res=224, seq=64, vocab=32_000, floor=True,
               config=_cfg(residual_stream="bfloat16", microbatch=4, microbatch_keep="all", microbatch_light=True),
               case="bf16 stream: siglip B/16 n=8 microbatch=4 light")
+  elif which == "b16_n32":   # what bench.py runs: B/16 + text-B, two-pass micro-batches with light contexts
+    image_cfg = dict(variant="B/16", pool_type="map")
+    text_cfg = dict(variant="B")
+    _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000, floor=True,
+              config=_cfg(residual_stream="bfloat16", microbatch=8, microbatch_keep="all", microbatch_light=True),
+              case="bf16 stream: siglip B/16 n=32 microbatch=8 light")
+  else:                      # BASELINE configs[4] shapes
+    image_cfg = dict(variant="B/16", pool_type="tok", head_zeroinit=False)
+    text_cfg = dict(variant="B")
+    _run_case(dev, image_cfg, text_cfg, E=768, n=8, res=224, seq=16, vocab=32_000, bias_init=-2.71,
+              config=_cfg(schedule=LIT_SCHEDULE, residual_stream="bfloat16"), frozen=("img/",), floor=True,
+              case="bf16 stream: LiT B/16 frozen img n=8")
 
 
 def test_mu_variant_step(dev):
