@@ -10,6 +10,7 @@ if [ "$1" != "notests" ]; then
   timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/pytest.txt; cat $O/pytest.txt
 fi
 timeout 400 python bench.py > $O/bench_line.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench_line.json
+timeout 300 python bench.py --residual-stream float32 --no-cpu-baseline > $O/bench_line_f32stream.json 2> $O/bench_f32.err; cat $O/bench_line_f32stream.json
 timeout 300 python bench.py --global-batch 512 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_n512.json 2> $O/bench_n512.err; cat $O/bench_n512.json
 for gb in 2048 1024; do timeout 300 python bench.py --global-batch $gb --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $O/bench_n$gb.json 2> $O/bench_n$gb.err; cat $O/bench_n$gb.json; done
 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 BV_DP_FORCE_COLLECTIVES=1 timeout 300 python bench.py --global-batch 512 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_n512_rccl.json 2> $O/bench_n512_rccl.err; tail -2 $O/bench_n512_rccl.err; cat $O/bench_n512_rccl.json
