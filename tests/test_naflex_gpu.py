@@ -102,7 +102,8 @@ def test_naflex_mask_must_be_a_prefix(dev):
     model.executor(store, "", patches.shape[-1]).fwd(tuple(t.to(dev) for t in (patches, ptype, yabs, xabs)))
 
 
-def test_siglip_step_with_naflex_image_tower(dev):
+@pytest.mark.parametrize("stream", ["float32", "bfloat16"])
+def test_siglip_step_with_naflex_image_tower(dev, stream):
   """two_towers(image_model='proj.image_text.naflex_vit') through the SigLIP trainer: loss vs the oracle,
   finite measurements, text tower and NaFlex tower both updated."""
   import bv_oracle as O
@@ -115,7 +116,8 @@ def test_siglip_step_with_naflex_image_tower(dev):
   model = two_towers.Model(image=icfg, text=tcfg, image_model="proj.image_text.naflex_vit", out_dim=(None, 128),
                            temperature_init=10.0, bias_init=-10.0)
   c = ConfigDict(dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
-                      schedule=dict(decay_type="cosine", warmup_steps=2)))
+                      schedule=dict(decay_type="cosine", warmup_steps=2),
+                      residual_stream=stream))   # the key-padding-masked encoder on either residual stream
   image = _batch(5)
   n = image[0].shape[0]
   _, text = O.synthetic_batch(2, n, 32, 8, 64)

@@ -26,10 +26,10 @@ def _cfg(**kw):
   return c
 
 
-def _run(dev, model_cfg, num_classes, n, res, loss, mixup_a):
+def _run(dev, model_cfg, num_classes, n, res, loss, mixup_a, **extra):
   import bv_oracle as O
   from big_vision_amd import train, utils as u
-  config = _cfg(model=model_cfg, num_classes=num_classes, loss=loss)
+  config = _cfg(model=model_cfg, num_classes=num_classes, loss=loss, **extra)
   if mixup_a is not None:
     config.mixup = dict(p=0.2, fold_in=None)
   _, model = train.get_model(config)
@@ -85,6 +85,12 @@ def test_tiny_sigmoid_xent_step(dev):
   """The trainer's default loss (sigmoid_xent, train.py:299), learned posemb, no mixup."""
   _run(dev, dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap"), 24, 6, 64,
        "sigmoid_xent", None)
+
+
+def test_tiny_step_on_the_bf16_residual_stream(dev):
+  """config.residual_stream = "bfloat16" through big_vision.train's update_fn (gap pooling, mixup)."""
+  _run(dev, dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap"), 24, 6, 64,
+       "softmax_xent", 0.7, residual_stream="bfloat16")
 
 
 def test_unknown_loss_raises(dev):
