@@ -30,6 +30,7 @@ PROTOTYPES = {
     "bv_gemm_tune": [c_int, c_int, c_int],
     "bv_gemm_pre_issue": [c_int],
     "bv_gemm_roll": [c_int],
+    "bv_gemm_reserve_cus": [c_int],
     "bv_set_workspace": [P, c_long],
     "bv_set_stream_workspace": [P, P, c_long],
     "bv_gemm_workspace_bytes": [c_int, c_int, c_int],

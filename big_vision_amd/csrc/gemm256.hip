@@ -1215,6 +1215,17 @@ extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
 static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1;
 // Which epilogues run on the rolling-epilogue kernel (bit mask): 1 = +residual (default: the only one
 // it measured faster on, 2-5 %), 2 = none/bias (bf16), 4 = GELU.
+// CUs left free by the persistent grid (0 = all 256).  A workgroup of this kernel fills a CU (160 KiB of
+// LDS, 8 waves x ~230 VGPRs), so a collective's workgroups cannot share one: while RCCL kernels are
+// resident, 256 persistent workgroups do not all fit and the ones that wait start a whole launch late.
+// The data-parallel trainer reserves as many CUs as RCCL has channels for the backward, where the
+// per-block gradient all-reduces run beside the GEMMs (dp.py).
+static int g_reserve = 0;
+extern "C" int bv_gemm_reserve_cus(int n) {
+  const int old = g_reserve;
+  if (n >= 0) g_reserve = n > 128 ? 128 : n;
+  return old;
+}
 extern "C" int bv_gemm_roll(int mask) {
   const int old = g_roll;
   if (mask >= 0) g_roll = mask;
@@ -1317,7 +1328,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
     if (split_k > 0) {
       splits = split_k;
     } else {
-      splits = 256 / p.ntiles;
+      splits = (256 - g_reserve) / p.ntiles;   // work items <= CUs in use (4 reserved CUs keep B/16's choices: 252 = 36 x 7 = 9 x 28)
       const int max_splits = nk / 8 > 0 ? nk / 8 : 1;
       if (splits > max_splits) splits = max_splits;
     }
@@ -1344,7 +1355,8 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   p.nt = g_nt;
   p.pre_issue = g_pre;
   p.dbg = nullptr;
-  dim3 grid(nwork < 256 ? nwork : 256), block(512);   // persistent: one workgroup per CU
+  const int cus = 256 - g_reserve;
+  dim3 grid(nwork < cus ? nwork : cus), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
   // rolling-epilogue kernel: k-major, at least two K-tiles per tile, the epilogues it implements
   const bool roll = km && nk >= 2 && !colsum &&

@@ -154,5 +154,34 @@ def init_from_env(backend: str | None = None) -> Comm:
       backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
       torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+      # The collectives of a step move < 1 GB per 90 ms: a few channels are plenty, and every RCCL
+      # channel is a workgroup that needs a CU of its own beside the persistent GEMMs (see RESERVED_CUS).
+      os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RESERVED_CUS))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
   return Comm()
+
+
+# CUs the persistent 256x256 GEMM leaves to RCCL while gradient all-reduces overlap the backward
+# (bv_gemm_reserve_cus): its workgroups fill a CU, so a collective launched beside it would otherwise
+# wait for - or delay - a whole GEMM launch.  4 keeps the split-K choices of the B/16 shapes intact
+# (252 = 36 x 7 = 9 x 28 work items) and costs the k-major GEMMs 1.6 % of the chip during the backward.
+RESERVED_CUS = 4
+
+
+class reserve_cus_for_collectives:
+  """`with reserve_cus_for_collectives(comm):` around the part of a step whose kernels overlap RCCL
+  traffic (the backward).  No-op on one rank and without a GPU library."""
+
+  def __init__(self, comm):
+    self.on = bool(comm is not None and comm.active and comm.size > 1 and torch.cuda.is_available())
+
+  def __enter__(self):
+    if self.on:
+      from big_vision_amd import _lib
+      self.old = _lib.load().bv_gemm_reserve_cus(RESERVED_CUS)
+    return self
+
+  def __exit__(self, *exc):
+    if self.on:
+      from big_vision_amd import _lib
+      _lib.load().bv_gemm_reserve_cus(self.old)

@@ -184,15 +184,17 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         if ctx is None:
           _, _, _, ctx = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro],
                                 save=("light" if state_cache["light"] else True))
-        ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
-               None if txt_frozen else dztxt[s:s + micro].contiguous(),
-               sync=(sync if s == starts[-1] else None))   # gradients are final in the LAST backward only
+        with dp.reserve_cus_for_collectives(comm if (sync is not None and s == starts[-1]) else None):
+          ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
+                 None if txt_frozen else dztxt[s:s + micro].contiguous(),
+                 sync=(sync if s == starts[-1] else None))   # gradients are final in the LAST backward only
         del ctx
     else:
       zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=True)
       norms = [(o_.get("img/norm"), o_.get("txt/norm"))]
       stats, dzimg, dztxt, *lx = loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
-      ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt, sync=sync)
+      with dp.reserve_cus_for_collectives(comm if sync is not None else None):
+        ex.bwd(ctx, None if img_frozen else dzimg, None if txt_frozen else dztxt, sync=sync)
 
     # dL/dt', dL/db (scalars computed by the loss kernel) into the flat grad buffer.
     gt = store.g("t")

@@ -115,6 +115,10 @@ int bv_gemm_pre_issue(int enable);
  * (alpha = 1), 2 = NONE (bf16 out), 4 = GELU; default 1 (the only one measured faster).
  * mask < 0 only queries; returns the old value. */
 int bv_gemm_roll(int mask);
+/* CUs the persistent 256x256 GEMM grid leaves free (0 = none; returns the old value, n < 0 only queries).
+ * Its workgroups fill a CU, so kernels that must run BESIDE it (RCCL collectives overlapping the
+ * backward) need CUs of their own; the data-parallel trainer reserves one per RCCL channel. */
+int bv_gemm_reserve_cus(int n);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,

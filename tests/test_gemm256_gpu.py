@@ -203,3 +203,29 @@ def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, 
       close(new[0][k], ref[k], 1e-6, 1e-4, name)
     else:
       assert torch.equal(new[0][k], ref[k]), f"{name}: rolling kernel differs from the full-epilogue kernel"
+
+
+def test_reserved_cus_change_nothing_but_the_grid(dev, fast):
+  """bv_gemm_reserve_cus(4): the persistent grid leaves 4 CUs to RCCL during an overlapped backward
+  (dp.reserve_cus_for_collectives).  k-major results are bit-identical (a tile's arithmetic does not
+  depend on which workgroup runs it); the split-K choice of the weight-gradient GEMM follows the CUs
+  in use, so dW matches to accumulation order."""
+  from big_vision_amd import ops, _lib
+  lib = _lib.load()
+  a = rnd((2048, 768), dev, 21, dtype=BF16)
+  w = rnd((2304, 768), dev, 22, 0.1, dtype=BF16)
+  dy = rnd((2048, 2304), dev, 23, dtype=BF16)
+  y0 = ops.gemm(a, w, a_kmajor=True, b_kmajor=True, out_dtype=BF16)
+  g0 = torch.zeros((768, 2304), device=dev)
+  ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=g0, epilogue=ops.EPI_ATOMIC)
+  old = lib.bv_gemm_reserve_cus(4)
+  try:
+    assert old == 0
+    y1 = ops.gemm(a, w, a_kmajor=True, b_kmajor=True, out_dtype=BF16)
+    g1 = torch.zeros((768, 2304), device=dev)
+    ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=g1, epilogue=ops.EPI_ATOMIC)
+  finally:
+    lib.bv_gemm_reserve_cus(old)
+  assert torch.equal(y0, y1)
+  close(g1, g0, 1e-5, 1e-3, "dW with 4 reserved CUs")
+  close(g0, a.float().T @ dy.float(), 1e-4, 2e-2, "dW")
