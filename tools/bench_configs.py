@@ -34,9 +34,14 @@ def timed(fn, steps, warmup):
   return (time.perf_counter() - t0) / steps
 
 
+STREAM = "float32"   # --residual-stream
+
+
 def c2(dev, steps):
+  from big_vision_amd import engine as E
   from big_vision_amd.models import vit
   from big_vision_amd.params import ParamStore
+  E.set_residual_stream(STREAM)
   n, res = 256, 224
   model = vit.Model(None, variant="B/16", pool_type="map")
   hw = model.grid((n, res, res, 3))
@@ -53,7 +58,7 @@ def c2(dev, steps):
   flops = 3 * 35.42e9 * n                      # fwd + bwd matmul FLOPs of the tower
   return {"metric": "images/sec, ViT-B/16 image tower forward+backward, batch 256 (BASELINE configs[1])",
           "value": n / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "tflops_algorithmic": flops / dt / 1e12,
-          "config": {"workload": "ViT-B/16@224 MAP tower, fwd+bwd, no optimizer", "batch": n}}
+          "config": {"workload": "ViT-B/16@224 MAP tower, fwd+bwd, no optimizer", "batch": n, "residual_stream": STREAM}}
 
 
 def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label=""):
@@ -63,6 +68,7 @@ def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=N
                            bias_init=-10.0 if schedule is None else -2.71)
   config = bench.make_config(20_000)
   config.microbatch = micro
+  config.residual_stream = STREAM
   if schedule is not None:
     config.schedule = schedule
   g = torch.Generator(device=dev).manual_seed(1)
@@ -77,7 +83,7 @@ def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=N
   dt = timed(step, steps, 2)
   siglip.check_finite(box["m"])
   return {"value": n / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
-          "config": {"workload": label, "per_gpu_batch": n, "microbatch": micro,
+          "config": {"workload": label, "per_gpu_batch": n, "microbatch": micro, "residual_stream": STREAM,
                      "final_loss": float(box["m"]["training_loss"].item())}}
 
 
@@ -104,7 +110,10 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("workloads", nargs="*", default=["c2", "c4", "c5"])
   ap.add_argument("--steps", type=int, default=5)
+  ap.add_argument("--residual-stream", default="float32", choices=("float32", "bfloat16"))
   a = ap.parse_args()
+  global STREAM
+  STREAM = a.residual_stream
   dev = torch.device("cuda", 0)
   torch.cuda.set_device(dev)
   for w in a.workloads:
