@@ -106,6 +106,11 @@ def pmc_traffic(world, micro):
 RESIDUAL_STREAM = "bfloat16"
 
 
+# siglip.make_update_fn's state_cache["light"] -> what a kept micro-batch context holds
+CTX_KIND = {False: "full", None: "full", "g": "gelu(h)-free (re-emitted by the fc2 dX GEMM)", True: "light",
+            "light": "light (no gelu(h), no LayerNorm outputs: both re-derived in the backward)"}
+
+
 def make_config(total_steps):
   from big_vision_amd.compat.ml_collections import ConfigDict
   c = ConfigDict()
@@ -301,10 +306,11 @@ def main():
                  "residual_stream": args.residual_stream,
                  "recompute": (f"{max(0, n // args.microbatch - update_fn.state_cache['keep_n'])} of "
                                f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
-                               f"(the others keep {'light' if update_fn.state_cache['light'] else 'full'} "
+                               f"(the others keep {CTX_KIND[update_fn.state_cache['light']]} "
                                "activation contexts in HBM)")
                               if n > args.microbatch else "none",
                  "parallelism": f"dp{world}", "final_loss": loss,
+                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                  "host_enqueue_ms_idle_gpu": host_unblocked_ms,
                  "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * host_dt / args.steps},
   }

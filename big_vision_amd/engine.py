@@ -273,7 +273,7 @@ class Block:
 
   def fwd(self, x, n, L, light=False, kv_len=None):
     """kv_len (int32 [n], optional): key-padding length per sample (NaFlex, naflex_vit.py:84-113).
-    light: the saved context drops what the backward can re-derive cheaply - the two
+    light (True, or "g" = only the second item): the saved context drops what the backward can re-derive cheaply - the two
     LayerNorm outputs (re-normalised from x / x1) and gelu(h) (re-emitted by the fc2 dX
     GEMM) - one third of the block's activation bytes."""
     T, D, H = n * L, self.D, self.H
@@ -283,7 +283,7 @@ class Block:
     x1 = linear_fwd(o, self.wo, self.bo, out_dtype=x.dtype, epilogue=ops.EPI_RESIDUAL, aux=x)   # fp32 or bf16 stream
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
     x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light)
-    if light:
+    if light is True:     # light == "g": only gelu(h) is dropped, the LayerNorm outputs stay
       y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
@@ -331,7 +331,7 @@ class Encoder:
       x = ops.cast_bf16(x)
     for i, blk in enumerate(self.blocks):
       x_in = x
-      x, s = blk.fwd(x, n, L, light=(save == "light"), kv_len=kv_len)
+      x, s = blk.fwd(x, n, L, light=(True if save == "light" else ("g" if save == "g" else False)), kv_len=kv_len)
       if save:
         saved.append(s)
       if out is not None:

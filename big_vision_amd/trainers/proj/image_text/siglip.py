@@ -148,11 +148,15 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
       def fits(per_ctx, count):
         return headroom() - margin >= count * (per_ctx + per_ctx // 32)
 
+      # state_cache["light"]: None = undecided ("auto", first step), False = full contexts, "g" = contexts
+      # without gelu(h) (re-emitted by the fc2 dX GEMM), True / "light" = also without the LayerNorm outputs
       if state_cache["light"] is None:
-        state_cache["light"] = bool(light_cfg) if light_cfg != "auto" else None
+        state_cache["light"] = ({"g": "g", "light": "light"}.get(light_cfg, bool(light_cfg))
+                                if light_cfg != "auto" else None)
+      mode_of = lambda l: "light" if l in (True, "light") else ("g" if l == "g" else True)
       zi, zt, kept, norms = [], [], {}, []
       for k, s in enumerate(starts):
-        mode = "light" if state_cache["light"] else True
+        mode = mode_of(state_cache["light"])
         per_ctx = state_cache["per_ctx"].get(mode)
         keep = len(kept) < keep_max and (per_ctx is None or keep_cfg == "all" or fits(per_ctx, 1))
         before = torch.cuda.memory_allocated(dev)
@@ -161,14 +165,18 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         if keep and per_ctx is None:
           per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
           if state_cache["light"] is None:
-            # first step, "auto": stay with full contexts only if all of them fit
-            state_cache["light"] = keep_max > 1 and not fits(per_ctx, min(keep_max, len(starts)) - 1)
-            if state_cache["light"]:
+            # first step, "auto": the richest kind of context of which ALL micro-batches fit - full, then
+            # without gelu(h), then light (each trial re-runs this micro-batch's forward once)
+            others = min(keep_max, len(starts)) - 1
+            state_cache["light"] = False
+            for trial in ("g", "light"):
+              if keep_max <= 1 or fits(per_ctx, others):
+                break
               del c
-              mode = "light"
+              state_cache["light"] = mode = trial
               before = torch.cuda.memory_allocated(dev)
               a, b, _, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=mode)
-              state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
+              per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
         if keep:
           kept[s] = c
         del c
@@ -183,7 +191,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         ctx = kept.pop(s, None)
         if ctx is None:
           _, _, _, ctx = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro],
-                                save=("light" if state_cache["light"] else True))
+                                save=mode_of(state_cache["light"]))
         with dp.reserve_cus_for_collectives(comm if (sync is not None and s == starts[-1]) else None):
           ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
                  None if txt_frozen else dztxt[s:s + micro].contiguous(),
