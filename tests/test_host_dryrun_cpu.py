@@ -243,3 +243,39 @@ def test_two_towers_out_dict_keys(dry):
   # one input only (two_towers.py:43)
   zimg, ztxt, out_i = model.apply({"params": st.tree()}, image, None)
   assert ztxt is None and not any(k.startswith("txt/") for k in out_i)
+
+
+def test_bf16_residual_stream_routes_the_encoder_through_the_bf16x_kernels(dry):
+  """config.residual_stream = "bfloat16": block LayerNorms run on the bf16x entry points (both towers),
+  the gradient leaving each encoder stack is cast back to fp32 once per tower, and the setting does
+  not leak out of the step (model.apply afterwards sees the default fp32 stream)."""
+  from big_vision_amd import engine as E
+  calls, _ = dry
+  fn, state, batch = _setup(_cfg(residual_stream="bfloat16"))
+  assert E.residual_stream() == torch.float32
+  fn(state, None, batch)
+  assert E.residual_stream() == torch.float32
+  # 2 LayerNorms per block + encoder_norm per tower on the bf16 stream; the MAP head's LayerNorm (fp32 [n, D]) is not
+  assert calls["bv_layernorm_fwd_bf16x"] == 2 * BLOCKS + 2
+  assert calls["bv_layernorm_bwd_bf16x"] == 2 * BLOCKS + 2
+  assert calls["bv_layernorm_fwd"] == 1 and calls["bv_layernorm_bwd"] == 1
+  assert calls["bv_cast_f32"] == 2
+  calls.clear()
+  fn32, state32, batch32 = _setup(_cfg())
+  fn32(state32, None, batch32)
+  assert calls["bv_layernorm_fwd_bf16x"] == 0 and calls["bv_cast_f32"] == 0
+  assert calls["bv_layernorm_fwd"] == 2 * BLOCKS + 3
+
+
+def test_context_kinds_full_then_gelu_free_then_light(dry):
+  """microbatch_light: "g" keeps the LayerNorm outputs and drops gelu(h) (the fc2 dX GEMM re-emits it, no
+  re-normalisation in the backward); "light" drops both."""
+  calls, _ = dry
+  for kind, renorm in (("g", False), ("light", True), (False, False)):
+    fn, state, batch = _setup(_cfg(microbatch=2, microbatch_keep="all", microbatch_light=kind))
+    calls.clear()
+    fn(state, None, batch)
+    assert fn.state_cache["light"] == kind
+    ln_fwd = calls["bv_layernorm_fwd"]
+    base = (2 * BLOCKS + 3) * 4                       # 4 micro-batches of forward LayerNorms
+    assert ln_fwd == base + (2 * BLOCKS * 4 if renorm else 0), (kind, ln_fwd)
