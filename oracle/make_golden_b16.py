@@ -28,7 +28,13 @@ CFG_SO = dict(width=1152, depth=2, mlp_dim=4304, num_heads=16, patch=14, res=224
               temperature_init=10.0, bias_init=-10.0, seed=3, perturb_seed=321, batch_seed=2)
 IMAGE_CFG_SO = dict(variant="So400m/14", pool_type="map", depth=2)
 TEXT_CFG_SO = dict(variant="So400m", depth=2, vocab_size=32_000)
-FIXTURES = {"b16": (CFG, IMAGE_CFG, TEXT_CFG), "so400m_d2": (CFG_SO, IMAGE_CFG_SO, TEXT_CFG_SO)}
+# third fixture: the L/16@336 shapes of BASELINE configs[3] (width 1024, 16 heads, mlp 4096, 441 tokens) at 2 blocks
+CFG_L = dict(width=1024, depth=2, mlp_dim=4096, num_heads=16, patch=16, res=336, vocab=32_000, seq=64, n=2,
+             temperature_init=10.0, bias_init=-10.0, seed=5, perturb_seed=55, batch_seed=3)
+IMAGE_CFG_L = dict(variant="L/16", pool_type="map", depth=2)
+TEXT_CFG_L = dict(variant="L", depth=2, vocab_size=32_000)
+FIXTURES = {"b16": (CFG, IMAGE_CFG, TEXT_CFG), "so400m_d2": (CFG_SO, IMAGE_CFG_SO, TEXT_CFG_SO),
+            "l16_336_d2": (CFG_L, IMAGE_CFG_L, TEXT_CFG_L)}
 
 
 def make_inputs(dtype=torch.float32, tag="b16"):
