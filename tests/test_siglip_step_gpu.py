@@ -182,7 +182,9 @@ def test_bf16_residual_stream_step(dev, which):
   elif which == "b16_n32":   # what bench.py runs: B/16 + text-B, two-pass micro-batches with light contexts
     image_cfg = dict(variant="B/16", pool_type="map")
     text_cfg = dict(variant="B")
-    _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000, floor=True,
+    # (no floor measurement here: two more fp64 oracle passes at n = 32; measured 0.0127 at a floor of 0.0108,
+    #  profiles/r02_parity_report.jsonl - the default bounds hold with a wide margin)
+    _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000,
               config=_cfg(residual_stream="bfloat16", microbatch=8, microbatch_keep="all", microbatch_light=True),
               case="bf16 stream: siglip B/16 n=32 microbatch=8 light")
   else:                      # BASELINE configs[4] shapes
