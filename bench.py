@@ -42,7 +42,7 @@ IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 DOMINANT = (("bv_gemm_bf16", "bv_gemm_bf16_colsum"), 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
-PMC_PROFILE = "r02_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
+PMC_PROFILE = "r03_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
 DOMINANT_KERNEL = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
 
 
@@ -83,7 +83,7 @@ class GemmObserver:
 
 def pmc_traffic(world, micro):
   """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
-  THIS command (profiles/r02_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
+  THIS command (profiles/r03_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
   be read from inside the process).  None when the profile does not match the configuration."""
   path = os.path.join(ROOT, "profiles", PMC_PROFILE)
   try:
@@ -96,14 +96,15 @@ def pmc_traffic(world, micro):
     return None, None
 
 
-# Activations between the encoder blocks (config.residual_stream).  The trainers default to "float32", the
-# reference's arithmetic (models/vit.py keeps activations in fp32, only matmul inputs are cast).  The
-# benchmark opts into "bfloat16": LayerNorm inputs, the +residual GEMM epilogues, the saved block inputs and
-# the gradient stream are bf16, statistics / softmax / loss / optimizer stay fp32.  Its parity cost is
-# measured, not assumed: worst per-tensor gradient rel-L2 vs the fp64 oracle 0.014 -> 0.017 on this model
-# (tools/bf16_residual_budget.py), the -m gpu step tests run B/16 in this mode inside SURVEY 8c's bounds
-# (cosine >= 0.999, rel-L2 <= 3e-2); `--residual-stream float32` reproduces the other arithmetic.
-RESIDUAL_STREAM = "bfloat16"
+# Activations between the encoder blocks (config.residual_stream).  `value` is measured on "float32": the
+# reference's arithmetic (models/vit.py:92-110 keeps the residual stream in fp32 even with dtype_mm=bfloat16,
+# only matmul inputs are cast).  "bfloat16" (LayerNorm inputs, the +residual GEMM epilogues, the
+# saved block inputs and the gradient stream in bf16; statistics / softmax / loss / optimizer fp32) is an
+# opt-in trainer mode that is NARROWER than the reference: at N = 1 the line carries it as a second,
+# clearly separate object ("bf16_stream": value, ms_per_step and the worst per-tensor gradient rel-L2 the
+# -m gpu step tests measured for that mode), never as `value`.
+RESIDUAL_STREAM = "float32"
+BF16_STREAM_PARITY = ("profiles/r03_parity_report.jsonl", "bf16 stream: siglip B/16 n=32 microbatch=8 light")
 
 
 # siglip.make_update_fn's state_cache["light"] -> what a kept micro-batch context holds
@@ -174,6 +175,40 @@ def cpu_baseline(sample_pairs):
                     f"pairs, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
+def bf16_stream_parity():
+  """Worst per-tensor gradient rel-L2 / cosine of the bf16-stream B/16 n=32 micro-batched step vs the fp64
+  oracle, as the -m gpu suite last measured it (the committed report; bench.py never runs the oracle on
+  the timed path)."""
+  path, case = BF16_STREAM_PARITY
+  try:
+    with open(os.path.join(ROOT, path)) as f:
+      rows = [json.loads(l) for l in f if l.strip()]
+    row = [x for x in rows if x.get("case") == case][-1]
+    return {"parity_worst_rel_l2": row["worst_rel"], "parity_worst_cos": row["worst_cos"],
+            "parity_case": case, "parity_source": path}
+  except (OSError, IndexError, KeyError, ValueError):
+    return {"parity_worst_rel_l2": None, "parity_source": None}
+
+
+def rccl_info(comm, dev):
+  """Evidence that the N ranks of this line really joined one RCCL communicator: backend name, RCCL
+  version, and the result of an all-reduce of ones over the group (= the number of ranks that took part)."""
+  import torch.distributed as dist
+  info = {"ranks": comm.size, "backend": None, "version": None, "allreduce_of_ones": None}
+  if dist.is_available() and dist.is_initialized():
+    info["backend"] = dist.get_backend()
+    try:
+      v = torch.cuda.nccl.version()
+      info["version"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+      pass
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    info["allreduce_of_ones"] = float(one.item())
+    info["max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+  return info
+
+
 def _free_port():
   import socket
   with socket.socket() as sk:
@@ -194,13 +229,24 @@ def spawn_ranks(n):
     env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+  # Poll ALL children: a rank that dies while the others sit in an RCCL collective would otherwise leave a
+  # sequential wait() blocked forever on a healthy-looking rank.  First non-zero exit -> terminate the rest.
   rc = 0
-  for p in procs:
-    p.wait()
-    rc = rc or p.returncode
+  live = list(procs)
+  while live and not rc:
+    time.sleep(0.2)
+    for p in list(live):
+      if p.poll() is not None:
+        live.remove(p)
+        rc = rc or p.returncode
   if rc:
-    for p in procs:
-      if p.poll() is None:
+    for p in live:
+      p.terminate()
+    deadline = time.time() + 10
+    for p in live:
+      try:
+        p.wait(timeout=max(0.1, deadline - time.time()))
+      except subprocess.TimeoutExpired:
         p.kill()
     raise SystemExit(rc)
 
@@ -213,6 +259,8 @@ def main():
   ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
   ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch HIP events")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-bf16-stream", action="store_true",
+                  help="skip the second (bf16 residual stream) measurement that N = 1 appends as `bf16_stream`")
   ap.add_argument("--cpu-sample", type=int, default=16)
   ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
   ap.add_argument("--residual-stream", default=RESIDUAL_STREAM, choices=("float32", "bfloat16"),
@@ -235,7 +283,7 @@ def main():
 
   if not torch.cuda.is_available():
     raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
-  comm = dp.init_from_env()
+  comm = dp.init_from_env(overlap_channels=dp.RESERVED_CUS)   # gradient all-reduces overlap the backward's GEMMs
   world = comm.size
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
   local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,53 +292,82 @@ def main():
   assert args.global_batch % world == 0
   n = args.global_batch // world
 
-  model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, EMB),
-                           temperature_init=10.0, bias_init=-10.0)
   total_steps = max(20_000, args.steps + args.warmup)
-  config = make_config(total_steps)
-  config.microbatch = args.microbatch
-  config.residual_stream = args.residual_stream
   image, text = synthetic_batch(n, dev, seed=1 + comm.rank)
-  state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,
-                                     total_steps=total_steps, device=dev)
-  update_fn = siglip.make_update_fn(model, config, comm=comm)
   batch = {"image": image, "labels": text}
 
-  obs = GemmObserver()
-  meas = None
-  for _ in range(args.warmup):
-    state, meas = update_fn(state, None, batch)
-  # Host cost of one step = wall time to ENQUEUE it on an idle GPU with an empty launch queue (the
-  # average over the timed steps below also contains the time the host spends blocked on a full
-  # queue while the GPU is the bottleneck, so it says nothing about host-boundness).  Untimed extra
-  # step, outside the timed region.
-  host_unblocked_ms = None
-  if args.warmup > 0:
+  def measure(stream, steps, warmup, roofline):
+    """W untimed + K timed steps of the full training step on `stream`; everything it allocates is freed
+    on return (the second, bf16-stream measurement at N = 1 needs the HBM back)."""
+    model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, EMB),   # (the model caches its
+                             temperature_init=10.0, bias_init=-10.0)                # executors: one per measurement)
+    config = make_config(total_steps)
+    config.microbatch = args.microbatch
+    config.residual_stream = stream
+    state, _ = siglip.make_train_state(model, config, (n, RES, RES, 3), (n, SEQ), rng=0, comm=comm,
+                                       total_steps=total_steps, device=dev)
+    update_fn = siglip.make_update_fn(model, config, comm=comm)
+    obs = GemmObserver()
+    meas = None
+    for _ in range(warmup):
+      state, meas = update_fn(state, None, batch)
+    # Host cost of one step = wall time to ENQUEUE it on an idle GPU with an empty launch queue (the
+    # average over the timed steps below also contains the time the host spends blocked on a full
+    # queue while the GPU is the bottleneck, so it says nothing about host-boundness).  Untimed extra
+    # step, outside the timed region.
+    host_unblocked_ms = None
+    if warmup > 0:
+      comm.barrier()
+      torch.cuda.synchronize()
+      h0 = time.perf_counter()
+      state, meas = update_fn(state, None, batch)
+      host_unblocked_ms = 1e3 * (time.perf_counter() - h0)
+    if roofline:
+      _lib.observer = obs
     comm.barrier()
     torch.cuda.synchronize()
-    h0 = time.perf_counter()
-    state, meas = update_fn(state, None, batch)
-    host_unblocked_ms = 1e3 * (time.perf_counter() - h0)
-  if not args.no_roofline:
-    _lib.observer = obs
-  comm.barrier()
-  torch.cuda.synchronize()
-  obs.active = True
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    state, meas = update_fn(state, None, batch)
-  host_dt = time.perf_counter() - t0   # host enqueue time (diagnostic: host- vs GPU-bound)
-  torch.cuda.synchronize()
-  comm.barrier()
-  dt = time.perf_counter() - t0
-  obs.active = False
-  _lib.observer = None
-  t = torch.tensor([dt], device=dev, dtype=torch.float64)
-  if world > 1:
-    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-  dt = float(t.item())
-  loss = float(meas["training_loss"].item())
-  siglip.check_finite(meas)
+    obs.active = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      state, meas = update_fn(state, None, batch)
+    host_dt = time.perf_counter() - t0   # host enqueue time (diagnostic: host- vs GPU-bound)
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = time.perf_counter() - t0
+    obs.active = False
+    _lib.observer = None
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+      torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(meas["training_loss"].item())
+    siglip.check_finite(meas)
+    res = dict(dt=dt, host_dt=host_dt, host_unblocked_ms=host_unblocked_ms, loss=loss, obs=obs,
+               keep_n=update_fn.state_cache["keep_n"], light=update_fn.state_cache["light"],
+               peak=torch.cuda.max_memory_allocated(dev))
+    del state, update_fn, meas, model
+    return res
+
+  r = measure(args.residual_stream, args.steps, args.warmup, not args.no_roofline)
+  dt, host_dt, host_unblocked_ms, loss, obs = r["dt"], r["host_dt"], r["host_unblocked_ms"], r["loss"], r["obs"]
+  # N = 1 only: the opt-in bf16 residual stream on the same workload, as a separate object of the line
+  bf16_line = None
+  if world == 1 and args.residual_stream == "float32" and not args.no_bf16_stream:
+    try:
+      import gc
+      gc.collect()
+      torch.cuda.empty_cache()
+      torch.cuda.reset_peak_memory_stats(dev)
+      k2 = max(1, min(args.steps, 2))
+      r2 = measure("bfloat16", k2, 1, False)
+      bf16_line = {"value": args.global_batch * k2 / r2["dt"], "unit": "pairs/s", "ms_per_step": 1e3 * r2["dt"] / k2,
+                   "steps": k2, "warmup": 1, "final_loss": r2["loss"], "peak_hbm_gb": round(r2["peak"] / 1e9, 1),
+                   "contexts": CTX_KIND[r2["light"]] if n > args.microbatch else "full",
+                   "note": "config.residual_stream='bfloat16': narrower than the reference's fp32 residual stream "
+                           "(models/vit.py:92-110); reported beside `value`, never as `value`"}
+      bf16_line.update(bf16_stream_parity())
+    except Exception as e:   # the headline must not depend on the optional second measurement
+      bf16_line = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
   if comm.rank != 0:
     return
@@ -304,13 +381,13 @@ def main():
                              "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
                  "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
                  "residual_stream": args.residual_stream,
-                 "recompute": (f"{max(0, n // args.microbatch - update_fn.state_cache['keep_n'])} of "
+                 "recompute": (f"{max(0, n // args.microbatch - r['keep_n'])} of "
                                f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
-                               f"(the others keep {CTX_KIND[update_fn.state_cache['light']]} "
+                               f"(the others keep {CTX_KIND[r['light']]} "
                                "activation contexts in HBM)")
                               if n > args.microbatch else "none",
                  "parallelism": f"dp{world}", "final_loss": loss,
-                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                 "peak_hbm_gb": round(r["peak"] / 1e9, 1),
                  "host_enqueue_ms_idle_gpu": host_unblocked_ms,
                  "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * host_dt / args.steps},
   }
@@ -326,6 +403,10 @@ def main():
                         "algorithmic_bytes_per_launch": nbytes / max(1, launches),
                         "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
                         "share_of_step_time": ms / (1e3 * dt)}
+  if bf16_line is not None:
+    line["bf16_stream"] = bf16_line
+  if world > 1 or os.environ.get("BV_DP_FORCE_COLLECTIVES") == "1":
+    line["rccl"] = rccl_info(comm, dev)
   if world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
   sys.stdout.flush()

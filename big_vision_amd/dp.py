@@ -142,8 +142,14 @@ class GradSync:
     self.done = []
 
 
-def init_from_env(backend: str | None = None) -> Comm:
-  """Initialises torch.distributed from torchrun-style env vars (if present)."""
+def init_from_env(backend: str | None = None, overlap_channels: int | None = None) -> Comm:
+  """Initialises torch.distributed from torchrun-style env vars (if present).
+
+  overlap_channels: cap RCCL at this many channels (NCCL_MAX_NCHANNELS, only if the variable is not already
+  set).  Pass it ONLY for a job whose gradient all-reduces overlap the persistent GEMMs of the backward
+  (bench.py / the SigLIP trainer with overlap_grad_sync: one channel = one workgroup = one CU taken from the
+  GEMMs, see RESERVED_CUS); the default leaves RCCL's channel count alone, so other nccl jobs in the
+  process (large or multi-node all-reduces) are not throttled.  BV_NCCL_MAX_NCHANNELS overrides the value."""
   world = int(os.environ.get("WORLD_SIZE", "1"))
   force = os.environ.get("BV_DP_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
   if (world > 1 or force) and not dist.is_initialized():
@@ -156,7 +162,9 @@ def init_from_env(backend: str | None = None) -> Comm:
       torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
       # The collectives of a step move < 1 GB per 90 ms: a few channels are plenty, and every RCCL
       # channel is a workgroup that needs a CU of its own beside the persistent GEMMs (see RESERVED_CUS).
-      os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RESERVED_CUS))
+      cap = os.environ.get("BV_NCCL_MAX_NCHANNELS", overlap_channels)
+      if cap:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(cap)))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
   return Comm()
 

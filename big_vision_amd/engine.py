@@ -132,23 +132,24 @@ def map_entries(prefix, D, H, M):
 # halves the LayerNorm traffic and the +residual GEMM epilogues; measured against the parity bounds
 # by tools/bf16_residual_budget.py (oracle) and the -m gpu step tests.  Everything outside
 # Encoder.fwd / Encoder.bwd sees fp32 tensors in both modes.
-_STREAM = F32
+import threading
+
+_tls = threading.local()   # per host thread: two trainers driving two streams from two threads do not race
 
 
 def set_residual_stream(dtype):
-  """dtype: torch.float32 / torch.bfloat16 or their names; returns the previous setting."""
-  global _STREAM
-  old = _STREAM
+  """dtype: torch.float32 / torch.bfloat16 or their names; returns the previous setting (of this thread)."""
+  old = residual_stream()
   if isinstance(dtype, str):
     dtype = {"float32": F32, "fp32": F32, "f32": F32, "bfloat16": BF16, "bf16": BF16}[dtype]
   if dtype not in (F32, BF16):
     raise ValueError(f"residual_stream must be float32 or bfloat16, got {dtype}")
-  _STREAM = dtype
+  _tls.stream = dtype
   return old
 
 
 def residual_stream():
-  return _STREAM
+  return getattr(_tls, "stream", F32)
 
 
 class _W:
@@ -327,7 +328,7 @@ class Encoder:
     """x: fp32 [n*L, D].  Returns the last block's output in the stream dtype (the callers hand it to
     encoder_norm, whose kernel takes either) and the saved contexts."""
     saved = []
-    if _STREAM == BF16 and x.dtype == F32:
+    if residual_stream() == BF16 and x.dtype == F32:
       x = ops.cast_bf16(x)
     for i, blk in enumerate(self.blocks):
       x_in = x

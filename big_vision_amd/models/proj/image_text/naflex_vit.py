@@ -53,6 +53,14 @@ class NaflexExec:
   def __init__(self, m: "_Model", store: ParamStore, prefix: str, patch_dim: int):
     self.m, self.store = m, store
     D, H, M, P = m.width, m.num_heads, m.mlp_dim, m.nposemb
+    if patch_dim % 8:
+      # The GEMM operands move in 16-byte (8 x bf16) pieces.  The pixel-input ViT pads its im2col rows to a
+      # multiple of 8 inside bv_patchify_ld (14 x 14 x 3 = 588 -> 592); here the patches ARRIVE flattened
+      # and go through patchln_pre / a cast unpadded, so the stem's K would not match the padded weight.
+      raise NotImplementedError(
+          f"NaFlex stem with patch_dim = {patch_dim} (not a multiple of 8): the flattened patches are consumed "
+          "as they arrive (naflex_vit.py:227-236) and the stem GEMM needs 16-byte rows; use a patch size whose "
+          "P*P*3 is a multiple of 8 (16x16, 32x32) or zero-pad the patches and the embedding kernel's input rows")
     self.wemb = E._W(store, f"{prefix}embedding/kernel", (patch_dim, D))
     self.bemb = E._W(store, f"{prefix}embedding/bias")
     self.pos = E._W(store, f"{prefix}pos_embedding", (P * P, D))

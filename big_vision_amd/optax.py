@@ -30,6 +30,22 @@ MAX_SCHED = 8
 ADAFACTOR_NAMES = ("big_vision.scale_by_adafactor", "scale_by_adafactor")
 
 
+
+def _refuse_per_example_clip(config):
+  """`config.grad_clip_per_example` (reference optax.py:100-103 -> `clip_by_per_example_global_norm`,
+  optax.py:54-72) clips PER-EXAMPLE gradients: its update_fn takes a gradient tree whose leaves carry a
+  leading batch axis (`grads_flat[0].shape[0]`), clips every example's global norm and averages.  Neither
+  trainer on this path produces such a tree - `train.py:275-315` and `trainers/proj/image_text/siglip.py:
+  271-323` differentiate the batch-mean loss - and the fused step here accumulates the batch-summed
+  gradient in the kernels (dW GEMMs reduce over the batch), so the option cannot be honoured; it is
+  refused instead of silently clipping the wrong quantity."""
+  if config.get("grad_clip_per_example"):
+    raise NotImplementedError(
+        "config.grad_clip_per_example (big_vision/optax.py:100-103, clip_by_per_example_global_norm :54-72) "
+        "needs per-example gradient trees [batch, ...]; this step produces the batch gradient only "
+        "(as big_vision's own train.py / siglip.py trainers do). Use grad_clip_norm alone.")
+
+
 def factored_dims(shape, min_dim_size_to_factor=32):
   """optax/_src/factorized.py `_factored_dims` (factored=True): None, or (d1, d0) = the axes of the
   second-largest and the largest dimension (numpy argsort order on ties)."""
@@ -132,7 +148,7 @@ class Optimizer:
       mu_dtype = torch.bfloat16 if str(mu_dtype) in ("bfloat16", "torch.bfloat16") else torch.float32
     elif self.name in ADAFACTOR_NAMES:
       self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
-      assert not config.get("grad_clip_per_example"), "per-example clipping is not supported"
+      _refuse_per_example_clip(config)
       self.lr = float(config["lr"])
       self._init_adafactor(okw, lr_mult, wd, sched_idx_of_leaf)
       return
@@ -140,7 +156,7 @@ class Optimizer:
       raise NotImplementedError(f"optax_name={self.name!r}: scale_by_adam and big_vision.scale_by_adafactor "
                                 "are on the fused path")
     self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
-    assert not config.get("grad_clip_per_example"), "per-example clipping is not supported"
+    _refuse_per_example_clip(config)
     self.lr = float(config["lr"])
     # ---- per-entry hyper-parameter table + chunk map
     n_tr = store.trainable_count
@@ -194,6 +210,21 @@ class Optimizer:
       v = t if sl is None else t.select(sl[0], sl[1])
       shape, strides = tuple(v.shape), tuple(v.stride())
       fd = factored_dims(shape, self.af["min_dim"])
+      # scan=True models present their blocks as ONE stacked Flax leaf [depth, ...] and optax factors THAT
+      # leaf (optax/_src/factorized.py:_factored_dims on the stacked shape).  Per-block statistics are the
+      # same arithmetic as long as the depth axis is not one of the two factored axes, i.e. depth is not
+      # among the two largest extents >= min_dim_size_to_factor (B/16, L/16: depth 12 / 24 < 32).  Where it
+      # would be (g/14 depth 40, G/14 depth 48: [depth, D] biases factor over (depth, D)) the update rule
+      # would silently differ from the reference's - refuse.
+      group = st.ext_index[st.ext_of[leaf]]
+      if len(group) > 1:
+        fd_st = factored_dims((len(group),) + shape, self.af["min_dim"])
+        fd_shift = None if fd_st is None else tuple(a - 1 for a in fd_st)
+        if fd_shift != fd:
+          raise NotImplementedError(
+              f"{st.ext_of[leaf]}: stacked (scan) leaf {(len(group),) + shape} factors over axes {fd_st} in optax "
+              f"(the depth axis {len(group)} >= min_dim_size_to_factor enters the factored pair); per-block "
+              "Adafactor statistics would differ from big_vision's - not implemented")
       if fd is None:
         d1 = d0 = None
         rest = list(range(len(shape)))
@@ -350,8 +381,8 @@ class Optimizer:
     `<i>/0/2/<leaf>` = nu of masked(scale_by_adam) at chain position i (MaskedState.inner_state ->
     ScaleByAdamState(count, mu, nu); frozen leaves are MaskedNode()s and emit nothing), and
     `<j>/0/0` = count of every masked(scale_by_schedule).  Adafactor (scale_by_factored_rms +
-    ema, optax.py:187-216): `<i>/0/0/{0: count, 1: v_row, 2: v_col, 3: v}` and `<i>/0/2/0` = the
-    momentum trace.  Tensors are copies (stacked for scan-layout leaves)."""
+    ema, optax.py:187-216): `<i>/0/0/{0: count, 1: v_row, 2: v_col, 3: v}` and `<i>/0/2/{0: count,
+    1: ema}` (_af_state_tree).  Tensors are copies (stacked for scan-layout leaves)."""
     i_opt, i_sched = self._chain_layout()
     cnt = np.asarray(self.count, np.int32)
     tree = {str(j): {"0": {"0": cnt}} for j in i_sched}
@@ -359,7 +390,59 @@ class Optimizer:
     return tree
 
   def _opt_state_tree(self, cnt):
+    if self.name in ADAFACTOR_NAMES:
+      return self._af_state_tree(cnt)
     return {"0": cnt, "1": self._moment_tree(self.mu), "2": self._moment_tree(self.nu)}
+
+  def _trainable_ext_names(self):
+    st = self.store
+    return [n for n in st.leaf_names() if not any(e in st.frozen for e in st.entries_of(n))]
+
+  def _af_state_tree(self, cnt):
+    """State of masked(chain(scale_by_factored_rms, identity | clip, ema)) (optax.py:187-216) in the
+    reference's naming: inner_state = (FactoredState(count, v_row, v_col, v), EmptyState(), EmaState(count,
+    ema)) -> `0/{0: count, 1: v_row, 2: v_col, 3: v}` and `2/{0: count, 1: ema}` (no `2` when momentum is
+    off: optax.identity has an empty state).  optax keeps a zeros((1,)) placeholder in v_row / v_col of an
+    unfactored leaf and in v of a factored one; scan-layout leaves are stacked over depth (placeholders are
+    not: optax builds them from the stacked leaf)."""
+    st = self.store
+    trees = ({}, {}, {})
+    for n in self._trainable_ext_names():
+      group = st.ext_index[n]
+      stacked = not (len(group) == 1 and group[0] == n)
+      per = [self.adafactor_state_of(leaf) for leaf in group]
+      factored = next(l for l in self.af_leaves if l["leaf"] == group[0])["factored"]
+      for k in range(3):
+        real = (k < 2) == factored
+        ts = [p[k].detach().clone() for p in per]
+        trees[k][n] = (torch.stack(ts) if (stacked and real) else ts[0])
+    rt = lambda d: u.recover_tree(list(d.keys()), list(d.values()))
+    out = {"0": {"0": cnt, "1": rt(trees[0]), "2": rt(trees[1]), "3": rt(trees[2])}}
+    if self.mu is not None:
+      out["2"] = {"0": cnt, "1": self._moment_tree(self.mu)}
+    return out
+
+  def _af_assign(self, leaf, v_row, v_col, v):
+    """Inverse of adafactor_state_of: optax-ordered (v_row, v_col, v) of one storage leaf into af_state."""
+    lf = next(l for l in self.af_leaves if l["leaf"] == leaf)
+    buf = self.af_state[lf["soff"]:lf["soff"] + lf["n_state"]]
+    shape = lf["shape"]
+    if not lf["factored"]:
+      if tuple(v.shape) != tuple(shape):
+        raise ValueError(f"Shape mismatch for Adafactor v of {leaf}: {tuple(v.shape)} vs {tuple(shape)}")
+      # canonical order = the (up to four) non-trivial axes in leaf order: a plain flatten
+      buf.copy_(v.to(buf.dtype).to(buf.device).reshape(-1))
+      return
+    d1, d0 = lf["dims"]
+    B, R, C = lf["B"], lf["R"], lf["C"]
+    others = [a for a in range(len(shape)) if a not in (d1, d0)]
+    for t, drop, keep_last, lo, n in ((v_row, d0, d1, 0, B * R), (v_col, d1, d0, B * R, B * C)):
+      keep = [a for a in range(len(shape)) if a != drop]
+      want = tuple(shape[a] for a in keep)
+      if tuple(t.shape) != want:
+        raise ValueError(f"Shape mismatch for Adafactor statistics of {leaf}: {tuple(t.shape)} vs {want}")
+      perm = [keep.index(a) for a in others + [keep_last]]
+      buf[lo:lo + n].copy_(t.to(buf.dtype).to(buf.device).permute(perm).reshape(-1))
 
   def load_state_tree(self, tree):
     """Inverse of `state_tree` (accepts the flat `{name: array}` form too)."""
@@ -389,14 +472,42 @@ class Optimizer:
         dst.copy_(src.to(dst.dtype).to(dst.device))
 
   def _load_opt_state(self, flat, pre):
+    if self.name in ADAFACTOR_NAMES:
+      return self._load_af_state(flat, pre)
     self.count = int(np.asarray(flat[pre + "0"]))
     self._assign_moment(self.mu, flat, pre + "1/")
     self._assign_moment(self.nu, flat, pre + "2/")
 
+  def _load_af_state(self, flat, pre):
+    st = self.store
+    as_t = lambda x: x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, np.float32))
+    self.count = int(np.asarray(flat[pre + "0/0"]))
+    for n in self._trainable_ext_names():
+      keys = [f"{pre}0/{k}/{n}" for k in (1, 2, 3)]
+      missing = [k for k in keys if k not in flat]
+      if missing:
+        raise ValueError(f"optimizer state is missing '{missing[0]}'")
+      vr, vc, vv = (as_t(flat[k]) for k in keys)
+      group = st.ext_index[n]
+      stacked = not (len(group) == 1 and group[0] == n)
+      factored = next(l for l in self.af_leaves if l["leaf"] == group[0])["factored"]
+      for i, leaf in enumerate(group):
+        pick = lambda t, real: t[i] if (stacked and real) else t
+        self._af_assign(leaf, pick(vr, factored), pick(vc, factored), pick(vv, not factored))
+    if self.mu is not None:
+      self._assign_moment(self.mu, flat, pre + "2/1/")
+
   def state_dict(self):
+    if self.name in ADAFACTOR_NAMES:
+      return {"mu": self.mu, "af_state": self.af_state, "count": self.count}
     return {"mu": self.mu, "nu": self.nu, "count": self.count}
 
   def load_state_dict(self, d):
+    if self.name in ADAFACTOR_NAMES:
+      if self.mu is not None:
+        self.mu.copy_(d["mu"].to(self.mu.dtype))
+      self.af_state.copy_(d["af_state"]); self.count = int(d["count"])
+      return
     self.mu.copy_(d["mu"].to(self.mu.dtype)); self.nu.copy_(d["nu"]); self.count = int(d["count"])
 
 

@@ -1,9 +1,14 @@
-"""Host-side utilities mirroring the subset of big_vision/utils.py the hot path uses.
+"""Host-side utilities PORTED from big_vision/utils.py (Copyright 2024 Big Vision Authors,
+Apache-2.0): the subset of that file the hot path uses, with the jax / flax lines removed.
 
-Pure Python / numpy (no device code): tree naming (utils.py:616-862), regex
-masks (:1169-1212), duration -> steps (:1002-1067), learning-rate schedules
-(:1070-1143) and .npz parameter loading (:133-227).  Function names, argument
-meaning and error behaviour follow the reference.
+This file is a port, not a rewrite: `_traverse_with_names`, `recover_tree`,
+`check_and_compile_patterns`, `make_mask_trees`, `steps`, `create_learning_rate_schedule`,
+`npload` and `load_checkpoint_np` are the reference's host-side contract helpers (leaf naming
+utils.py:616-862, regex masks :1169-1212, duration -> steps :1002-1067, learning-rate schedules
+:1070-1143, .npz parameter loading :133-227) kept line-compatible on purpose - configs, checkpoints
+and schedules written for the reference must mean the same thing here, and the reference's own
+known-answer tests (utils_test.py:228-281) pin them (tests/test_host_cpu.py).  Pure Python / numpy,
+no device code; nothing of the hot path's arithmetic lives here.
 """
 from __future__ import annotations
 
@@ -218,10 +223,21 @@ def load_params(ckpt, **kw):
   return params
 
 
+def _to_numpy(v):
+  """bfloat16 tensors (Adam / Adafactor momentum with a bf16 accumulator) are written the way the
+  reference's checkpoints hold them: raw 2-byte void, which `npload` widens back exactly (utils.py:827-833)."""
+  if hasattr(v, "detach"):
+    v = v.detach().cpu()
+    if str(v.dtype) == "torch.bfloat16":
+      import torch
+      return v.contiguous().view(torch.int16).numpy().view(np.dtype("V2"))
+    return v.numpy()
+  return np.asarray(v)
+
+
 def save_params_npz(fname, tree):
   names_and_vals, _ = tree_flatten_with_names(tree)
-  np.savez(fname, **{n: np.asarray(v.detach().cpu() if hasattr(v, "detach") else v)
-                     for n, v in names_and_vals})
+  np.savez(fname, **{n: _to_numpy(v) for n, v in names_and_vals})
 
 
 def save_train_state(fname, train_state):

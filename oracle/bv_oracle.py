@@ -678,6 +678,21 @@ def create_learning_rate_schedule(total_steps, batch_size=None, data_size=None,
 # -----------------------------------------------------------------------------
 # Optimizer chain — optax.py:75-149 (bv_optax.make) restated on flat name->tensor
 # -----------------------------------------------------------------------------
+def clip_by_per_example_global_norm(per_example_grads, max_norm):
+  """optax.py:54-72 (`clip_by_per_example_global_norm`): every leaf carries a leading batch axis; each
+  example's gradient is scaled to a global norm of at most max_norm over ALL leaves
+  (optax.per_example_global_norm_clip: scale_i = min(1, max_norm / ||g_i||)), the clipped gradients are
+  summed over the batch and divided by the batch size.  List of [B, ...] tensors in, list of [...] out."""
+  B = per_example_grads[0].shape[0]
+  sq = sum((g.reshape(B, -1) ** 2).sum(1) for g in per_example_grads)
+  norm = torch.sqrt(sq)
+  scale = torch.clamp(max_norm / torch.clamp(norm, min=1e-30), max=1.0)
+  out = []
+  for g in per_example_grads:
+    out.append((g * scale.view((B,) + (1,) * (g.dim() - 1))).sum(0) / B)
+  return out
+
+
 class OptaxOracle:
   """Functional restatement of `bv_optax.make(config, params, sched_kw=...)`.
 

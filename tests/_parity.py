@@ -31,7 +31,9 @@ ABS_SMALL = 2e-3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-FLOOR_MULT = 2.0
+# Round 3: the measured bf16-operand floor is REPORTED next to every tensor but no
+# longer widens a bound.  A tensor above REL_MAX / below COS_MIN fails unless the case lists it by
+# name in `exceptions` with its own stated bound (a visible, per-tensor exception in the test body).
 
 
 def bf16_floor(loss_closure, params64):
@@ -57,11 +59,11 @@ def bf16_floor(loss_closure, params64):
   return out
 
 
-def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen=(), floor=None):
+def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen=(), floor=None, exceptions=None):
   """gref / gours: {leaf name: fp64 cpu tensor}.  `frozen`: name prefixes that must be ABSENT from
   gours (no gradient is ever produced for frozen leaves).  `floor` ({name: (rel, cos)} from
-  bf16_floor): a tensor may exceed the default bounds up to FLOOR_MULT x the error the prescribed
-  bf16-operand arithmetic itself shows on that tensor (measured, same weights and batch).
+  bf16_floor): reported next to each tensor, never used as a bound.  `exceptions` ({leaf name:
+  (rel_max, cos_min)}): tensors held to their own stated bound instead of the case's.
   Returns (global norm over the trainable leaves, sorted worst list); raises AssertionError naming
   every offending tensor."""
   is_frozen = lambda k: any(k.startswith(p) for p in frozen)
@@ -84,8 +86,7 @@ def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen
     rel = err / nr
     frel, fcos = (floor or {}).get(k, (0.0, 1.0))
     rows.append((rel, cos, k, nr / gnorm, frel, fcos))
-    rmax = max(rel_max, FLOOR_MULT * frel)
-    cmin = 1.0 - max(1.0 - cos_min, FLOOR_MULT * (1.0 - fcos))
+    rmax, cmin = (exceptions or {}).get(k, (rel_max, cos_min))
     if not (cos >= cmin and rel <= rmax):
       bad.append(f"{k}: cosine {cos:.5f} (>= {cmin:.5f}) rel-L2 {rel:.4f} (<= {rmax:.4f}) "
                  f"share of global norm {nr / gnorm:.3f}, bf16 floor rel {frel:.4f}")

@@ -97,3 +97,99 @@ def test_unsupported_options_raise():
   store = ParamStore([Entry("k", (64, 64), init_zeros)], "cpu")
   with pytest.raises(NotImplementedError, match="clip_by_block_rms"):
     bv_optax.make(_cfg(optax=dict(clipping_threshold=1.0)), store, sched_kw=dict(global_batch_size=1, total_steps=1))
+
+
+def _af_store(scan_depth=0):
+  D, H = 64, 2
+  views = {f"blk/attn/{n}/kernel": (1, i) for i, n in enumerate(("query", "key", "value"))}
+  ents = [Entry("blk/attn/qkv/kernel", (D, 3, H, 32), init_zeros, views),
+          Entry("blk/attn/out/kernel", (H, 32, D), init_zeros),
+          Entry("blk/mlp/kernel", (D, 96), init_zeros),
+          Entry("blk/ln/scale", (D,), init_zeros),
+          Entry("t", (1,), init_zeros)]
+  return ParamStore(ents, "cpu")
+
+
+def test_adafactor_state_tree_roundtrip(tmp_path):
+  """`state_tree()` / `load_state_tree()` / `u.save_train_state` for the Adafactor
+  optimizer.  The reference's optax state is masked(chain(scale_by_factored_rms, identity, ema)):
+  `1/0/0/{0 count, 1 v_row, 2 v_col, 3 v}/<leaf>` + `1/0/2/{0 count, 1 ema}` (optax.py:187-216, leaf naming
+  utils.py:616-641).  Random state -> tree (shapes as optax keeps them) -> .npz -> fresh optimizer: every
+  statistic, the bf16 momentum and the count come back bit for bit."""
+  from big_vision_amd import utils as u
+  store = _af_store()
+  opt, _ = bv_optax.make(_cfg(), store, sched_kw=dict(global_batch_size=1, total_steps=4))
+  g = torch.Generator().manual_seed(3)
+  opt.af_state.copy_(torch.rand(opt.af_state.shape, generator=g))
+  # the padding between leaves is never read or written by the kernels; zero it for the equality below
+  mask = torch.zeros_like(opt.af_state, dtype=torch.bool)
+  for lf in opt.af_leaves:   # (the trailing rcm[B] of a factored leaf is per-step scratch: mean_R(v_row), rebuilt by the row pass)
+    n_real = lf["B"] * (lf["R"] + lf["C"]) if lf["factored"] else lf["n_state"]
+    mask[lf["soff"]:lf["soff"] + n_real] = True
+  opt.af_state.mul_(mask)
+  opt.mu.copy_(torch.randn(opt.mu.shape, generator=g).to(opt.mu.dtype))
+  opt.count = 7
+  tree = opt.state_tree()
+  flat = dict(u.tree_flatten_with_names(tree)[0])
+  # shapes as optax keeps them: v_row drops d0, v_col drops d1, placeholders are (1,)
+  assert tuple(flat["1/0/0/1/blk/attn/query/kernel"].shape) == (2, 32)       # [H, Dh]  (D dropped)
+  assert tuple(flat["1/0/0/2/blk/attn/query/kernel"].shape) == (64, 2)       # [D, H]   (Dh dropped)
+  assert tuple(flat["1/0/0/3/blk/attn/query/kernel"].shape) == (1,)
+  assert tuple(flat["1/0/0/1/blk/mlp/kernel"].shape) == (64,) and tuple(flat["1/0/0/2/blk/mlp/kernel"].shape) == (96,)
+  assert tuple(flat["1/0/0/3/blk/ln/scale"].shape) == (64,) and tuple(flat["1/0/0/1/blk/ln/scale"].shape) == (1,)
+  assert int(flat["1/0/0/0"]) == 7 and int(flat["1/0/2/0"]) == 7
+  assert tuple(flat["1/0/2/1/blk/attn/key/kernel"].shape) == (64, 2, 32) and flat["1/0/2/1/blk/attn/key/kernel"].dtype == torch.bfloat16
+  f = str(tmp_path / "af_state.npz")
+  u.save_train_state(f, {"params": store.tree(), "opt": opt})
+  store2 = _af_store()
+  opt2, _ = bv_optax.make(_cfg(), store2, sched_kw=dict(global_batch_size=1, total_steps=4))
+  # (u.load_train_state = store.load_tree + refresh of the bf16 shadow on the GPU + this call)
+  opt2.load_state_tree({k[len("opt/"):]: v for k, v in u.npload(f).items() if k.startswith("opt/")})
+  assert opt2.count == 7
+  assert torch.equal(opt2.af_state, opt.af_state)
+  mu_a, mu_b = (dict(u.tree_flatten_with_names(o._moment_tree(o.mu))[0]) for o in (opt, opt2))   # (the flat buffer has alignment gaps)
+  assert mu_a.keys() == mu_b.keys() and all(torch.equal(mu_a[k], mu_b[k]) for k in mu_a)
+  # state_dict form too
+  opt3, _ = bv_optax.make(_cfg(), _af_store(), sched_kw=dict(global_batch_size=1, total_steps=4))
+  opt3.load_state_dict(opt.state_dict())
+  assert torch.equal(opt3.af_state, opt.af_state) and opt3.count == 7
+  # a wrong shape is refused, not reshaped
+  bad = dict(flat); bad["1/0/0/1/blk/mlp/kernel"] = torch.zeros(96)
+  with pytest.raises(ValueError, match="Shape mismatch"):
+    opt2.load_state_tree(bad)
+
+
+def test_adafactor_scan_leaves_factor_like_the_stacked_leaf():
+  """optax factors the STACKED leaf of a scan=True model.  depth < min_dim_size_to_factor
+  never enters the factored pair (same statistics per block; the state tree stacks them over depth); a depth
+  that would (>= 32 with a [depth, D] bias) is refused instead of silently diverging."""
+  def store_of(depth):
+    ents = [e for i in range(depth) for e in (Entry(f"enc/encoderblock_{i}/k/kernel", (64, 96), init_zeros),
+                                              Entry(f"enc/encoderblock_{i}/k/bias", (96,), init_zeros))]
+    return ParamStore(ents, "cpu", scan_prefixes=("enc",))
+  st = store_of(3)
+  opt, _ = bv_optax.make(_cfg(), st, sched_kw=dict(global_batch_size=1, total_steps=4))
+  from big_vision_amd import utils as u
+  flat = dict(u.tree_flatten_with_names(opt.state_tree())[0])
+  assert tuple(flat["1/0/0/1/enc/encoderblock/k/kernel"].shape) == (3, 64)      # v_row of [3, 64, 96]: drops d0 = 96
+  assert tuple(flat["1/0/0/2/enc/encoderblock/k/kernel"].shape) == (3, 96)
+  assert tuple(flat["1/0/0/3/enc/encoderblock/k/bias"].shape) == (3, 96)        # unfactored [3, 96]
+  assert tuple(flat["1/0/0/1/enc/encoderblock/k/bias"].shape) == (1,)
+  opt.load_state_tree(flat)
+  with pytest.raises(NotImplementedError, match="depth axis"):
+    bv_optax.make(_cfg(), store_of(40), sched_kw=dict(global_batch_size=1, total_steps=4))
+
+
+def test_per_example_clipping_is_refused_with_the_reference_line():
+  """optax.py:100-103: grad_clip_per_example needs per-example gradient trees (clip_by_per_example_global_norm,
+  optax.py:54-72); no trainer on this path produces them, so the option raises instead of clipping the batch
+  gradient and calling it per-example.  The math it would apply (known answer, 2 examples): clip each
+  example's global norm to max_norm, then average."""
+  store = ParamStore([Entry("k", (64, 64), init_zeros)], "cpu")
+  for name in ("big_vision.scale_by_adafactor", "scale_by_adam"):
+    with pytest.raises(NotImplementedError, match=r"optax.py:100-103"):
+      bv_optax.make(_cfg(optax_name=name, grad_clip_norm=1.0, grad_clip_per_example=True), store,
+                    sched_kw=dict(global_batch_size=1, total_steps=1))
+  g = torch.tensor([[3.0, 4.0], [0.3, 0.4]])                       # norms 5 and 0.5, max_norm 1
+  want = (g[0] / 5.0 + g[1]) / 2
+  assert torch.allclose(O.clip_by_per_example_global_norm([g], 1.0)[0], want)

@@ -7,10 +7,12 @@ oracle restatement of the reference step (oracle/bv_oracle.py).  Tolerances
   embeddings zimg/ztxt (unit norm)   max-abs  <= 2e-2
   logits  S = t z.z + b  (t = 10)    max-abs  <= 0.25
   loss                               rel      <= 1e-2
-  parameter gradients                per tensor: cosine >= 0.999 and rel-L2 <= 3e-2, or
-                                     up to 2x the error the prescribed bf16-operand arithmetic
-                                     itself shows on that tensor (oracle with bf16-rounded
-                                     contraction operands vs fp64, measured per case: _parity.py);
+  parameter gradients                per tensor: cosine >= 0.999 and rel-L2 <= 3e-2; the
+                                     error the prescribed bf16-operand arithmetic itself shows on
+                                     each tensor (oracle with bf16-rounded contraction operands vs
+                                     fp64: _parity.bf16_floor) is REPORTED next to it, it is not a
+                                     bound; a tensor outside the bounds is a per-tensor exception
+                                     named in the test body with its own bound;
                                      tensors below 1e-3 of the global grad norm: abs err <= 2e-3 of it
   params after 1 Adam step           compared to the oracle chain fed OUR grads
                                      (isolates the optimizer): rtol 1e-5
@@ -43,9 +45,11 @@ def _cfg(total_steps=10, **kw):
 
 
 def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, config=None,
-              tol_z=2e-2, tol_logit=0.25, frozen=(), floor=False, dirty_step=False, case=None, rel_max=None):
+              tol_z=2e-2, tol_logit=0.25, frozen=(), floor=False, dirty_step=False, case=None, rel_max=None,
+              exceptions=None):
   """frozen: leaf-name prefixes config.schedule freezes (LiT).  floor: also measure the bf16-operand
-  noise floor of the oracle for this case (tests/_parity.py) and allow 2x that per tensor.
+  noise floor of the oracle for this case (tests/_parity.py; reported, not a bound).  exceptions:
+  {leaf name: (rel_max, cos_min)} for tensors held to their own stated bound.
   dirty_step: the weights are edited in place (as store.load_tree does) and update_fn runs FIRST,
   with the bf16 shadow still dirty - the step itself has to refresh it; the forward-only parity
   then runs on the restored pre-step weights."""
@@ -111,7 +115,7 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
   if floor:
     fl = _parity.bf16_floor(lambda p: O.siglip_step_loss(p, image.double(), text, **okw)[0], params64)
   kw_tol = {} if rel_max is None else {"rel_max": rel_max}
-  gnorm, rows = _parity.compare_grads(case, gref, gours, frozen=frozen, floor=fl, **kw_tol)
+  gnorm, rows = _parity.compare_grads(case, gref, gours, frozen=frozen, floor=fl, exceptions=exceptions, **kw_tol)
   # l2_grads / clip norm cover the trainable leaves only (optax.py:105, siglip.py:316)
   assert abs(meas["l2_grads"].item() - gnorm) <= 2e-2 * gnorm, (meas["l2_grads"].item(), gnorm)
   # ---- optimizer: oracle chain on OUR grads must reproduce OUR new params -------
@@ -190,8 +194,13 @@ def test_bf16_residual_stream_step(dev, which):
   else:                      # BASELINE configs[4] shapes
     image_cfg = dict(variant="B/16", pool_type="tok", head_zeroinit=False)
     text_cfg = dict(variant="B")
+    # The ONE tensor of the whole suite outside SURVEY 8c's rel-L2 <= 3e-2, listed by name: the query kernel
+    # of text block 5 on this 8-pair, 16-token batch measures 0.0338 at cosine 0.99943 on the bf16 stream
+    # (0.0228 on the fp32 stream = its bf16-operand floor 0.0229; 0.1 % of the global gradient norm).  The
+    # bf16 stream is an opt-in mode (not the reference's arithmetic, not what bench.py's `value` runs).
     _run_case(dev, image_cfg, text_cfg, E=768, n=8, res=224, seq=16, vocab=32_000, bias_init=-2.71,
               config=_cfg(schedule=LIT_SCHEDULE, residual_stream="bfloat16"), frozen=("img/",), floor=True,
+              exceptions={"txt/Encoder_0/encoderblock_5/MultiHeadDotProductAttention_0/query/kernel": (4e-2, 0.999)},
               case="bf16 stream: LiT B/16 frozen img n=8")
 
 
@@ -257,6 +266,19 @@ def test_b16_siglip_step_n32_through_microbatches(dev):
   _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000,
             config=_cfg(microbatch=8, microbatch_keep="all", microbatch_light=True), floor=True,
             case="siglip B/16 n=32 microbatch=8 light")
+
+
+@pytest.mark.parametrize("stream", ["float32", "bfloat16"])
+def test_b16_n32_bench_mode_gelu_free_contexts(dev, stream):
+  """The context kind bench.py's N = 1 step can end up in when `microbatch_light="auto"` finds that full
+  contexts do not fit: "g" = gelu(h) is not kept, the fc2 dX GEMM re-emits it (BV_EPI_GELU_BWD_EMIT) while
+  the LayerNorm outputs stay.  B/16 + text-B, n = 32 as 4 micro-batches of 8, both residual streams,
+  against the fp64 oracle on the whole batch (VERDICT r2 weak #2b: this mode had only a CPU dry run)."""
+  image_cfg = dict(variant="B/16", pool_type="map")
+  text_cfg = dict(variant="B")
+  _run_case(dev, image_cfg, text_cfg, E=768, n=32, res=224, seq=64, vocab=32_000,
+            config=_cfg(residual_stream=stream, microbatch=8, microbatch_keep="all", microbatch_light="g"),
+            case=f"siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, {stream} stream")
 
 
 def test_l16_336_siglip_step_small_batch(dev):
