@@ -39,6 +39,7 @@ PROTOTYPES = {
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_fwd_bf16x": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
+    "bv_layernorm_bwd_y": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P, P, P],
     "bv_layernorm_bwd_bf16x": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
@@ -88,7 +89,7 @@ PROTOTYPES["bv_adafactor_leaf"] = [P, P, P, c_int, P, P, P, c_int, P, c_float, c
 
 RESTYPES = {"bv_gemm_workspace_bytes": c_long}   # everything else returns an int status
 
-EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT = range(7)
+EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)
 
 _lib = None
 

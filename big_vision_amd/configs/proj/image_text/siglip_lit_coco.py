@@ -8,8 +8,8 @@ max(3 % of the run, 100) warm-up steps, image tower frozen through the schedule,
 so a run configured from either file takes the same step.  Input pipeline, tokenizer,
 checkpoint locations and the retrieval evaluator's dataset plumbing of the reference file are
 outside the hot path: this file states the tensors the step consumes instead (`init_shapes`,
-`input.batch_size`).  `txt`: 'transformer_b' (default here, the in-repo text transformer of width
-768) or 'bert_base' (models.proj.flaxformer.bert, the reference default).
+`input.batch_size`).  `txt`: 'bert_base' (default, as in the reference: models.proj.flaxformer.bert,
+Adam), 'bert_large' (Adafactor, :91-94) or 'transformer_b' (the in-repo text transformer of width 768).
 """
 import big_vision.configs.common as bvcc
 from ml_collections import ConfigDict
@@ -18,7 +18,7 @@ _IMG = {"B/16": ("B/16", 768), "L/16": ("L/16", 1024)}
 
 
 def get_config(arg=None):
-  arg = bvcc.parse_arg(arg, res=224, runlocal=False, token_len=16, txt="transformer_b", img="B/16",
+  arg = bvcc.parse_arg(arg, res=224, runlocal=False, token_len=16, txt="bert_base", img="B/16",
                        init="", img_head=False, batch_size=512)
   variant, dim = _IMG[arg.img]
   c = ConfigDict()
@@ -36,10 +36,11 @@ def get_config(arg=None):
   c.model = ConfigDict()
   c.model.image_model = "vit"
   c.model.image = ConfigDict(dict(variant=variant, pool_type="tok", head_zeroinit=False))
-  if arg.txt == "bert_base":
+  if arg.txt in ("bert_base", "bert_large"):
+    txt_name = arg.txt[len("bert_"):]
     c.model.text_model = "proj.flaxformer.bert"
-    c.model.text = ConfigDict(dict(config="base", head_zeroinit=False))
-    c.optax_name = "scale_by_adam"
+    c.model.text = ConfigDict(dict(config=txt_name, head_zeroinit=False))
+    c.optax_name = "scale_by_adam" if txt_name == "base" else "big_vision.scale_by_adafactor"   # :91-94
   else:
     c.model.text_model = "proj.image_text.text_transformer"
     c.model.text = ConfigDict(dict(variant="B", vocab_size=32_000))

@@ -52,30 +52,60 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// flax nn.gelu(approximate=True): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
-// Written as x * sigmoid(2u) = x / (1 + exp2(-2 log2(e) u)): one v_exp_f32 + one v_rcp_f32,
-// no IEEE division (these run inside GEMM epilogues, 128 evaluations per lane and tile).
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float k = -2.0f * 1.4426950408889634f * 0.7978845608028654f;   // -2 log2(e) sqrt(2/pi)
-  const float z = k * x * (1.0f + 0.044715f * x * x);
-  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));   // sigmoid(2u)
-  return x * sg;
+// flax nn.gelu(approximate=True): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3), written as
+// x * sigmoid(2u) = x / (1 + exp2(z)), z = x (k0 + k1 x^2), k0 = -2 log2(e) sqrt(2/pi), k1 = 0.044715 k0:
+// one v_exp_f32 + one v_rcp_f32 per element, no IEEE division.  These run inside GEMM epilogues (128
+// evaluations per lane and 256x256 tile) where both waves of a SIMD are in their epilogue at the same time,
+// i.e. they are bound by the SIMD's VALU throughput: everything but the two transcendentals is written on
+// PAIRS of elements (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two fp32 lanes per instruction, full rate).
+// The scalar entry points evaluate the SAME operation sequence (same fused / unfused roundings), so a value
+// computed by any kernel through any of them has the same bits (forward g vs the backward's re-emitted g).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define BV_GELU_K0 (-2.0f * 1.4426950408889634f * 0.7978845608028654f)
+#define BV_GELU_K1 (BV_GELU_K0 * 0.044715f)
+#define BV_GELU_U0 (2.0f * 0.7978845608028654f)
+#define BV_GELU_U1 (BV_GELU_U0 * 3.0f * 0.044715f)
+__device__ __forceinline__ f32x2 pk_splat(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 gelu_sigmoid_pk(f32x2 x, f32x2 x2) {   // sigmoid(2u) of both elements
+  const f32x2 z = x * __builtin_elementwise_fma(x2, pk_splat(BV_GELU_K1), pk_splat(BV_GELU_K0));
+  const f32x2 den = f32x2{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + pk_splat(1.0f);
+  return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
 }
-// value g = x sigmoid(2u) and derivative d/dx g = s + x s (1 - s) 2 u',
-// u' = sqrt(2/pi) (1 + 3*0.044715 x^2), in one pass (shared exp/rcp).  The explicit fmaf /
-// products pin the rounding so that every caller (with or without the value) gets the same bits.
+__device__ __forceinline__ f32x2 gelu_tanh_pk(f32x2 x) { return x * gelu_sigmoid_pk(x, x * x); }
+// value g = x s and derivative dg = s + x s (1 - s) 2 u', 2 u' = U0 + U1 x^2, sharing exp / rcp
+__device__ __forceinline__ void gelu_tanh_val_grad_pk(f32x2 x, f32x2& g, f32x2& dg) {
+  const f32x2 x2 = x * x;
+  const f32x2 s = gelu_sigmoid_pk(x, x2);
+  g = x * s;
+  const f32x2 up = __builtin_elementwise_fma(x2, pk_splat(BV_GELU_U1), pk_splat(BV_GELU_U0));
+  dg = __builtin_elementwise_fma(g * (pk_splat(1.0f) - s), up, s);
+}
+__device__ __forceinline__ float gelu_tanh_f(float x) { return gelu_tanh_pk(pk_splat(x)).x; }
 __device__ __forceinline__ void gelu_tanh_val_grad_f(float x, float& g, float& dg) {
-  const float c = 0.7978845608028654f;
-  const float x2 = x * x;
-  const float z = (-2.0f * 1.4426950408889634f * c) * x * __builtin_fmaf(0.044715f, x2, 1.0f);
-  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
-  g = x * sg;
-  const float up = (2.0f * c) * __builtin_fmaf(3.0f * 0.044715f, x2, 1.0f);
-  dg = __builtin_fmaf(g * (1.0f - sg), up, sg);
+  f32x2 gg, dd;
+  gelu_tanh_val_grad_pk(pk_splat(x), gg, dd);
+  g = gg.x; dg = dd.x;
 }
 __device__ __forceinline__ float gelu_tanh_grad_f(float x) {
   float g, dg;
   gelu_tanh_val_grad_f(x, g, dg);
   return dg;
+}
+// both bf16 halves of a packed dword as an fp32 pair (exact), and back (round to nearest even)
+__device__ __forceinline__ f32x2 bf2_unpack(uint32_t w) { return f32x2{bflo(w), bfhi(w)}; }
+__device__ __forceinline__ uint32_t bf2_pack(f32x2 v) { return pack_bf2(v.x, v.y); }
+// The MLP activation as every epilogue applies it (one definition, so that the context kinds of the
+// trainer - full: g and gelu' kept; gelu(h)-free / light: h kept - feed the backward the SAME bits):
+//   h  = bf16(pre-activation)          the only form of h that is ever stored or differentiated
+//   g  = bf16(gelu(h)),  d = bf16(gelu'(h))
+// mlp_act_words: packed (h, g, d) of a pair of fp32 pre-activations; mlp_act_from_h: (g, d) from a stored h word.
+__device__ __forceinline__ void mlp_act_from_h(uint32_t hw, uint32_t& gw, uint32_t& dw) {
+  f32x2 g, d;
+  gelu_tanh_val_grad_pk(bf2_unpack(hw), g, d);
+  gw = bf2_pack(g); dw = bf2_pack(d);
+}
+__device__ __forceinline__ void mlp_act_words(f32x2 pre, uint32_t& hw, uint32_t& gw, uint32_t& dw) {
+  hw = bf2_pack(pre);
+  mlp_act_from_h(hw, gw, dw);
 }
 #endif

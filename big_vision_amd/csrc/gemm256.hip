@@ -75,6 +75,7 @@ typedef __attribute__((address_space(1))) const void gl_void;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 __device__ __forceinline__ int swzk(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
@@ -293,6 +294,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // PROBE 11 (tools/probes/gemm_r3_probe.hip, TIMING ONLY - the fragments are not re-mapped, results are
+  // garbage): the same main loop issuing v_mfma_f32_32x32x16_bf16 - per quadrant 2 x 1 fragments of 32 x 32
+  // x 4 k-steps of 16 = 8 MFMAs instead of 16, the same 32 accumulator and 48 operand registers.
+  f32x16 acc32[4][2];
+  if constexpr (PROBE == 11) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  }
+#define BV_ACC(i, j, r) (PROBE == 11 ? acc32[(i) >> 1][(j) >> 1][(((i) & 1) * 2 + ((j) & 1)) * 4 + (r)] : acc[i][j][r])
   bf16x8 af[4][2], bfg[4][2];
 
   // A fragments of 64-row sub-tile `sub` (4 frags x 2 k-steps) of stage base `sa`
@@ -359,12 +373,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #define BV_MFMA_QUAD(I0, J0)                                                                   \
   do {                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                             \
-    if (PROBE != 4)                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+    if constexpr (PROBE == 11) {                                                               \
+      if (first) {                                                                             \
+        _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2)                                       \
+          acc32[((I0) >> 1) + r2][(J0) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
+              bfg[(J0)][0], af[r2 * 2][0], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+      } else {                                                                                 \
+        _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2)                                       \
+          acc32[((I0) >> 1) + r2][(J0) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
+              bfg[(J0)][0], af[r2 * 2][0], acc32[((I0) >> 1) + r2][(J0) >> 1], 0, 0, 0);       \
+      }                                                                                        \
+      _Pragma("unroll") for (int k4 = 1; k4 < 4; ++k4)                                         \
+        _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2)                                       \
+          acc32[((I0) >> 1) + r2][(J0) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
+              bfg[(J0) + (k4 >> 1)][k4 & 1], af[r2 * 2 + (k4 >> 1)][k4 & 1],                   \
+              acc32[((I0) >> 1) + r2][(J0) >> 1], 0, 0, 0);                                    \
+    } else                                                                                     \
+    if (PROBE != 4) {                                                                          \
+      /* first K-tile of a work item: the k-step-0 MFMAs take C = 0 (an inline constant), so   \
+         the 128 accumulator registers are never cleared by VALU moves (512 cycles per wave    \
+         and tile during which the SIMD's matrix pipe had nothing to do) */                    \
+      if (first) {                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
+            acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+                bfg[(J0) + j][0], af[i][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);               \
+      } else {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                          \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
+            acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                 \
+                bfg[(J0) + j][0], af[i][0], acc[(I0) + i][(J0) + j], 0, 0, 0);                 \
+      }                                                                                        \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
           acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
-              bfg[(J0) + j][ks], af[i][ks], acc[(I0) + i][(J0) + j], 0, 0, 0);                 \
+              bfg[(J0) + j][1], af[i][1], acc[(I0) + i][(J0) + j], 0, 0, 0);                   \
+    }                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                             \
   } while (0)
 
@@ -405,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   // DMA): with `pre` set, the loads K-tile 0 of the next tile would issue were issued BEFORE
   // the stores (into the ring slots the finished tile freed), and K-tile 0's counted wait
   // leaves the stores outstanding (vmcnt(4 + NSTORE)) instead of draining them.
-  constexpr int NSTORE = KM ? ((OUTF32 || EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_BWD_EMIT) ? 32 : 16) : 32;
+  constexpr int NSTORE = KM ? ((OUTF32 || EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_BWD_EMIT || EPI == BV_EPI_GELU_GD) ? 32 : 16) : 32;
   bool pre = false;
   for (int jt = 0; jt < nmy; ++jt) {
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
@@ -417,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       const int bs2 = (bs1 == 2) ? 0 : bs1 + 1;        // slot of K-tile gk+2
       const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
       const bool doA = moreA && !pre, doB = moreB && !pre;
+      const bool first = t == 0;
       // -------- phase 0: quadrant (0,0)
       readA(sa, 0);
       readB(sb, 0);
@@ -463,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     stamp();
     // Every wave has finished reading the last K-tile: its ring slots are free.  Issue the next
     // tile's K-tile 1 (A) / K-tile 2 (B) now, ahead of the epilogue's stores.
-    if ((KM || p.slab) && EPI != BV_EPI_GELU_BWD && EPI != BV_EPI_GELU_BWD_EMIT && p.pre_issue) {
+    if ((KM || p.slab) && EPI != BV_EPI_GELU_BWD && EPI != BV_EPI_GELU_BWD_EMIT && EPI != BV_EPI_MUL && p.pre_issue) {
       const bool mA = ca.j < nmy, mB = cb.j < nmy;
       if (mA || mB) {
         const int b1 = (bs == 2) ? 0 : bs + 1, b2 = (b1 == 2) ? 0 : b1 + 1;
@@ -488,21 +533,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       nc[j] = n0 + wc * 64 + (OUTF32 ? j * 16 + lg * 4 : (j >> 1) * 32 + lg * 8 + (j & 1) * 4);
-    float bv[16], cs[16];
+    // Everything below works on PAIRS of adjacent columns (f32x2: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32,
+    // two fp32 lanes per VALU instruction): pair q of a row fragment = columns nc[q >> 1] + 2 (q & 1) + {0, 1}.
+    f32x2 bv[8], cs[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bv[e] = cs[e] = 0.f;
+    for (int q = 0; q < 8; ++q) bv[q] = cs[q] = pk_splat(0.f);
     if (p.bias) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + nc[j]);
-        bv[j * 4 + 0] = b.x; bv[j * 4 + 1] = b.y; bv[j * 4 + 2] = b.z; bv[j * 4 + 3] = b.w;
+        bv[j * 2 + 0] = f32x2{b.x, b.y}; bv[j * 2 + 1] = f32x2{b.z, b.w};
       }
     }
+    const f32x2 alpha2 = pk_splat(p.alpha);
     const int mrow0 = m0 + wr * 128 + lr;
     const bool nts = (p.nt & 1) || PROBE == 6, ntl = p.nt & 2;
-    // row fragments per batch of auxiliary loads (GELU': 2, the variant is at the VGPR limit)
-    constexpr bool GBWD = EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT;
+    // GBWD: epilogues that take a bf16 auxiliary operand of C's shape and feed the fused column sums
+    constexpr bool GBWD = EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT || EPI == BV_EPI_MUL;
     constexpr bool RESBF = EPI == BV_EPI_RESIDUAL && !OUTF32;   // bf16 residual stream: aux bf16, C bf16
+    // row fragments per batch of auxiliary loads (GELU': 2, the variants are at the VGPR limit)
     constexpr int IB = GBWD ? 2 : 4;
 #pragma unroll
     for (int ib = 0; ib < 8; ib += IB) {
@@ -530,98 +579,77 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       for (int ii = 0; ii < IB; ++ii) {
         const int i = ib + ii;
         const int m = mrow0 + i * 16;
-        float v[16];
+        // the GELU' variants sit at the VGPR limit: keep the scheduler from interleaving the (register-
+        // hungry) evaluation of two row fragments
+        if constexpr (GBWD) __builtin_amdgcn_sched_barrier(0);
+        f32x2 v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[i][j][r] * p.alpha + bv[j * 4 + r];
-        if constexpr ((EPI == BV_EPI_RESIDUAL && OUTF32) || EPI == BV_EPI_POS) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j * 4 + 0] += ax[ii][j].x; v[j * 4 + 1] += ax[ii][j].y;
-            v[j * 4 + 2] += ax[ii][j].z; v[j * 4 + 3] += ax[ii][j].w;
-          }
-        } else if constexpr (RESBF) {
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[hh * 8 + e * 2 + 0] += bflo(w[e]);
-              v[hh * 8 + e * 2 + 1] += bfhi(w[e]);
-            }
-          }
-        } else if constexpr (EPI == BV_EPI_GELU_BWD) {
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[hh * 8 + e * 2 + 0] *= gelu_tanh_grad_f(bflo(w[e]));
-              v[hh * 8 + e * 2 + 1] *= gelu_tanh_grad_f(bfhi(w[e]));
-            }
-          }
-        } else if constexpr (EPI == BV_EPI_GELU_BWD_EMIT) {
-          // same, and C2 = gelu(aux): the activation is recomputed here (from the same bf16
-          // pre-activation the forward applied it to) instead of being kept from the forward.
-          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            const uint32_t w[4] = {hx[ii][hh].x, hx[ii][hh].y, hx[ii][hh].z, hx[ii][hh].w};
-            uint32_t gw[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float g0, d0, g1, d1;
-              gelu_tanh_val_grad_f(bflo(w[e]), g0, d0);
-              gelu_tanh_val_grad_f(bfhi(w[e]), g1, d1);
-              v[hh * 8 + e * 2 + 0] *= d0;
-              v[hh * 8 + e * 2 + 1] *= d1;
-              gw[e] = pack_bf2(g0, g1);
-            }
-            st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
-          }
-        }
-        if constexpr (GBWD) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) cs[e] += v[e];
-        }
+          for (int h2 = 0; h2 < 2; ++h2)
+            v[j * 2 + h2] = __builtin_elementwise_fma(f32x2{BV_ACC(i, j, h2 * 2), BV_ACC(i, j, h2 * 2 + 1)}, alpha2, bv[j * 2 + h2]);
         if constexpr (OUTF32) {
+          if constexpr (EPI == BV_EPI_RESIDUAL || EPI == BV_EPI_POS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j * 2 + 0] += f32x2{ax[ii][j].x, ax[ii][j].y};
+              v[j * 2 + 1] += f32x2{ax[ii][j].z, ax[ii][j].w};
+            }
+          }
           float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            st16(c + nc[j], __builtin_bit_cast(u32x4, make_float4(v[j * 4], v[j * 4 + 1], v[j * 4 + 2], v[j * 4 + 3])), nts);
+            st16(c + nc[j], __builtin_bit_cast(u32x4, make_float4(v[j * 2].x, v[j * 2].y, v[j * 2 + 1].x, v[j * 2 + 1].y)), nts);
         } else {
           bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc;
+          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
           if (PROBE == 7)   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back)
             c = reinterpret_cast<bf16*>(p.C) + ((long)bid * 128 + ((m - m0) & 127)) * 256 - n0;
           if (PROBE == 5) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
 #pragma unroll
-            for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(v[e]));
+            for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(v[q]));
             continue;
           }
+          // one 16-byte half (8 columns = 4 pairs) at a time: evaluate, reduce, convert, store - short live ranges
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
-            uint4 o;
-            o.x = pack_bf2(v[hh * 8 + 0], v[hh * 8 + 1]);
-            o.y = pack_bf2(v[hh * 8 + 2], v[hh * 8 + 3]);
-            o.z = pack_bf2(v[hh * 8 + 4], v[hh * 8 + 5]);
-            o.w = pack_bf2(v[hh * 8 + 6], v[hh * 8 + 7]);
-            st16(c + nc[hh * 2], __builtin_bit_cast(u32x4, o), nts);
-          }
-          if constexpr (EPI == BV_EPI_GELU) {
-            bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
+            // bf16 auxiliary operand: word e of half hh holds the pair q = hh * 4 + e
+            uint32_t aw[4] = {0, 0, 0, 0};
+            if constexpr (GBWD || RESBF) { aw[0] = hx[ii][hh].x; aw[1] = hx[ii][hh].y; aw[2] = hx[ii][hh].z; aw[3] = hx[ii][hh].w; }
+            uint32_t cw[4], gw[4];   // first / second bf16 output of this half, packed pairs
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-              // g = gelu(h) of the bf16-ROUNDED pre-activation h that is stored (and that the
-              // backward differentiates / can recompute g from): forward and backward agree.
-              uint32_t gw[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const uint32_t hw = pack_bf2(v[hh * 8 + e * 2], v[hh * 8 + e * 2 + 1]);
-                gw[e] = pack_bf2(gelu_tanh_f(bflo(hw)), gelu_tanh_f(bfhi(hw)));
+            for (int e = 0; e < 4; ++e) {
+              f32x2& x = v[hh * 4 + e];
+              if constexpr (RESBF) {
+                x += bf2_unpack(aw[e]);
+              } else if constexpr (EPI == BV_EPI_MUL) {
+                x *= bf2_unpack(aw[e]);   // dH = dG o gelu'(h): the derivative was written (bf16) by the forward's GELU_GD epilogue
+              } else if constexpr (EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT) {
+                // EMIT: also C2 = gelu(aux), recomputed here (from the same bf16 pre-activation the forward
+                // applied it to) instead of being kept from the forward
+                // (gelu' is rounded to bf16 before the product, as GELU_GD stores it: all context kinds agree)
+                uint32_t dw;
+                mlp_act_from_h(aw[e], gw[e], dw);
+                x *= bf2_unpack(dw);
               }
-              st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
+              if constexpr (GBWD) {
+                cs[hh * 4 + e] += x;
+                asm volatile("" : "+v"(cs[hh * 4 + e]));   // accumulate HERE (hipcc otherwise defers the 64 adds of a tile to its end: 40+ spilled pairs)
+              }
+              if constexpr (EPI == BV_EPI_GELU_GD) {
+                // C = gelu(h), C2 = gelu'(h) of the bf16-rounded pre-activation h (which is not stored)
+                uint32_t hw;
+                mlp_act_words(x, hw, cw[e], gw[e]);
+              } else {
+                cw[e] = bf2_pack(x);
+                // g = gelu(h) of the bf16-ROUNDED pre-activation h that is stored (and that the
+                // backward differentiates / can recompute g from): forward and backward agree.
+                if constexpr (EPI == BV_EPI_GELU) gw[e] = bf2_pack(gelu_tanh_pk(bf2_unpack(cw[e])));
+              }
             }
+            st16(c + nc[hh * 2], u32x4{cw[0], cw[1], cw[2], cw[3]}, nts);
+            if constexpr (EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_GD || EPI == BV_EPI_GELU_BWD_EMIT)
+              st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
           }
         }
       }
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       if (p.colsum) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          float sum = cs[e];
+          float sum = cs[e >> 1][e & 1];
           sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
           sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
           sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x141, 0xF, 0xF, true));  // row_half_mirror
@@ -674,17 +702,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   }
     stamp();
     tstamp(jt);
-    // ---- next work item: clear the accumulators, move the math cursor
+    // ---- next work item: move the math cursor (the accumulators restart from C = 0 in the MFMAs)
+    if constexpr (PROBE == 4) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     cur.t = cur.nk - 1;
     advance(cur);
   }
 #undef BV_MFMA_QUAD
 #undef BV_MID
 #undef BV_END
+#undef BV_ACC
   if (PROBE != 0 && p.dbg && tid == 0) {
     p.dbg[bid * 4 + 2] = __builtin_amdgcn_s_memtime();
     p.dbg[bid * 4 + 3] = __builtin_amdgcn_s_memrealtime();
@@ -1378,6 +1409,8 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_BWD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_BWD_EMIT) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD_EMIT, false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_GELU_GD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_GD, false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_MUL) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_MUL, false>), grid, block, 0, s, p);
   else if (out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, false>), grid, block, 0, s, p);
   if (use_slab)

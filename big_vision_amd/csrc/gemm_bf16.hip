@@ -233,25 +233,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         const float4 x = *reinterpret_cast<const float4*>(
             reinterpret_cast<const float*>(p.aux) + (long)(m % p.aux_rows) * p.ldaux + n);
         v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+      } else if (epi == BV_EPI_MUL) {
+        const uint2 d = *reinterpret_cast<const uint2*>(
+            reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + n);
+        v[0] *= bflo(d.x); v[1] *= bfhi(d.x); v[2] *= bflo(d.y); v[3] *= bfhi(d.y);
       } else if (epi == BV_EPI_GELU_BWD || epi == BV_EPI_GELU_BWD_EMIT) {
         const uint2 h = *reinterpret_cast<const uint2*>(
             reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux + n);
-        float g[4], d[4];
-        gelu_tanh_val_grad_f(bflo(h.x), g[0], d[0]);
-        gelu_tanh_val_grad_f(bfhi(h.x), g[1], d[1]);
-        gelu_tanh_val_grad_f(bflo(h.y), g[2], d[2]);
-        gelu_tanh_val_grad_f(bfhi(h.y), g[3], d[3]);
-        if (epi == BV_EPI_GELU_BWD_EMIT) {
-          uint2 go;
-          go.x = pack_bf2(g[0], g[1]);
-          go.y = pack_bf2(g[2], g[3]);
+        uint2 go, dw;
+        mlp_act_from_h(h.x, go.x, dw.x);
+        mlp_act_from_h(h.y, go.y, dw.y);
+        const float d[4] = {bflo(dw.x), bfhi(dw.x), bflo(dw.y), bfhi(dw.y)};   // gelu' rounded to bf16 (as GELU_GD stores it)
+        if (epi == BV_EPI_GELU_BWD_EMIT)
           *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + n) = go;
-        }
         v[0] *= d[0]; v[1] *= d[1]; v[2] *= d[2]; v[3] *= d[3];
       }
       if (p.colsum) {   // small / ragged problems only: one atomic per element
 #pragma unroll
         for (int r = 0; r < 4; ++r) unsafeAtomicAdd(p.colsum + n + r, v[r]);
+      }
+      if (epi == BV_EPI_GELU_GD) {   // C = gelu(h), C2 = gelu'(h) of the bf16-rounded pre-activation
+        uint2 hw, gw, dw;
+        mlp_act_words(f32x2{v[0], v[1]}, hw.x, gw.x, dw.x);
+        mlp_act_words(f32x2{v[2], v[3]}, hw.y, gw.y, dw.y);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = gw;
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc + n) = dw;
+        continue;
       }
       if (p.out_f32) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) =
@@ -313,22 +320,22 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
              "bv_gemm_bf16: B contiguous dim / ldb must be multiples of 8 (N=%d K=%d ldb=%ld)", N, K, ldb);
   BV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0),
              "bv_gemm_bf16: operand pointers must be 16-byte aligned");
-  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_GELU_BWD_EMIT, "bv_gemm_bf16: bad epilogue %d", epilogue);
+  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_MUL, "bv_gemm_bf16: bad epilogue %d", epilogue);
   BV_REQUIRE(ldc % 4 == 0, "bv_gemm_bf16: ldc=%ld must be a multiple of 4", ldc);
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_GELU_BWD ||
-      epilogue == BV_EPI_GELU_BWD_EMIT)
+      epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_MUL)
     BV_REQUIRE(aux != nullptr && ldaux % 4 == 0, "bv_gemm_bf16: epilogue %d needs aux (ldaux %% 4 == 0)", epilogue);
   if (epilogue == BV_EPI_POS) BV_REQUIRE(aux_rows > 0, "bv_gemm_bf16: POS epilogue needs aux_rows > 0");
-  if (epilogue == BV_EPI_GELU || epilogue == BV_EPI_GELU_BWD_EMIT)
+  if (epilogue == BV_EPI_GELU || epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_GELU_GD)
     BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: epilogue %d needs bf16 C and C2", epilogue);
   if (epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)   // RESIDUAL: aux and C share one dtype (fp32 or bf16)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
-  if (epilogue == BV_EPI_GELU_BWD)
-    BV_REQUIRE(!out_f32, "bv_gemm_bf16: epilogue GELU_BWD writes bf16 (out_f32 must be 0)");
+  if (epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_MUL)
+    BV_REQUIRE(!out_f32, "bv_gemm_bf16: epilogue %d writes bf16 (out_f32 must be 0)", epilogue);
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
   if (colsum)
-    BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT,
-               "bv_gemm_bf16_colsum: column sums are fused into the GELU_BWD epilogues only (got %d)", epilogue);
+    BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_MUL,
+               "bv_gemm_bf16_colsum: column sums are fused into the GELU_BWD / MUL epilogues only (got %d)", epilogue);
 
   if (g_fast_path && bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K,
                                      epilogue, bias, aux, ldaux, aux_rows, C2, alpha, split_k, colsum, stream))

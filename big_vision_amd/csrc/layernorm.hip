@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      float* __restrict__ dscale,
                                                      float* __restrict__ dbias,
                                                      float* __restrict__ dxsum, int rows, int D,
-                                                     long row_stride, long row_offset) {
+                                                     long row_stride, long row_offset,
+                                                     const float* __restrict__ bias, bf16* __restrict__ y_out) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
@@ -120,6 +121,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         dr[it] = dres ? *reinterpret_cast<const float4*>(dres + xrow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         xh[it] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
                              (xv.w - mean) * rstd);
+        if (y_out) {
+          // the forward's bf16 output, re-derived from the x this kernel reads anyway (same expression as
+          // ln_fwd_kernel): "light" contexts do not keep it, and a separate re-normalisation pass would
+          // read x a second time (4 of its 6 bytes per element)
+          const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+          float4 o;
+          o.x = (xv.x - mean) * rstd * sc.x + bb.x;
+          o.y = (xv.y - mean) * rstd * sc.y + bb.y;
+          o.z = (xv.z - mean) * rstd * sc.z + bb.z;
+          o.w = (xv.w - mean) * rstd * sc.w + bb.w;
+          uint2 pk;
+          pk.x = pack_bf2(o.x, o.y);
+          pk.y = pack_bf2(o.z, o.w);
+          *reinterpret_cast<uint2*>(y_out + (long)r * D + c) = pk;
+        }
         g[it] = make_float4(d.x * sc.x, d.y * sc.y, d.z * sc.z, d.w * sc.w);
         s1 += g[it].x + g[it].y + g[it].z + g[it].w;
         s2 += g[it].x * xh[it].x + g[it].y * xh[it].y + g[it].z * xh[it].z + g[it].w * xh[it].w;
@@ -561,10 +577,24 @@ extern "C" int bv_layernorm_fwd(const float* x, const float* scale, const float*
   return bv_check_launch("bv_layernorm_fwd");
 }
 
+extern "C" int bv_layernorm_bwd_y(const void* dy, int dy_is_f32, const float* x, const float* scale,
+                                  const float* mean, const float* rstd, const float* dres, float* dx,
+                                  void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows,
+                                  int D, long row_stride, long row_offset, const float* bias, void* y_bf16,
+                                  void* stream);
 extern "C" int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float* scale,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
                                 void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows,
                                 int D, long row_stride, long row_offset, void* stream) {
+  return bv_layernorm_bwd_y(dy, dy_is_f32, x, scale, mean, rstd, dres, dx, dx_bf16, dscale, dbias, dx_colsum, rows, D,
+                            row_stride, row_offset, nullptr, nullptr, stream);
+}
+extern "C" int bv_layernorm_bwd_y(const void* dy, int dy_is_f32, const float* x, const float* scale,
+                                  const float* mean, const float* rstd, const float* dres, float* dx,
+                                  void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows,
+                                  int D, long row_stride, long row_offset, const float* bias, void* y_bf16,
+                                  void* stream) {
+  BV_REQUIRE(!y_bf16 || (bias && row_stride == 1), "bv_layernorm_bwd_y: y_bf16 needs the LayerNorm bias and row_stride 1");
   BV_REQUIRE(rows > 0 && D > 0, "bv_layernorm_bwd: empty input rows=%d D=%d", rows, D);
   BV_REQUIRE(D % 4 == 0 && D <= 256 * MAXV, "bv_layernorm_bwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
   BV_REQUIRE(row_stride >= 1 && row_offset >= 0 && row_offset < row_stride, "bv_layernorm_bwd: bad row_stride/offset");
@@ -577,7 +607,7 @@ extern "C" int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, c
 #define BV_LN_BWD(F32, NV)                                                                              \
   hipLaunchKernelGGL((ln_bwd_kernel<F32, NV>), dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x, \
                      scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D,     \
-                     row_stride, row_offset)
+                     row_stride, row_offset, bias, (bf16*)y_bf16)
   if (dy_is_f32) {
     if (nv == 3) BV_LN_BWD(true, 3); else if (nv == 4) BV_LN_BWD(true, 4); else BV_LN_BWD(true, MAXV);
   } else {

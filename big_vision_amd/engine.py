@@ -220,7 +220,10 @@ class LN:
   def fwd(self, x, rows, D, **kw):
     return ops.layernorm_fwd(x, self.scale.f32, self.bias.f32, rows=rows, D=D, **kw)
 
-  def bwd(self, dy, x, mean, rstd, rows, D, **kw):
+  def bwd(self, dy, x, mean, rstd, rows, D, y_out=None, **kw):
+    """y_out (bf16 [rows, D]): also re-emit this LayerNorm's forward output (fp32 x only)."""
+    if y_out is not None:
+      kw.update(bias=self.bias.f32, y_out=y_out)
     return ops.layernorm_bwd(dy, x, self.scale.f32, mean, rstd, rows=rows, D=D,
                              dscale=self.scale.grad, dbias=self.bias.grad, **kw)
 
@@ -232,29 +235,43 @@ class MLP:
     self.M = M
 
   def fwd(self, y_bf, resid, keep_g=True):
-    """resid + fc2(gelu(fc1(y))) ; returns (out f32, h_pre bf16, g bf16 or None)."""
-    g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
-    h = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
-    out = linear_fwd(g, self.w2, self.b2, out_dtype=resid.dtype, epilogue=ops.EPI_RESIDUAL, aux=resid)
-    return out, h, (g if keep_g else None)
+    """resid + fc2(gelu(fc1(y))) ; returns (out, hd bf16, g bf16 or None).
 
-  def bwd(self, dout_f32, dout_bf, y_bf, h, g, bias2_done=False):
+    keep_g (full contexts): the fc1 epilogue BV_EPI_GELU_GD evaluates gelu AND its derivative on the fp32
+    pre-activation - they share the exp / rcp - and writes g = gelu(h) and hd = gelu'(h); the pre-activation
+    itself is never stored and the backward's fc2 dX GEMM only multiplies by hd (BV_EPI_MUL).
+    not keep_g (light contexts): hd = the bf16 pre-activation h (BV_EPI_GELU: g is applied to the rounded h
+    that is stored) and g is dropped after fc2; the backward re-derives both g and gelu'(h) from h
+    (BV_EPI_GELU_BWD_EMIT, bit-identical g)."""
+    g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
+    if keep_g:
+      hd = torch.empty_like(g)
+      linear_fwd(y_bf, self.w1, self.b1, out=g, epilogue=ops.EPI_GELU_GD, out2=hd)
+    else:
+      hd = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
+    out = linear_fwd(g, self.w2, self.b2, out_dtype=resid.dtype, epilogue=ops.EPI_RESIDUAL, aux=resid)
+    return out, hd, (g if keep_g else None)
+
+  def bwd(self, dout_f32, dout_bf, y_bf, hd, g, bias2_done=False, dx_kw=None):
     """Returns dy (bf16) = gradient w.r.t. the MLP input y.  bias2_done: the Dense_1 bias
     gradient (column sums of dout) was already accumulated by the LayerNorm-backward kernel
-    that produced dout (bv_layernorm_bwd dx_colsum).  g = None ("light" context): the
-    activation gelu(h) was not kept; the dX GEMM that needs gelu'(h) anyway re-emits it
-    (BV_EPI_GELU_BWD_EMIT, bit-identical to the forward's g)."""
+    that produced dout (bv_layernorm_bwd dx_colsum).  g given: hd = gelu'(h) from the forward (see fwd).
+    g = None ("light" context): hd = the pre-activation h; the dX GEMM that needs gelu'(h) anyway
+    re-emits the activation (BV_EPI_GELU_BWD_EMIT, bit-identical to the forward's g)."""
     # The Dense_0 bias gradient (column sums of dh) is reduced inside the same epilogue.
     if g is None:
-      g = torch.empty_like(h)
-      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g, colsum=self.b1.grad)
+      g = torch.empty_like(hd)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=hd, out2=g, colsum=self.b1.grad)
       linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
       del g
     else:
       linear_bwd_w(g, dout_bf, self.w2, None if bias2_done else self.b2, dy_for_bias=dout_f32)
-      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_GELU_BWD, aux=h, colsum=self.b1.grad)
+      dh = linear_bwd_x(dout_bf, self.w2, epilogue=ops.EPI_MUL, aux=hd, colsum=self.b1.grad)
+    # dx_kw: epilogue of the last dX GEMM (post-LN blocks add the residual branch there, fp32 out)
+    if y_bf is None:   # the caller gets y from the LayerNorm backward and runs the Dense_0 dW GEMM afterwards
+      return linear_bwd_x(dh, self.w1, **(dx_kw or {})), dh
     linear_bwd_w(y_bf, dh, self.w1, None)
-    return linear_bwd_x(dh, self.w1)
+    return linear_bwd_x(dh, self.w1, **(dx_kw or {}))
 
 
 # ------------------------------------------------------------- encoder -------
@@ -294,24 +311,42 @@ class Block:
     LayerNorm_0 backward that produces that block's dx2 (bias grads = column sums of dx)."""
     x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g = saved
     T, D, H = n * L, self.D, self.H
-    if y1 is None:   # light context: same kernel, same input -> the forward's y1 bit for bit
-      y1 = self.ln1.fwd(x1, T, D)[0]
     if x.dtype == BF16:   # bf16 residual stream: the gradient stream IS the GEMM operand
       dx2 = dx2_bf
-    dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g, bias2_done=b2_done)
-    del y1
+    # Light contexts keep neither LayerNorm output.  On the fp32 stream the LayerNorm BACKWARD kernel re-emits
+    # it (bv_layernorm_bwd_y: it reads x anyway; same expression, same bits as the forward) and the weight-
+    # gradient GEMM that needs it runs right after; on the bf16 stream a forward pass re-normalises first.
+    emit_y = x.dtype == F32
+    if y1 is None and not emit_y:
+      y1 = self.ln1.fwd(x1, T, D)[0]
+    dh = None
+    if y1 is None:
+      dy1, dh = self.mlp.bwd(dx2, dx2_bf, None, h, g, bias2_done=b2_done)
+      y1 = torch.empty((T, D), device=dx2.device, dtype=BF16)
+      y1_out = y1
+    else:
+      dy1 = self.mlp.bwd(dx2, dx2_bf, y1, h, g, bias2_done=b2_done)
+      y1_out = None
     dx1_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
-    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad)
+    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2, dx_bf16=dx1_bf, dx_colsum=self.bo.grad, y_out=y1_out)
+    if dh is not None:
+      linear_bwd_w(y1, dh, self.mlp.w1, None)
+    del y1, dh
     linear_bwd_w(o, dx1_bf, self.wo, None)      # out-proj bias grad = colsum(dx1): fused above
     d_o = linear_bwd_x(dx1_bf, self.wo)
     dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=self.bqkv.grad, kv_len=kv_len)   # q/k/v bias grads fused
-    if y0 is None:
+    if y0 is None and not emit_y:
       y0 = self.ln0.fwd(x, T, D)[0]
-    linear_bwd_w(y0, dqkv, self.wqkv, None)
-    del y0
+    y0_out = None
+    if y0 is None:
+      y0_out = torch.empty((T, D), device=dx2.device, dtype=BF16)
+    else:
+      linear_bwd_w(y0, dqkv, self.wqkv, None)
     dy0 = linear_bwd_x(dqkv, self.wqkv)
     dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
-    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf, dx_colsum=next_b2)
+    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf, dx_colsum=next_b2, y_out=y0_out)
+    if y0_out is not None:
+      linear_bwd_w(y0_out, dqkv, self.wqkv, None)
     return dx, dx_bf
 
 

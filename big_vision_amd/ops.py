@@ -8,7 +8,7 @@ import torch
 
 from big_vision_amd import _lib
 from big_vision_amd._lib import (EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD,
-                                 EPI_ATOMIC, EPI_GELU_BWD_EMIT)
+                                 EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -53,7 +53,7 @@ def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=Non
          epilogue=EPI_NONE, bias=None, aux=None, aux_rows=0, out2=None, alpha=1.0, split_k=0,
          colsum=None):
   """C[M,N] = A(MxK) B(KxN) with bf16 inputs; see bv_gemm_bf16 in include/bvhip.h.
-  colsum (fp32 [N], GELU_BWD epilogues): += column sums of C (bv_gemm_bf16_colsum).
+  colsum (fp32 [N], GELU_BWD / MUL epilogues): += column sums of C (bv_gemm_bf16_colsum).
 
   a: [M,K] if a_kmajor else [K,M];  b: [N,K] if b_kmajor else [K,N].
   """
@@ -113,8 +113,10 @@ def layernorm_fwd(x, scale, bias, *, rows, D, row_stride=1, row_offset=0, want_b
 
 
 def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_bf16=None,
-                  dscale=None, dbias=None, dx_colsum=None, row_stride=1, row_offset=0):
-  """dx = dres + LN_bwd(dy); dscale/dbias (and dx_colsum += column sums of dx) accumulated in place."""
+                  dscale=None, dbias=None, dx_colsum=None, row_stride=1, row_offset=0, bias=None, y_out=None):
+  """dx = dres + LN_bwd(dy); dscale/dbias (and dx_colsum += column sums of dx) accumulated in place.
+  y_out (bf16 [rows, D], fp32 x only, needs the LayerNorm `bias`): also re-emits the forward's output
+  (bv_layernorm_bwd_y)."""
   if dy.dtype not in (BF16, F32):
     raise TypeError("layernorm_bwd.dy must be bf16 or fp32")
   if x.dtype == BF16:
@@ -132,6 +134,13 @@ def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_b
   _chk(x, F32, "layernorm_bwd.x")
   if dx is None:
     dx = torch.empty_like(x) if row_stride == 1 else torch.zeros_like(x)
+  if y_out is not None:
+    _chk(y_out, BF16, "layernorm_bwd.y_out"); _chk(bias, F32, "layernorm_bwd.bias")
+    assert row_stride == 1 and y_out.is_contiguous()
+    _lib.call("bv_layernorm_bwd_y", _p(dy), int(dy.dtype == F32), _p(x), _p(scale), _p(mean), _p(rstd),
+              _p(dres), _p(dx), _p(dx_bf16), _p(dscale), _p(dbias), _p(dx_colsum), rows, D, row_stride,
+              row_offset, _p(bias), _p(y_out), _stream())
+    return dx
   _lib.call("bv_layernorm_bwd", _p(dy), int(dy.dtype == F32), _p(x), _p(scale), _p(mean), _p(rstd),
             _p(dres), _p(dx), _p(dx_bf16), _p(dscale), _p(dbias), _p(dx_colsum), rows, D, row_stride,
             row_offset,

@@ -65,13 +65,17 @@ int bv_version(void);
 #define BV_EPI_GELU_BWD_EMIT 6 /* GELU_BWD, and C2(bf16) = gelu_tanh(aux): the activation is
                              recomputed by the backward instead of being kept (bit-identical
                              to what BV_EPI_GELU wrote)                                      */
+#define BV_EPI_GELU_GD 7  /* C(bf16) = gelu_tanh(h), C2(bf16) = gelu_tanh'(h), h = the bf16-rounded result
+                             (vit.py:75 and its derivative in ONE forward epilogue: the pre-activation
+                             is not stored; the backward multiplies by C2 with BV_EPI_MUL)        */
+#define BV_EPI_MUL 8      /* C(bf16) *= aux(bf16)[m,n]  (dH = dG o gelu'(h), gelu' kept by GELU_GD) */
 int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                  float alpha, int split_k /*0 = auto*/, void* stream);
 
 /* bv_gemm_bf16 with a fused column reduction: colsum[n] += sum_m C[m][n], taken from the fp32
- * results before the output rounding (fp32 atomics).  Supported with the GELU_BWD epilogues:
+ * results before the output rounding (fp32 atomics).  Supported with the GELU_BWD / MUL epilogues:
  * the column sums of dH are the gradient of the MlpBlock Dense_0 bias (vit.py:72), which
  * saves a separate pass over the [tokens, mlp_dim] tensor.  colsum = NULL: plain bv_gemm_bf16. */
 int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
@@ -148,6 +152,15 @@ int bv_layernorm_bwd(const void* dy, int dy_is_f32, const float* x, const float*
                      const float* mean, const float* rstd, const float* dres, float* dx,
                      void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows, int D,
                      long row_stride, long row_offset, void* stream);
+/* bv_layernorm_bwd that ALSO re-emits the forward's bf16 output y = LN(x) (y_bf16 [rows][D], needs the LayerNorm
+ * bias; row_stride must be 1): the "light" activation contexts of the micro-batched trainer do not keep the
+ * LayerNorm outputs (vit.py:92,103 feed them to the QKV / Dense_0 projections, whose weight gradients need them
+ * again), and this kernel reads x anyway - re-deriving y here costs 2 bytes per element instead of the 6 of a
+ * second bv_layernorm_fwd pass.  Same expression, same bits as bv_layernorm_fwd. */
+int bv_layernorm_bwd_y(const void* dy, int dy_is_f32, const float* x, const float* scale,
+                       const float* mean, const float* rstd, const float* dres, float* dx,
+                       void* dx_bf16, float* dscale, float* dbias, float* dx_colsum, int rows, int D,
+                       long row_stride, long row_offset, const float* bias, void* y_bf16, void* stream);
 /* The same on a bf16 RESIDUAL STREAM (trainer option config.residual_stream = "bfloat16": the activations
  * between the blocks, their gradients and the saved block inputs are bf16; statistics, scale / bias
  * gradients, dx_colsum and all arithmetic stay fp32).  x, dres and dx are bf16 here; there is no separate

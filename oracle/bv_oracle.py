@@ -404,16 +404,107 @@ def text_forward(params, text, *, num_classes, width=512, depth=12, mlp_dim=2048
   return x, out
 
 
-def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim,
+# -----------------------------------------------------------------------------
+# BERT text tower - models/proj/flaxformer/bert.py:33-64 on flaxformer's BertEncoder
+# -----------------------------------------------------------------------------
+# PARITY UNPINNED against the reference's own arithmetic: the encoder lives in the un-vendored, un-pinned
+# `flaxformer` package (flaxformer/architectures/bert/bert.py; big_vision/requirements.txt lists
+# `flaxformer` without a version).  This restates its published algorithm = the original BERT encoder
+# (Devlin et al. 2018, google-research/bert modeling.py): token + position + segment embeddings ->
+# LayerNorm(eps 1e-12) -> num_hidden_layers POST-LayerNorm blocks {self-attention (+bias, key mask from
+# input_mask) -> +residual -> LayerNorm -> Dense(intermediate) -> gelu (tanh approximation: flax nn.gelu
+# default, the original TF BERT's formula) -> Dense -> +residual -> LayerNorm}.  bert.py:45-56 fixes the
+# call: position_ids = arange(max_len), segment_ids = 0, input_mask = (text != 0).  What pins it here is
+# HuggingFace `BertModel(hidden_act="gelu_new")`, an independent implementation of the same published
+# network (tests/test_oracle.py, tests/golden/bert_hf_tiny.npz, generator oracle/make_golden_bert.py).
+BERT_CONFIGS = {   # flaxformer/architectures/bert/configs.py: BertBaseConfig / BertLargeConfig
+    "base": dict(hidden_size=768, intermediate_dim=3072, num_hidden_layers=12, num_attention_heads=12,
+                 vocab_size=30522, max_length=512, num_segments=2),
+    "large": dict(hidden_size=1024, intermediate_dim=4096, num_hidden_layers=24, num_attention_heads=16,
+                  vocab_size=30522, max_length=512, num_segments=2),
+}
+BERT_LN_EPS = 1e-12
+
+
+def bert_config(config):
+  """`config`: "base" / "large" (bert.py:46-49) or an explicit dict of the same fields (tests)."""
+  return dict(BERT_CONFIGS[config]) if isinstance(config, str) else dict(config)
+
+
+def bert_encoder(p, text, cfg):
+  """flaxformer BertEncoder.__call__(token_ids, position_ids, segment_ids, input_mask) as bert.py:50-57
+  calls it.  Masked logits get the large negative bias flax's attention uses (a fully masked QUERY row -
+  a padded position - attends uniformly; those rows never reach the CLS output)."""
+  n, L = text.shape
+  H = cfg["num_attention_heads"]
+  emb = p["embedder"]
+  x = (emb["embedders_token_ids"]["embedding"][text]
+       + emb["embedders_position_ids"]["embedding"][:L][None]
+       + emb["embedders_segment_ids"]["embedding"][0][None, None])
+  x = layernorm(x, p["layer_norm"], eps=BERT_LN_EPS)
+  valid = text != 0
+  mask = (valid[:, :, None] & valid[:, None, :])[:, None]          # make_attention_mask(input_mask, input_mask)
+  for i in range(cfg["num_hidden_layers"]):
+    b = p[f"encoder_block_{i}"]
+    a = mha(x, x, b["attention_block"]["attention_layer"], H, mask=mask)
+    x = layernorm(_stream(x + a), b["attention_block"]["layer_norm"], eps=BERT_LN_EPS)
+    m = dense(gelu_tanh(dense(x, b["mlp_block"]["mlp"]["wi"])), b["mlp_block"]["mlp"]["wo"])
+    x = layernorm(_stream(x + m), b["mlp_block"]["layer_norm"], eps=BERT_LN_EPS)
+  return x
+
+
+def bert_forward(params, text, *, config, num_classes=None, **_unused):
+  """models/proj/flaxformer/bert.py:40-64: encoder -> CLS token -> optional `head` Dense."""
+  cfg = bert_config(config)
+  out = {}
+  x = out["transformed"] = bert_encoder(params["BertEncoder_0"], text.long(), cfg)
+  x = out["pre_logits"] = x[:, 0]
+  if num_classes:
+    x = out["logits"] = dense(x, params["head"])
+  return x, out
+
+
+def init_bert(gen, *, config, num_classes=None, head_zeroinit=True, dtype=torch.float32, **_):
+  """Random init in the flaxformer tree layout (truncated-normal(0.02)-like scale; the reference always
+  loads a checkpoint, the init only has to be a valid point)."""
+  cfg = bert_config(config)
+  D, M, H = cfg["hidden_size"], cfg["intermediate_dim"], cfg["num_attention_heads"]
+  Dh = D // H
+  rn = lambda *shape: torch.randn(shape, generator=gen, dtype=dtype) * 0.02
+  ln = lambda: {"scale": torch.ones(D, dtype=dtype), "bias": torch.zeros(D, dtype=dtype)}
+  enc = {"embedder": {"embedders_token_ids": {"embedding": rn(cfg["vocab_size"], D)},
+                      "embedders_position_ids": {"embedding": rn(cfg["max_length"], D)},
+                      "embedders_segment_ids": {"embedding": rn(cfg["num_segments"], D)}},
+         "layer_norm": ln()}
+  for i in range(cfg["num_hidden_layers"]):
+    att = {k: {"kernel": rn(D, H, Dh), "bias": torch.zeros((H, Dh), dtype=dtype)} for k in ("query", "key", "value")}
+    att["out"] = {"kernel": rn(H, Dh, D), "bias": torch.zeros(D, dtype=dtype)}
+    enc[f"encoder_block_{i}"] = {
+        "attention_block": {"attention_layer": att, "layer_norm": ln()},
+        "mlp_block": {"mlp": {"wi": {"kernel": rn(D, M), "bias": torch.zeros(M, dtype=dtype)},
+                              "wo": {"kernel": rn(M, D), "bias": torch.zeros(D, dtype=dtype)}},
+                      "layer_norm": ln()}}
+  p = {"BertEncoder_0": enc}
+  if num_classes:
+    p["head"] = {"kernel": (torch.zeros((D, num_classes), dtype=dtype) if head_zeroinit
+                            else _lecun_normal(gen, (D, num_classes), D, dtype)),
+                 "bias": torch.zeros(num_classes, dtype=dtype)}
+  return p
+
+
+def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None,
                        **_unused):
   """models/proj/image_text/two_towers.py:39-90."""
   out = {}
   out_dims = (out_dim, out_dim) if isinstance(out_dim, int) else tuple(out_dim)
   zimg = ztxt = None
   if text is not None:
-    kw = {**decode_variant(text_cfg.get("variant")),
-          **{k: v for k, v in text_cfg.items() if k != "variant"}}
-    ztxt, o = text_forward(params["txt"], text, num_classes=out_dims[1], **kw)
+    if text_model == "proj.flaxformer.bert":            # two_towers.py:51-53: towers by module path
+      ztxt, o = bert_forward(params["txt"], text, num_classes=out_dims[1], **text_cfg)
+    else:
+      kw = {**decode_variant(text_cfg.get("variant")),
+            **{k: v for k, v in text_cfg.items() if k != "variant"}}
+      ztxt, o = text_forward(params["txt"], text, num_classes=out_dims[1], **kw)
     out.update({f"txt/{k}": v for k, v in o.items()})
     out["txt/norm"] = torch.linalg.norm(ztxt, dim=1, keepdim=True)
     out["txt/normalized"] = ztxt = ztxt / (out["txt/norm"] + 1e-8)
@@ -996,9 +1087,9 @@ def synthetic_batch(seed, n, res, seq_len, vocab_size=32_000, dtype=torch.float3
   return image.to(dtype), text.to(torch.int32)
 
 
-def siglip_step_loss(params, image, text, *, image_cfg, text_cfg, out_dim):
+def siglip_step_loss(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None):
   """siglip.py:287-308 loss_fn: model.apply -> global sigmoid loss."""
   zimg, ztxt, out = two_towers_forward(
-      params, image, text.long(), image_cfg=image_cfg, text_cfg=text_cfg, out_dim=out_dim)
+      params, image, text.long(), image_cfg=image_cfg, text_cfg=text_cfg, out_dim=out_dim, text_model=text_model)
   loss, logits = siglip_loss_global(zimg, ztxt, out["t"], out["b"])
   return loss, (zimg, ztxt, logits, out)

@@ -53,16 +53,26 @@ def test_lit_coco_config_under_both_names():
   assert a.lr == 1e-3 and a.wd == 1e-2 and a.grad_clip_norm == 1.0
 
 
-def test_reference_style_trainer_snippet(dry):
-  """What trainers/proj/image_text/siglip.py:180-323 does, with big_vision.* names only."""
+@pytest.mark.parametrize("txt", ["bert_base", "transformer_b"])
+def test_reference_style_trainer_snippet(dry, txt):
+  """What trainers/proj/image_text/siglip.py:180-323 does, with big_vision.* names only - with the config's
+  default BERT text tower (`text_model='proj.flaxformer.bert'`, siglip_lit_coco.py:78,84-87; cut to a
+  test-sized encoder) and with the in-repo text transformer."""
   import big_vision.optax as bv_optax
   import big_vision.sharding as bv_sharding
   import big_vision.utils as u
   from big_vision.trainers.proj.image_text import siglip as trainer
-  config = importlib.import_module("big_vision.configs.proj.image_text.lit_coco").get_config("batch_size=4,res=32,token_len=8")
+  config = importlib.import_module("big_vision.configs.proj.image_text.lit_coco").get_config(
+      f"batch_size=4,res=32,token_len=8,txt={txt}")
   config.model.image = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok",
                             head_zeroinit=False)
-  config.model.text = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=50)
+  if txt == "bert_base":
+    assert config.model.text_model == "proj.flaxformer.bert" and config.model.text.config == "base"
+    assert config.optax_name == "scale_by_adam"
+    config.model.text = dict(config=dict(hidden_size=128, intermediate_dim=256, num_hidden_layers=2, num_attention_heads=2,
+                                         vocab_size=50, max_length=16, num_segments=2), head_zeroinit=False)
+  else:
+    config.model.text = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=50)
   config.model.out_dim = (None, 128)
   model_mod = importlib.import_module(f"big_vision.models.{config.model_name}")      # siglip.py:190
   model = model_mod.Model(**config.model)
@@ -80,7 +90,10 @@ def test_reference_style_trainer_snippet(dry):
   dry.clear()
   state, meas = update_fn(state, None, {"image": image, "labels": text})
   assert {"training_loss", "l2_grads", "l2_params", "l2_updates"} <= set(meas)
-  assert dry["bv_attn_fwd"] == 4 and dry["bv_attn_bwd"] == 2       # image tower frozen: text-only backward
+  if txt == "bert_base":   # BERT masks the padded keys (input_mask = text != 0): the *_masked entry points; image tower frozen
+    assert (dry["bv_attn_fwd"], dry["bv_attn_fwd_masked"], dry["bv_attn_bwd"], dry["bv_attn_bwd_masked"]) == (2, 2, 0, 2)
+  else:
+    assert dry["bv_attn_fwd"] == 4 and dry["bv_attn_bwd"] == 2       # image tower frozen: text-only backward
   assert len(sched_fns) >= 1
 
 

@@ -106,6 +106,36 @@ def test_nt_epilogues(dev, fast):
     o3 = ops.gemm(x, w, out_dtype=BF16, epilogue=epi, aux=hh, colsum=cs, **extra, **kw)
     assert torch.equal(o3, out), "colsum changed the GEMM result"
     close(cs, 1.0 + ref.sum(0), 1e-3, 1e-3 * ref.abs().sum(0).max().item(), "fused colsum")
+  # GELU_GD (forward, full contexts): C = gelu(pre), C2 = gelu'(pre) from the fp32 pre-activation; MUL
+  # (backward): C = (x w^T) o aux with the fused column sums.  The pair must reproduce GELU_BWD's dX when
+  # fed the derivative GELU_GD emitted.
+  g4 = torch.empty((M, N), device=dev, dtype=BF16)
+  d4 = torch.empty((M, N), device=dev, dtype=BF16)
+  ret = ops.gemm(x, w, bias=b, out=g4, epilogue=ops.EPI_GELU_GD, out2=d4, **kw)
+  assert ret is g4
+  pf = pre.detach().clone().requires_grad_(True)
+  torch.nn.functional.gelu(pf, approximate="tanh").sum().backward()
+  close(g4, torch.nn.functional.gelu(pre, approximate="tanh"), 1e-2, 1e-2, "gelu_gd value")
+  close(d4, pf.grad, 1e-2, 1e-2, "gelu_gd derivative")
+  # one definition of the activation for every context kind: GELU_GD's g has the bits of GELU's g, and
+  # MUL fed GELU_GD's derivative reproduces GELU_BWD / GELU_BWD_EMIT fed the stored h, bit for bit
+  assert torch.equal(g4, g), "GELU_GD and GELU disagree on gelu(h)"
+  o_mul = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_MUL, aux=d4, **kw)
+  o_bwd = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=h, **kw)
+  g5 = torch.empty((M, N), device=dev, dtype=BF16)
+  o_emit = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g5, **kw)
+  assert torch.equal(o_mul, o_bwd) and torch.equal(o_mul, o_emit) and torch.equal(g5, g)
+  dd = hf.grad.to(BF16)
+  cs = torch.ones((N,), device=dev, dtype=F32)
+  o5 = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_MUL, aux=dd, colsum=cs, **kw)
+  ref5 = (x.float() @ w.float().T) * dd.float()
+  close(o5, ref5, 1e-2, 2e-2, "mul")
+  close(cs, 1.0 + ref5.sum(0), 1e-3, 1e-3 * ref5.abs().sum(0).max().item(), "mul: fused colsum")
+  assert torch.equal(o5, ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_MUL, aux=dd, **kw))
+  # the 256x256 kernel and the general kernel evaluate the same operation sequence: same bits
+  gg, dg = torch.empty_like(g4), torch.empty_like(d4)
+  _general(lambda: ops.gemm(x, w, bias=b, out=gg, epilogue=ops.EPI_GELU_GD, out2=dg, **kw))
+  close(gg, g4, 1e-2, 1e-2, "gelu_gd vs general kernel"); close(dg, d4, 1e-2, 1e-2, "gelu_gd' vs general kernel")
   y = ops.gemm(x, w, out_dtype=BF16, alpha=0.5, **kw)
   close(y, 0.5 * (x.float() @ w.float().T), 1e-2, 1e-2, "alpha")
 

@@ -80,10 +80,15 @@ def test_microbatch_schemes_recompute_exactly_what_was_not_kept(dry, keep, light
   assert calls["bv_attn_bwd"] == BLOCKS * 4
   assert calls["bv_siglip_loss"] == 1 and calls["bv_adam_step"] == 1
   assert fn.state_cache["keep_n"] == (4 if keep == "all" else keep)
-  # light contexts: LayerNorm outputs are re-derived in the backward (2 per block and kept micro-batch
-  # beyond the forward's own), and the fc2 dX GEMM re-emits gelu(h)
+  # light contexts (fp32 stream): the LayerNorm outputs are re-emitted by the LayerNorm BACKWARD kernel
+  # (bv_layernorm_bwd_y, 2 per block and kept micro-batch) - no extra forward normalisation passes - and the
+  # fc2 dX GEMM re-emits gelu(h)
   if light:
-    assert calls["bv_layernorm_fwd"] > (2 * BLOCKS + 4) * fwd_passes
+    kept = fn.state_cache["keep_n"]
+    assert calls["bv_layernorm_bwd_y"] >= 2 * BLOCKS * kept
+    assert calls["bv_layernorm_fwd"] <= (2 * BLOCKS + 6) * fwd_passes
+  else:
+    assert calls["bv_layernorm_bwd_y"] == 0
 
 
 def test_auto_switches_to_light_contexts_when_full_ones_do_not_fit(dry):
@@ -268,14 +273,19 @@ def test_bf16_residual_stream_routes_the_encoder_through_the_bf16x_kernels(dry):
 
 
 def test_context_kinds_full_then_gelu_free_then_light(dry):
-  """microbatch_light: "g" keeps the LayerNorm outputs and drops gelu(h) (the fc2 dX GEMM re-emits it, no
-  re-normalisation in the backward); "light" drops both."""
+  """microbatch_light: "g" keeps the LayerNorm outputs and drops gelu(h) (the fc2 dX GEMM re-emits it);
+  "light" drops both - on the fp32 stream the LayerNorm outputs then come out of the LayerNorm BACKWARD kernel
+  (bv_layernorm_bwd_y), on the bf16 stream out of a re-normalisation pass."""
   calls, _ = dry
   for kind, renorm in (("g", False), ("light", True), (False, False)):
     fn, state, batch = _setup(_cfg(microbatch=2, microbatch_keep="all", microbatch_light=kind))
     calls.clear()
     fn(state, None, batch)
     assert fn.state_cache["light"] == kind
-    ln_fwd = calls["bv_layernorm_fwd"]
     base = (2 * BLOCKS + 3) * 4                       # 4 micro-batches of forward LayerNorms
-    assert ln_fwd == base + (2 * BLOCKS * 4 if renorm else 0), (kind, ln_fwd)
+    assert calls["bv_layernorm_fwd"] == base, (kind, calls["bv_layernorm_fwd"])
+    assert calls["bv_layernorm_bwd_y"] == (2 * BLOCKS * 4 if renorm else 0), (kind, calls["bv_layernorm_bwd_y"])
+  fn, state, batch = _setup(_cfg(microbatch=2, microbatch_keep="all", microbatch_light="light", residual_stream="bfloat16"))
+  calls.clear()
+  fn(state, None, batch)
+  assert calls["bv_layernorm_fwd_bf16x"] == (2 * BLOCKS + 2) * 4 + 2 * BLOCKS * 4 and calls["bv_layernorm_bwd_y"] == 0

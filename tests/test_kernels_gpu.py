@@ -160,6 +160,13 @@ def test_layernorm(dev, rows, D):
   assert_close(dx_bf, xr.grad + dres.double(), 1e-2, 1e-2, "ln dx bf16")
   assert_close(dscale, sr.grad, 1e-4, 1e-3, "ln dscale")
   assert_close(dbias, br.grad, 1e-4, 1e-3, "ln dbias")
+  # bv_layernorm_bwd_y: the same backward that also re-emits the forward's bf16 output (light contexts):
+  # y bit-identical to bv_layernorm_fwd's, every other output bit-identical to the plain backward
+  y_re = torch.zeros((rows, D), device=dev, dtype=BF16)
+  dx_bf2 = torch.empty((rows, D), device=dev, dtype=BF16)
+  dx_y = ops.layernorm_bwd(dy, x, scale, mean, rstd, rows=rows, D=D, dres=dres, dx_bf16=dx_bf2, bias=bias, y_out=y_re)
+  assert torch.equal(y_re, y_bf), "re-emitted LayerNorm output differs from the forward's"
+  assert torch.equal(dx_y, dx) and torch.equal(dx_bf2, dx_bf)
   # bf16 upstream gradient variant
   dyb = dy.to(BF16)
   dx2 = ops.layernorm_bwd(dyb, x, scale, mean, rstd, rows=rows, D=D)

@@ -46,7 +46,7 @@ def _cfg(total_steps=10, **kw):
 
 def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, config=None,
               tol_z=2e-2, tol_logit=0.25, frozen=(), floor=False, dirty_step=False, case=None, rel_max=None,
-              exceptions=None):
+              exceptions=None, text_model=None, pad_id=None):
   """frozen: leaf-name prefixes config.schedule freezes (LiT).  floor: also measure the bf16-operand
   noise floor of the oracle for this case (tests/_parity.py; reported, not a bound).  exceptions:
   {leaf name: (rel_max, cos_min)} for tensors held to their own stated bound.
@@ -60,10 +60,17 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
   from big_vision_amd import utils as u
 
   case = case or f"siglip {image_cfg.get('variant', image_cfg.get('width'))} n={n} res={res} seq={seq}"
-  model = two_towers.Model(image=image_cfg, text={**text_cfg, "vocab_size": vocab},
-                           out_dim=(None, E), temperature_init=10.0, bias_init=bias_init)
+  # text_model (two_towers.py:51-53): another text tower by module path, e.g. "proj.flaxformer.bert" whose
+  # config carries its own vocabulary; pad_id: the sticky-EOS padding of the synthetic batch (id 1) is
+  # re-labelled (BERT's input_mask is text != 0)
+  tcfg = dict(text_cfg) if text_model else {**text_cfg, "vocab_size": vocab}
+  mkw = dict(text_model=text_model) if text_model else {}
+  model = two_towers.Model(image=image_cfg, text=tcfg, out_dim=(None, E), temperature_init=10.0, bias_init=bias_init,
+                           **mkw)
   config = config or _cfg()
   image, text = O.synthetic_batch(1, n, res, seq, vocab)
+  if pad_id is not None:
+    text = torch.where(text == 1, torch.full_like(text, pad_id), text)
   image_d, text_d = image.to(dev), text.to(dev)
   train_state, sched_fns = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape),
                                                    rng=0, total_steps=config.total_steps)
@@ -82,7 +89,7 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
 
   params64 = O.recover_tree([(k, v.detach().cpu().double().clone().requires_grad_(not is_frozen(k)))
                              for k, v in u.tree_flatten_with_names(train_state["params"])[0]])
-  okw = dict(image_cfg=image_cfg, text_cfg={**text_cfg, "vocab_size": vocab}, out_dim=(None, E))
+  okw = dict(image_cfg=image_cfg, text_cfg=tcfg, out_dim=(None, E), **mkw)
   loss_ref, (zi_ref, zt_ref, logits_ref, _) = O.siglip_step_loss(params64, image.double(), text, **okw)
   p_before = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(train_state["params"])[0]}
 
