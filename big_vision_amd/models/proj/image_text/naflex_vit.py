@@ -74,18 +74,22 @@ class NaflexExec:
     self._mask_checked = False
 
   def _lengths(self, ptype):
-    """Valid tokens per example; ptype == 1 must be a prefix (checked once: one host sync)."""
+    """Valid tokens per example (ptype == 1, naflex_vit.py:84-94) and, when they are not a prefix of the
+    sequence, the per-example permutation that moves them to the front.  The attention kernels mask a SUFFIX
+    of the keys; the tower is equivariant to a permutation of an example's tokens (the position embedding is
+    gathered per token from its own (yabs, xabs), masked MAP / gap / max pooling are permutation invariant),
+    so a mask with holes is served by reordering the example's tokens - outputs per token are put back in
+    the caller's order.  The prefix test is one host sync per call of a NEW mask layout."""
     valid = ptype == 1
     lens = valid.sum(dim=1).to(torch.int32).contiguous()
-    if not self._mask_checked:
-      N = ptype.shape[1]
-      prefix = torch.arange(N, device=ptype.device)[None, :] < lens[:, None]
-      if not torch.equal(valid, prefix):
-        raise NotImplementedError("NaFlex mask must mark a prefix of the sequence (padding at the end)")
-      if int(lens.min()) < 1:
-        raise ValueError("an example without any real patch")
-      self._mask_checked = True
-    return lens
+    N = ptype.shape[1]
+    prefix = torch.arange(N, device=ptype.device)[None, :] < lens[:, None]
+    if int(lens.min()) < 1:
+      raise ValueError("an example without any real patch")
+    if torch.equal(valid, prefix):
+      return lens, None
+    perm = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)   # valid tokens first, original order kept
+    return lens, perm
 
   def fwd(self, image, save=False, collect=False):
     m = self.m
@@ -95,7 +99,12 @@ class NaflexExec:
     assert pd == self.patch_dim, (pd, self.patch_dim)
     T = n * N
     out = {}
-    lens = self._lengths(ptype)
+    lens, perm = self._lengths(ptype)
+    if perm is not None:   # holes in the mask: reorder every example's tokens (input-side gather, like patchify)
+      if m.pool_type == "none":
+        raise NotImplementedError("pool_type='none' with a non-prefix NaFlex mask")
+      patches = torch.gather(patches, 1, perm[:, :, None].expand(-1, -1, pd))
+      yabs, xabs = torch.gather(yabs, 1, perm), torch.gather(xabs, 1, perm)
     x_in = patches.to(F32).contiguous().view(T, pd)
     ctx = dict(n=n, N=N, lens=lens)
     if self.ln_pre is not None:
@@ -159,6 +168,16 @@ class NaflexExec:
       ctx["head_in"] = zb
     if m.pool_type == "none":
       x = x.view(n, N, -1)
+    if perm is not None and collect:   # per-token diagnostics back in the caller's token order
+      inv = torch.argsort(perm, dim=1)
+
+      def unperm(v):
+        if isinstance(v, dict):
+          return {k: unperm(t) for k, t in v.items()}
+        if torch.is_tensor(v) and v.dim() == 3 and v.shape[:2] == (n, N):
+          return torch.gather(v, 1, inv[:, :, None].expand(-1, -1, v.shape[2]))
+        return v
+      out = unperm(out)
     return x, out, (ctx if save else None)
 
   def bwd(self, ctx, dx, on_block=None):

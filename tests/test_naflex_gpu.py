@@ -31,7 +31,7 @@ def _batch(seed, grids=GRIDS, N=36):
   return patches, ptype, yabs, xabs
 
 
-def _case(dev, cfg, case):
+def _case(dev, cfg, case, shuffle=False):
   import bv_oracle as O
   import _parity
   from big_vision_amd import utils as u
@@ -39,6 +39,12 @@ def _case(dev, cfg, case):
   from big_vision_amd.params import ParamStore
   model = naflex_vit.Model(None, **cfg)
   image = _batch(3)
+  if shuffle:   # the same examples with their tokens (valid AND padding) in a random order: a mask with holes
+    gp = torch.Generator().manual_seed(5)
+    perm = torch.stack([torch.randperm(image[0].shape[1], generator=gp) for _ in range(image[0].shape[0])])
+    image = (torch.gather(image[0], 1, perm[:, :, None].expand(-1, -1, image[0].shape[2])),) + \
+        tuple(torch.gather(t, 1, perm) for t in image[1:])
+    assert not torch.equal(image[1], _batch(3)[1])
   n = image[0].shape[0]
   pd = image[0].shape[-1]
   store = ParamStore(model.entries("", pd), dev)
@@ -90,16 +96,28 @@ def test_naflex_gap_patchln_head(dev):
         "NaFlex tiny gap + patchln + pre_logits")
 
 
-def test_naflex_mask_must_be_a_prefix(dev):
+def test_naflex_mask_with_holes(dev):
+  """naflex_vit.py:84-113 builds a general [n, q, k] mask from ptype == 1; padding need not sit at the end.
+  The kernels mask a key SUFFIX, the tower is equivariant to reordering an example's tokens, so the executor
+  moves the valid tokens to the front: same pooled output and gradients as the oracle on the shuffled input,
+  per-token diagnostics returned in the caller's order."""
+  _case(dev, dict(width=128, depth=2, mlp_dim=256, num_heads=2, pool_type="map", nposemb=8, posemb="learn_2d(16)"),
+        "NaFlex tiny MAP, shuffled tokens (mask with holes)", shuffle=True)
+  import bv_oracle as O
+  from big_vision_amd import utils as u
   from big_vision_amd.models.proj.image_text import naflex_vit
-  from big_vision_amd.params import ParamStore
-  model = naflex_vit.Model(None, width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="gap", nposemb=8)
+  cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="gap", nposemb=8, posemb="learn_2d(16)")
+  model = naflex_vit.Model(None, **cfg)
   patches, ptype, yabs, xabs = _batch(1)
-  store = ParamStore(model.entries("", patches.shape[-1]), dev)
-  store.init_random(0); store.refresh_shadow()
   ptype[0, 0] = 0          # a hole at the front
-  with pytest.raises(NotImplementedError, match="prefix"):
-    model.executor(store, "", patches.shape[-1]).fwd(tuple(t.to(dev) for t in (patches, ptype, yabs, xabs)))
+  variables = model.init(0, tuple(t.to(dev) for t in (patches, ptype, yabs, xabs)))
+  z, out = model.apply(variables, tuple(t.to(dev) for t in (patches, ptype, yabs, xabs)))
+  p64 = O.recover_tree([(k, v.detach().cpu().double()) for k, v in u.tree_flatten_with_names(variables["params"])[0]])
+  z_ref, out_ref = O.naflex_vit_forward(p64, (patches.double(), ptype, yabs, xabs), **cfg)
+  assert (z.cpu().double() - z_ref).abs().max().item() <= 2e-2 * max(1.0, z_ref.abs().max().item())
+  valid = (ptype == 1)[..., None]
+  err = ((out["encoded"].cpu().double() - out_ref["encoded"]).abs() * valid).max().item()
+  assert err <= 3e-2 * max(1.0, out_ref["encoded"].abs().max().item()), err     # token order restored
 
 
 @pytest.mark.parametrize("stream", ["float32", "bfloat16"])

@@ -5,6 +5,7 @@
       rank's share of the step (its 1024 pairs, micro-batches of 256) on ONE GPU    (configs[3])
   c5  LiT: frozen ViT-B/16 (cls token) + trainable text-B at 16 tokens, config batch 512 on one
       GPU (text-only backward, no image-tower gradients / optimizer state)          (configs[4])
+  c5b the same with the BERT-base text tower the reference config names (text_model='proj.flaxformer.bert')
 
 One JSON line per workload (same fields as bench.py where they apply; `value` is per-GPU here because
 these lines are measured on one device).  GPU only; synthetic data resident in HBM; K timed steps
@@ -24,14 +25,33 @@ import bench  # noqa: E402
 
 
 def timed(fn, steps, warmup):
+  """Seconds per step, and the `roofline` object of bench.py for the same timed region (the k-major
+  256x256 GEMM family bracketed by HIP events on the launch stream)."""
+  from big_vision_amd import _lib
   for _ in range(warmup):
     fn()
+  obs = bench.GemmObserver()
+  _lib.observer = obs
   torch.cuda.synchronize()
+  obs.active = True
   t0 = time.perf_counter()
   for _ in range(steps):
     fn()
   torch.cuda.synchronize()
-  return (time.perf_counter() - t0) / steps
+  dt = (time.perf_counter() - t0) / steps
+  obs.active = False
+  _lib.observer = None
+  launches, ms, flops, nbytes = obs.summary()
+  ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+  ROOF.clear()
+  ROOF.update({"bound": "mfma", "kernel": bench.DOMINANT_KERNEL, "achieved": ach, "peak": bench.BF16_DENSE_PEAK_TFLOPS,
+               "unit": "TFLOP/s", "frac": ach / bench.BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+               "algorithmic_bytes_per_launch": nbytes / max(1, launches), "launches": launches,
+               "avg_launch_us": 1e3 * ms / max(1, launches), "share_of_step_time": ms / (1e3 * dt * steps)})
+  return dt
+
+
+ROOF = {}   # roofline object of the last timed() call
 
 
 STREAM = "float32"   # --residual-stream
@@ -61,11 +81,12 @@ def c2(dev, steps):
           "config": {"workload": "ViT-B/16@224 MAP tower, fwd+bwd, no optimizer", "batch": n, "residual_stream": STREAM}}
 
 
-def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label=""):
+def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label="", text_model=None):
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
   model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, emb), temperature_init=10.0,
-                           bias_init=-10.0 if schedule is None else -2.71)
+                           bias_init=-10.0 if schedule is None else -2.71,
+                           **({"text_model": text_model} if text_model else {}))
   config = bench.make_config(20_000)
   config.microbatch = micro
   config.residual_stream = STREAM
@@ -106,9 +127,20 @@ def c5(dev, steps):
   return r
 
 
+def c5b(dev, steps):
+  """The literal siglip_lit_coco.py: text_model='proj.flaxformer.bert', config 'base' (:78,84-87)."""
+  sched = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=150))]
+  r = _siglip(dev, steps, dict(variant="B/16", pool_type="tok", head_zeroinit=False), dict(config="base", head_zeroinit=False),
+              768, n=512, res=224, seq=16, micro=2048, schedule=sched, text_model="proj.flaxformer.bert",
+              label="LiT (siglip_lit_coco.py as written): frozen ViT-B/16 cls-token tower + trainable BERT-base text tower, "
+                    "16 tokens, batch 512, text-only backward")
+  r["metric"] = "image-text pairs/sec, LiT locked-image step with the BERT-base text tower, batch 512 (BASELINE configs[4])"
+  return r
+
+
 def main():
   ap = argparse.ArgumentParser()
-  ap.add_argument("workloads", nargs="*", default=["c2", "c4", "c5"])
+  ap.add_argument("workloads", nargs="*", default=["c2", "c4", "c5", "c5b"])
   ap.add_argument("--steps", type=int, default=5)
   ap.add_argument("--residual-stream", default="float32", choices=("float32", "bfloat16"))
   a = ap.parse_args()
@@ -117,8 +149,8 @@ def main():
   dev = torch.device("cuda", 0)
   torch.cuda.set_device(dev)
   for w in a.workloads:
-    r = {"c2": c2, "c4": c4, "c5": c5}[w](dev, a.steps)
-    r.update(n_gpus=1, steps=a.steps, dtype="bf16", data="synthetic", higher_is_better=True)
+    r = {"c2": c2, "c4": c4, "c5": c5, "c5b": c5b}[w](dev, a.steps)
+    r.update(n_gpus=1, steps=a.steps, dtype="bf16", data="synthetic", higher_is_better=True, roofline=dict(ROOF))
     print(json.dumps(r), flush=True)
     torch.cuda.empty_cache()
 

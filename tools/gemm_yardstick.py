@@ -100,6 +100,27 @@ def main():
         print("#  ", r)
     except Exception as e:   # noqa: BLE001
       print("# (no tunable results:", e, ")")
+  # ---- weight-gradient GEMMs (reduction over the tokens): dW[in, out] = X^T dY, ours = split-K slabs + reduce
+  # into an fp32 gradient buffer (accumulating), vendor = torch.matmul(x.t(), dy) -> bf16 [in, out] (less work:
+  # no fp32 output, no accumulation), default heuristic.
+  print(f"# dW = X^T dY   {'T':>7} {'in':>5} {'out':>5} | {'ours (fp32 +=)':>14} | {'hipblaslt (bf16 out)':>20} | ours/vendor")
+  for (T, din, dout) in [(401408, 768, 2304), (401408, 768, 768), (401408, 768, 3072), (401408, 3072, 768),
+                         (131072, 768, 2304), (131072, 768, 3072), (131072, 3072, 768)]:
+    if "--quick" in sys.argv and T > 131072:
+      continue
+    x = (torch.rand((T, din), device=dev, generator=g) * 2 - 1).to(BF16)
+    dy = ((torch.rand((T, dout), device=dev, generator=g) * 2 - 1) * 0.05).to(BF16)
+    grad = torch.zeros((din, dout), device=dev, dtype=torch.float32)
+    fl = 2.0 * T * din * dout
+    tf = lambda ms: fl / ms / 1e9
+    ours = tf(timeit(lambda: ops.gemm(x, dy, a_kmajor=False, b_kmajor=False, out=grad, epilogue=ops.EPI_ATOMIC), 4))
+    xt = x.t()
+    o16 = torch.empty((din, dout), device=dev, dtype=BF16)
+    if TUNE:
+      torch.cuda.tunable.enable(False)
+    lt = tf(timeit(lambda: torch.matmul(xt, dy, out=o16), 4))
+    print(f"                {T:>7} {din:>5} {dout:>5} | {ours:14.0f} | {lt:20.0f} | {ours / lt:6.2f}", flush=True)
+    del x, dy
   w = sum(2.0 * m * n * k for m, n, k, _, _ in rows)
   ours_t = sum(2.0 * m * n * k / o for m, n, k, o, _ in rows)
   ref_t = sum(2.0 * m * n * k / r for m, n, k, _, r in rows)
