@@ -660,7 +660,184 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dkv_kernel(const bf16*
   }
 }
 
+// ----------------------------------------- backward: dK, dV with 32-key blocks --
+// Same mathematics and LDS tiles as attn3_bwd_dkv_kernel; a wave owns TWO key fragments (32 keys, K / V rows in
+// registers) and sweeps the query fragments in pairs, so every LDS operand fragment (Q / dO rows, Q^T / dO^T
+// transposed pairs) feeds two MFMAs instead of one: half the LDS bytes per (query, key) block - the resource
+// the 16-key kernel spends 40 % of its time on.  ~200 VGPRs: two waves per SIMD, NW waves per
+// workgroup walk the ceil(QN / 2) key blocks.
+template <int QN, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* __restrict__ qkv,
+                                                                   const bf16* __restrict__ d_o,
+                                                                   const float* __restrict__ lse,
+                                                                   const float* __restrict__ delta,
+                                                                   bf16* __restrict__ dqkv,
+                                                                   float* __restrict__ dbias,
+                                                                   const int* __restrict__ kv_len, int L,
+                                                                   int H, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Gt = smem + QN * 16 * 128;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * QN * 16 * 128);
+  float* del_s = lse_s + QN * 16;
+  float* red = del_s + QN * 16;   // [NW waves][2][64] column sums of dK / dV
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i = blockIdx.x / H, h = blockIdx.x % H;
+  const int Lk = kv_len ? min(kv_len[i], L) : L;
+  const long ld = 3L * H * DH, ldo = (long)H * DH;
+  const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
+  const bf16* kb_ = qb_ + (long)H * DH;
+  const bf16* vb_ = qb_ + 2L * H * DH;
+  const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+  constexpr int NB = (QN + 1) / 2;   // key blocks of 32
+  int kb = wave;
+  bf16x8 k0[2], k1[2], v0[2], v1[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int kr = (2 * kb + e) * 16 + lr;
+    k0[e] = gfrag(kb_, ld, kr, Lk, lg * 8); k1[e] = gfrag(kb_, ld, kr, Lk, 32 + lg * 8);
+    v0[e] = gfrag(vb_, ld, kr, Lk, lg * 8); v1[e] = gfrag(vb_, ld, kr, Lk, 32 + lg * 8);
+  }
+  t64_stage2<QN * 16, NW * 64>(Qt, qb_, ld, Gt, dob_, ldo, L, tid);
+  for (int idx = tid; idx < QN * 16; idx += NW * 64) {
+    lse_s[idx] = idx < L ? lse[((long)i * H + h) * L + idx] * LOG2E : INFINITY;   // rows >= L: P = exp2(-inf) = 0
+    del_s[idx] = idx < L ? delta[((long)i * H + h) * L + idx] : 0.f;
+  }
+  if (dbias)
+    for (int idx = tid; idx < NW * 128; idx += NW * 64) red[idx] = 0.f;
+  __syncthreads();
+  const float c = scale * LOG2E;
+
+  // P and dS of query fragment f against this wave's two key fragments: p[e][r] = P[q = 4lg+r][key = lr of fragment e]
+  auto pds = [&](int f, f32x4 (&p)[2], f32x4 (&ds)[2]) {
+    const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
+    const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
+    const float4 l4 = *reinterpret_cast<const float4*>(lse_s + f * 16 + lg * 4);
+    const float4 d4 = *reinterpret_cast<const float4*>(del_s + f * 16 + lg * 4);
+    const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      sv = mfma16(q0, k0[e], sv);
+      sv = mfma16(q1, k1[e], sv);
+      dp = mfma16(g0, v0[e], dp);
+      dp = mfma16(g1, v1[e], dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[e][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], c, -lv[r]));
+        ds[e][r] = p[e][r] * (dp[r] - dl[r]);
+      }
+    }
+  };
+
+  for (; kb < NB; kb += NW) {
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dk[e][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[e][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 1
+    for (int ip = 0; ip < QN / 2; ++ip) {
+      f32x4 pa[2], dsa[2], pb[2], dsb[2];
+      pds(2 * ip, pa, dsa);
+      __builtin_amdgcn_sched_barrier(0);   // one query fragment's operand reads at a time (register pressure)
+      pds(2 * ip + 1, pb, dsb);
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        pf[e] = pack8(pa[e], pb[e]);
+        dsf[e] = pack8(dsa[e], dsb[e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 gt = t64_trpair(Gt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
+        const bf16x8 qt = t64_trpair(Qt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          dv[e][d] = mfma16(gt, pf[e], dv[e][d]);    // D[d = 4lg+r][key = lr]
+          dk[e][d] = mfma16(qt, dsf[e], dk[e][d]);
+        }
+      }
+    }
+    if constexpr (QN & 1) {
+      f32x4 pp[2], ds[2];
+      pds(QN - 1, pp, ds);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const s16x4 gt = t64_tr(Gt, (QN - 1) * 16 + 4 * lg, d, lr), qt = t64_tr(Qt, (QN - 1) * 16 + 4 * lg, d, lr);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          dv[e][d] = mfma16k16(gt, pack4(pp[e]), dv[e][d]);
+          dk[e][d] = mfma16k16(qt, pack4(ds[e]), dk[e][d]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      mfma_drain(dk[e][0], dk[e][1], dk[e][2], dk[e][3]);
+      mfma_drain(dv[e][0], dv[e][1], dv[e][2], dv[e][3]);
+    }
+    // the wave's NEXT key block goes straight into the registers of the finished one
+    const int kcur = kb;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kn = (2 * (kb + NW) + e) * 16 + lr;
+      k0[e] = gfrag(kb_, ld, kn, Lk, lg * 8); k1[e] = gfrag(kb_, ld, kn, Lk, 32 + lg * 8);
+      v0[e] = gfrag(vb_, ld, kn, Lk, lg * 8); v1[e] = gfrag(vb_, ld, kn, Lk, 32 + lg * 8);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int krow = (2 * kcur + e) * 16 + lr;
+      // key rows >= Lk (masked or padded): k = v = 0 there, so S = 0 and P = exp2(-lse) != 0 - their columns are
+      // garbage and are replaced by zeros (rows < L must still be written: the dX GEMM reads every row of dqkv)
+      const bool live = krow < Lk;
+      if (krow < L) {
+        bf16* rowk = dqkv + ((long)i * L + krow) * ld + (long)H * DH + h * DH;
+        bf16* rowv = rowk + (long)H * DH;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          uint2 a, b;
+          a.x = live ? pack_bf2(dk[e][d][0] * scale, dk[e][d][1] * scale) : 0u;
+          a.y = live ? pack_bf2(dk[e][d][2] * scale, dk[e][d][3] * scale) : 0u;
+          *reinterpret_cast<uint2*>(rowk + d * 16 + lg * 4) = a;
+          b.x = live ? pack_bf2(dv[e][d][0], dv[e][d][1]) : 0u;
+          b.y = live ? pack_bf2(dv[e][d][2], dv[e][d][3]) : 0u;
+          *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
+        }
+      }
+      if (dbias) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float tk = rowsum16(live ? dk[e][d][r] : 0.f), tv = rowsum16(live ? dv[e][d][r] : 0.f);
+            if (lr == 0) {
+              red[wave * 128 + d * 16 + lg * 4 + r] += tk * scale;
+              red[wave * 128 + 64 + d * 16 + lg * 4 + r] += tv;
+            }
+          }
+      }
+    }
+  }
+  if (dbias) {   // dbias[i][1][h][:] (key) and dbias[i][2][h][:] (value)
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, d = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * 128 + tid];
+      dbias[((long)i * 3 * H + (long)(1 + which) * H + h) * DH + d] = t;
+    }
+  }
+}
+
 int g_a3_one_sweep = 1;   // 0: always the two-sweep dQ kernel (A/B, bv_attn_tune bit 16)
+int g_a4_dkv = 0;          // 32-key-block dK/dV kernel: 0 off, 1 = 4 waves x 2 workgroups per CU, 2 = 7 waves x 1 (bv_attn_tune bits 32 / 64)
 
 template <typename K>
 void set_lds(K kernel, size_t bytes) {
@@ -707,6 +884,20 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
   }
   int rc = bv_check_launch("bv_attn_bwd(dq)");
   if (rc) return rc;
+  if (g_a4_dkv && KF >= 13) {   // 32-key blocks (A/B: bv_attn_tune bits 32 = 4 waves x 2 workgroups, 64 = 7 waves x 1)
+    if (g_a4_dkv == 2) {
+      const size_t sh = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)7 * 128 * 4;
+      set_lds(attn4_bwd_dkv_kernel<KF, 7>, sh);
+      hipLaunchKernelGGL((attn4_bwd_dkv_kernel<KF, 7>), dim3(n * H), dim3(7 * 64), sh, s, (const bf16*)qkv,
+                         (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+    } else {
+      const size_t sh = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)4 * 128 * 4;
+      set_lds(attn4_bwd_dkv_kernel<KF, 4>, sh);
+      hipLaunchKernelGGL((attn4_bwd_dkv_kernel<KF, 4>), dim3(n * H), dim3(4 * 64), sh, s, (const bf16*)qkv,
+                         (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len, L, H, 0.125f);
+    }
+    return bv_check_launch("bv_attn_bwd(dkv32)");
+  }
   const size_t sh2 = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)NW2 * 128 * 4;
   set_lds(attn3_bwd_dkv_kernel<KF, NW2, WPS2>, sh2);
   hipLaunchKernelGGL((attn3_bwd_dkv_kernel<KF, NW2, WPS2>), dim3(n * H), dim3(NW2 * 64), sh2, s, (const bf16*)qkv,
@@ -722,8 +913,8 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
 static int g_a3cfg = 0;
 // A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel
 extern "C" int bv_attn_tune(int cfg) {
-  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16);
-  if (cfg >= 0) { g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); }
+  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0);
+  if (cfg >= 0) { g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); g_a4_dkv = (cfg & 64) ? 2 : (cfg & 32) ? 1 : 0; }
   return old;
 }
 

@@ -81,7 +81,7 @@ def c2(dev, steps):
           "config": {"workload": "ViT-B/16@224 MAP tower, fwd+bwd, no optimizer", "batch": n, "residual_stream": STREAM}}
 
 
-def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label="", text_model=None):
+def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label="", text_model=None, vocab=32_000):
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
   model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, emb), temperature_init=10.0,
@@ -94,7 +94,7 @@ def _siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=N
     config.schedule = schedule
   g = torch.Generator(device=dev).manual_seed(1)
   image = torch.rand((n, res, res, 3), generator=g, device=dev) * 2 - 1
-  text = torch.randint(2, 32_000, (n, seq), generator=g, device=dev, dtype=torch.int32)
+  text = torch.randint(2, vocab, (n, seq), generator=g, device=dev, dtype=torch.int32)
   state, _ = siglip.make_train_state(model, config, (n, res, res, 3), (n, seq), rng=0, total_steps=20_000, device=dev)
   fn = siglip.make_update_fn(model, config)
   box = {"s": state}
@@ -131,7 +131,7 @@ def c5b(dev, steps):
   """The literal siglip_lit_coco.py: text_model='proj.flaxformer.bert', config 'base' (:78,84-87)."""
   sched = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=150))]
   r = _siglip(dev, steps, dict(variant="B/16", pool_type="tok", head_zeroinit=False), dict(config="base", head_zeroinit=False),
-              768, n=512, res=224, seq=16, micro=2048, schedule=sched, text_model="proj.flaxformer.bert",
+              768, n=512, res=224, seq=16, micro=2048, schedule=sched, text_model="proj.flaxformer.bert", vocab=30522,
               label="LiT (siglip_lit_coco.py as written): frozen ViT-B/16 cls-token tower + trainable BERT-base text tower, "
                     "16 tokens, batch 512, text-only backward")
   r["metric"] = "image-text pairs/sec, LiT locked-image step with the BERT-base text tower, batch 512 (BASELINE configs[4])"
