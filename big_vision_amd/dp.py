@@ -58,6 +58,40 @@ class Comm:
       dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
     return out
 
+  # ------------------------------------------------ sharded optimizer ("fsdp") --
+  def reduce_scatter_flat(self, flat: torch.Tensor, S: int) -> torch.Tensor:
+    """flat [n] partial sums on every rank -> this rank's slice [rank*S, (rank+1)*S) of the total, length S
+    (zero-padded beyond n; size * S >= n)."""
+    n = flat.numel()
+    if not self.active:
+      out = torch.zeros(S, device=flat.device, dtype=flat.dtype)
+      out[:min(n, S)] = flat[:min(n, S)]
+      return out
+    pad = torch.zeros(self.size * S, device=flat.device, dtype=flat.dtype)
+    pad[:n] = flat
+    if dist.get_backend(self.group) == "gloo":  # gloo has no reduce_scatter_tensor
+      dist.all_reduce(pad, group=self.group)
+      return pad[self.rank * S:(self.rank + 1) * S].clone()
+    out = torch.empty(S, device=flat.device, dtype=flat.dtype)
+    dist.reduce_scatter_tensor(out, pad, group=self.group)
+    return out
+
+  def all_gather_flat_(self, flat: torch.Tensor, lo: int, hi: int, S: int):
+    """In place: every rank contributes flat[lo:hi] (its slice, slices are S apart) and receives all others."""
+    if not self.active:
+      return
+    n = flat.numel()
+    mine = torch.zeros(S, device=flat.device, dtype=flat.dtype)
+    mine[:hi - lo] = flat[lo:hi]
+    if dist.get_backend(self.group) == "gloo":
+      parts = [torch.empty_like(mine) for _ in range(self.size)]
+      dist.all_gather(parts, mine, group=self.group)
+      full = torch.cat(parts)
+    else:
+      full = torch.empty(self.size * S, device=flat.device, dtype=flat.dtype)
+      dist.all_gather_into_tensor(full, mine, group=self.group)
+    flat.copy_(full[:n])
+
   # ----------------------------------------------------------------- grads --
   def all_reduce_sum_(self, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
     """In-place sum over ranks of a flat buffer, in large buckets.

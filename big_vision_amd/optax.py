@@ -82,8 +82,15 @@ def frozen_leaves(config, leaf_names) -> set:
 class Optimizer:
   """State + update of the fused chain (the `opt` half of the train state)."""
 
-  def __init__(self, config, store: ParamStore, *, sched_kw):
+  def __init__(self, config, store: ParamStore, *, sched_kw, comm=None, shard=False):
+    """comm / shard: placement of the optimizer.  shard=False (config.sharding_strategy "replicate"): every rank
+    holds the whole state and applies the whole update to gradients the trainer has all-reduced.  shard=True
+    ("fsdp", sharding.py): rank r owns the 1/N slice [lo, hi) of the flat trainable buffer - its Adam moments
+    exist only there; `step()` reduce-scatters the UNREDUCED gradients, updates its slice and all-gathers the
+    parameters (the reference's FSDP rule shards parameters and optimizer state, sharding.py:104-139; see
+    big_vision_amd/sharding.py for how the per-tensor axis rule maps onto flat slices)."""
     self.store = store
+    self.comm, self.sharded = comm, bool(shard)
     self._cfg = {k: config.get(k) for k in ("lr_mults", "wd", "wd_mults", "grad_clip_norm") if config.get(k) is not None}
     dev = store.device
     leaves = store.leaf_names()
@@ -147,6 +154,9 @@ class Optimizer:
       mu_dtype = okw.get("mu_dtype")
       mu_dtype = torch.bfloat16 if str(mu_dtype) in ("bfloat16", "torch.bfloat16") else torch.float32
     elif self.name in ADAFACTOR_NAMES:
+      if self.sharded:
+        raise NotImplementedError("fsdp placement with scale_by_adafactor: the factored statistics are per-leaf "
+                                  "row / column vectors, not sliceable with the flat buffer; use scale_by_adam or replicate")
       self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
       _refuse_per_example_clip(config)
       self.lr = float(config["lr"])
@@ -178,8 +188,18 @@ class Optimizer:
       segs[i, 2:3].view(np.int32)[0] = si
     self.segs = torch.from_numpy(segs).to(dev)
     self.chunk_seg = torch.from_numpy(chunk_seg).to(dev)
-    self.mu = torch.zeros(n_tr, device=dev, dtype=mu_dtype)
-    self.nu = torch.zeros(n_tr, device=dev, dtype=torch.float32)
+    if self.sharded:
+      from big_vision_amd import dp
+      self.comm = self.comm or dp.Comm()
+      N, r = self.comm.size, self.comm.rank
+      self.S = (n_tr + N * 1024 - 1) // (N * 1024) * 1024           # slice length, a whole number of 1024-chunks
+      self.lo = min(n_tr, r * self.S)
+      self.hi = min(n_tr, self.lo + self.S)
+      n_own = self.S
+    else:
+      self.lo, self.hi, n_own = 0, n_tr, n_tr
+    self.mu = torch.zeros(n_own, device=dev, dtype=mu_dtype)
+    self.nu = torch.zeros(n_own, device=dev, dtype=torch.float32)
     self.count = 0
     self.gsq = torch.zeros(1, device=dev, dtype=torch.float64)
     self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
@@ -333,6 +353,8 @@ class Optimizer:
     (l2_grads, l2_params, l2_updates) without synchronising."""
     if self.name in ADAFACTOR_NAMES:
       return self._adafactor_step()
+    if self.sharded:
+      return self._sharded_adam_step()
     st = self.store
     n_tr = st.trainable_count
     k = self.count
@@ -348,6 +370,46 @@ class Optimizer:
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
+
+  def _sharded_adam_step(self):
+    """"fsdp" placement: gradients arrive UNREDUCED (this rank's partial sums).  reduce_scatter -> this rank's
+    slice of the summed gradient -> global clip norm from the slices' square norms -> the fused Adam kernel on
+    the slice (same kernel, same per-chunk hyper-parameter table, offset pointers) -> all_gather of the updated
+    fp32 parameters -> bf16 shadow refreshed locally.  Per step and rank this moves (N-1)/N x 4 B x P each way -
+    exactly the bytes of the all-reduce it replaces - and runs 1/N of the optimizer kernel and of its state."""
+    st, comm = self.store, self.comm
+    n_tr, S, lo, hi = st.trainable_count, self.S, self.lo, self.hi
+    n_own = hi - lo
+    k = self.count
+    sched = [fn(k) for fn in self.schedule_fns]
+    g_own = comm.reduce_scatter_flat(st.grad[:n_tr], S)              # [S]; beyond n_own: zeros
+    self.gsq.zero_()
+    if n_own:
+      ops.sqnorm_(g_own[:n_own], self.gsq)
+    comm.all_reduce_scalars_(self.gsq)
+    self.stats.zero_()
+    if n_own:
+      ops.adam_step_(st.master[lo:hi], g_own[:n_own], self.mu[:n_own], self.nu[:n_own], st.shadow[lo:hi], self.segs,
+                     self.chunk_seg[lo // 1024:], n_own, sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
+                     1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
+    comm.all_reduce_scalars_(self.stats)
+    comm.all_gather_flat_(st.master[:n_tr], lo, hi, S)                 # every rank's slice into every rank's master
+    self.count = k + 1
+    st.mark_dirty()          # the kernel refreshed the shadow of the own slice only
+    st.refresh_shadow()
+    return {"l2_grads": torch.sqrt(self.gsq[0]),
+            "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
+            "l2_updates": torch.sqrt(self.stats[1])}
+
+  def _full_moment(self, t):
+    """Sharded moments as the full flat buffer every rank would hold when replicated (checkpointing)."""
+    if not self.sharded:
+      return t
+    n_tr = self.store.trainable_count
+    full = torch.zeros(n_tr, device=t.device, dtype=t.dtype)
+    full[self.lo:self.hi] = t[:self.hi - self.lo]
+    self.comm.all_gather_flat_(full, self.lo, self.hi, self.S)
+    return full
 
   # ---------------------------------------------------------------- checkpointing --
   def _chain_layout(self):
@@ -392,7 +454,7 @@ class Optimizer:
   def _opt_state_tree(self, cnt):
     if self.name in ADAFACTOR_NAMES:
       return self._af_state_tree(cnt)
-    return {"0": cnt, "1": self._moment_tree(self.mu), "2": self._moment_tree(self.nu)}
+    return {"0": cnt, "1": self._moment_tree(self._full_moment(self.mu)), "2": self._moment_tree(self._full_moment(self.nu))}
 
   def _trainable_ext_names(self):
     st = self.store
@@ -475,6 +537,14 @@ class Optimizer:
     if self.name in ADAFACTOR_NAMES:
       return self._load_af_state(flat, pre)
     self.count = int(np.asarray(flat[pre + "0"]))
+    if self.sharded:   # the checkpoint holds whole moments: lay them out in a full buffer, keep the own slice
+      n_tr = self.store.trainable_count
+      for buf, key in ((self.mu, "1/"), (self.nu, "2/")):
+        full = torch.zeros(n_tr, device=buf.device, dtype=buf.dtype)
+        self._assign_moment(full, flat, pre + key)
+        buf.zero_()
+        buf[:self.hi - self.lo] = full[self.lo:self.hi]
+      return
     self._assign_moment(self.mu, flat, pre + "1/")
     self._assign_moment(self.nu, flat, pre + "2/")
 
@@ -511,9 +581,9 @@ class Optimizer:
     self.mu.copy_(d["mu"].to(self.mu.dtype)); self.nu.copy_(d["nu"]); self.count = int(d["count"])
 
 
-def make(config, store: ParamStore, *, sched_kw):
-  """Returns (optimizer, schedule_fns) like bv_optax.make returns (tx, sched_fns)."""
-  opt = Optimizer(config, store, sched_kw=sched_kw)
+def make(config, store: ParamStore, *, sched_kw, comm=None, shard=False):
+  """Returns (optimizer, schedule_fns) like bv_optax.make returns (tx, sched_fns).  comm / shard: see Optimizer."""
+  opt = Optimizer(config, store, sched_kw=sched_kw, comm=comm, shard=shard)
   return opt, opt.schedule_fns
 
 

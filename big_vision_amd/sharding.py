@@ -10,10 +10,23 @@ pattern that hits it and the ops of that entry rewrite its partition spec; ops a
 
 North star of this repo: REPLICATED data parallelism - every rank holds the whole flat parameter
 buffer (203 M parameters of B/16 + text-B = 0.8 GB fp32 of 288 GB), gradients are summed with an
-RCCL all-reduce (big_vision_amd/dp.py).  So the only placement that exists is "every axis
-unsharded on every rank".  This module accepts exactly the strategies that mean that and REFUSES
-the others - `fsdp`, `shard_dim`, `logical_partitioning` raise NotImplementedError naming the
-parameter - instead of silently running replicated under a config that asked for something else.
+RCCL all-reduce (big_vision_amd/dp.py).  Two placements exist:
+
+  replicate  every axis unsharded on every rank (the default strategy).
+  fsdp       `fsdp(axis=..., min_size_to_shard_mb=4)` (:104-139).  `infer_sharding` returns the spec the
+             reference would return - the largest axis divisible by the device count of every tensor above the
+             size threshold carries the mesh axis name.  WHAT IS BUILT BEHIND IT (round 3): the state that the
+             reference's FSDP spreads over the devices - parameters' fp32 masters' UPDATE and the optimizer
+             moments - is owned in contiguous 1/N slices of the flat buffer (`optax.Optimizer(shard=True)`):
+             reduce_scatter of the gradients, Adam on the own slice, all_gather of the updated parameters.  It
+             is a slice of the FLAT buffer, not a cut along each tensor's axis: the same bytes per rank, no
+             per-tensor bookkeeping, identical arithmetic (Adam is elementwise; the clip norm is all-reduced).
+             The gathered parameters stay resident between steps - every kernel of the step reads them and
+             0.8 GB is 0.3 % of the HBM - where XLA would re-gather per use; what is sharded in memory is
+             the optimizer state (2/3 of the train state).  Adafactor's factored statistics do not slice:
+             refused.
+`shard_dim` and `logical_partitioning` raise NotImplementedError naming the parameter - instead of silently
+running replicated under a config that asked for something else.
 A spec is a tuple with one entry per array axis (None = not sharded), like the reference's
 intermediate `specs` tree; there is no device mesh object: `mesh` is the rank group (dp.Comm) or None.
 """
@@ -72,14 +85,44 @@ def _unsupported(rule):
   return factory
 
 
-for _r in ("fsdp", "shard_dim", "logical_partitioning"):
+@register("fsdp")
+def fsdp(axis, min_size_to_shard_mb=4):
+  """FSDP rule (:104-139): the largest not-yet-sharded dimension that the device count divides gets `axis`;
+  tensors of at most `min_size_to_shard_mb` MiB stay replicated."""
+  axis = axis if isinstance(axis, str) else tuple(axis)
+
+  def update(cur_spec, mesh, name, x):
+    del name
+    shape = tuple(x.shape)
+    axis_size = int(getattr(mesh, "size", 1) or 1)
+    itemsize = x.element_size() if hasattr(x, "element_size") else getattr(getattr(x, "dtype", None), "itemsize", 4)
+    numel = 1
+    for d in shape:
+      numel *= int(d)
+    if numel * itemsize <= min_size_to_shard_mb * (2 ** 20):
+      return cur_spec
+    for i in sorted(range(len(shape)), key=lambda j: shape[j])[::-1]:   # np.argsort(shape)[::-1]
+      if shape[i] % axis_size == 0 and cur_spec[i] is None:
+        return cur_spec[:i] + (axis,) + cur_spec[i + 1:]
+    return cur_spec      # nothing divisible / free: stays as it is (the reference logs and moves on)
+  return update
+
+
+for _r in ("shard_dim", "logical_partitioning"):
   _OPS[_r] = _unsupported(_r)
+
+
+def is_sharded(specs) -> bool:
+  """True if any leaf of a spec tree names a mesh axis (i.e. the strategy asked for fsdp somewhere)."""
+  if isinstance(specs, dict):
+    return any(is_sharded(v) for v in specs.values())
+  return any(a is not None for a in specs)
 
 
 def infer_sharding(params, strategy=None, mesh=None):
   """-> tree of specs (tuples of None) with the structure of `params` (:38-71).  Every leaf is
   matched by at most one strategy entry (first pattern wins, utils.make_mask_trees semantics); an
-  unmatched leaf stays replicated, as in the reference.  Raises on any rule other than replicate."""
+  unmatched leaf stays replicated, as in the reference.  Raises on shard_dim / logical_partitioning."""
   strategy = list(strategy if strategy is not None else DEFAULT_STRATEGY)
   flat, names = u.tree_flatten_with_names(params)
   by_name = dict(flat)
@@ -102,7 +145,7 @@ def infer_sharding(params, strategy=None, mesh=None):
 
 def check_config(config, params, mesh=None):
   """What a trainer calls once: validates `config.sharding_strategy` / `config.sharding_rules`
-  against the replicated placement and returns the spec tree."""
+  and returns the spec tree (`is_sharded(specs)` tells the trainer to build the sharded optimizer)."""
   if config.get("sharding_rules"):
     raise NotImplementedError("config.sharding_rules (logical axis partitioning, sharding.py:142-166) "
                               "is not implemented: parameters are replicated")

@@ -72,12 +72,12 @@ def make_train_state(model, config, image_shape, *, rng=0, comm=None, total_step
   store.init_random(_seed_of(rng))
   store.refresh_shadow()
   store.want_grads = True
-  from big_vision_amd import sharding     # train.py:201-203: replicated, anything else is refused
-  sharding.check_config(config, store.tree(), mesh=comm)
+  from big_vision_amd import sharding     # train.py:201-203: replicate, or fsdp = sharded optimizer state / update
+  fsdp = sharding.is_sharded(sharding.check_config(config, store.tree(), mesh=comm))
   batch_size = config.get("input", {}).get("batch_size", image_shape[0] * comm.size)
   total_steps = total_steps if total_steps is not None else u.steps("total", config, None, batch_size)
   opt, sched_fns = bv_optax.make(config, store, sched_kw=dict(total_steps=total_steps, batch_size=batch_size,
-                                                               data_size=None))
+                                                               data_size=None), comm=comm, shard=fsdp)
   return {"params": store.tree(), "opt": opt}, sched_fns
 
 
@@ -121,7 +121,8 @@ def make_update_fn(model, config, comm=None):
     logits, _, ctx = ex.fwd(images, save=True)
     acc = torch.zeros(1, device=images.device, dtype=torch.float64)
     dlogits = loss_kernel(logits.contiguous(), labels, acc, want_grad=True, n_global=n * comm.size)
-    sync = dp.GradSync(comm, store.grad) if comm.size > 1 else None
+    # ("fsdp" placement: the optimizer reduce-scatters the unreduced gradients itself)
+    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and not getattr(opt, "sharded", False)) else None
     ex.bwd(ctx, dlogits)
     if sync is not None:
       sync.finish()

@@ -83,12 +83,13 @@ def make_train_state(model, config, image_shape, text_shape, *, rng=0, comm=None
   store.want_grads = True
   # parameter placement (siglip.py:196, 232-237): replicated; any other strategy is refused, not ignored
   from big_vision_amd import sharding
-  sharding.check_config(config, store.tree(), mesh=comm)
+  specs = sharding.check_config(config, store.tree(), mesh=comm)
+  fsdp = sharding.is_sharded(specs)   # "fsdp" somewhere in config.sharding_strategy: sharded optimizer state / update
   batch_size = config.get("input", {}).get("batch_size", image_shape[0] * comm.size)
   total_steps = total_steps if total_steps is not None else u.steps(
       "total", config, None, batch_size)
   sched_kw = dict(total_steps=total_steps, batch_size=batch_size, data_size=None)
-  opt, sched_fns = bv_optax.make(config, store, sched_kw=sched_kw)
+  opt, sched_fns = bv_optax.make(config, store, sched_kw=sched_kw, comm=comm, shard=fsdp)
   return {"params": store.tree(), "opt": opt}, sched_fns
 
 
@@ -123,7 +124,9 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     t_param = store.t("t")
     b_param = store.t("b") if "b" in store.entries else None
     # N > 1: the gradient all-reduce overlaps the (last) backward, see dp.GradSync
-    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and config.get("overlap_grad_sync", True)) else None
+    # "fsdp" placement: the optimizer reduce-scatters the gradients itself (optax._sharded_adam_step)
+    sharded = getattr(opt, "sharded", False)
+    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and config.get("overlap_grad_sync", True) and not sharded) else None
 
     if micro and n > micro:
       assert n % micro == 0, f"per-device batch {n} not divisible by microbatch {micro}"
@@ -214,7 +217,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     # DP: sum partial gradients and the loss shares (pmean of the reference).
     if sync is not None:
       sync.finish()
-    else:
+    elif not sharded:
       comm.all_reduce_sum_(store.grad)
     loss = stats[:1].clone()
     comm.all_reduce_scalars_(loss)

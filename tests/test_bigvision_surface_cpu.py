@@ -121,7 +121,7 @@ def test_contrastive_trainer_loss_switch(dry):
     contrastive.make_update_fn(model, bad)
 
 
-def test_sharding_accepts_replicate_and_refuses_the_rest():
+def test_sharding_replicate_fsdp_and_the_refused_rules():
   import numpy as np
   import big_vision.sharding as sh
   params = {"img": {"embedding": {"kernel": np.zeros((16, 16, 3, 8)), "bias": np.zeros(8)}}, "t": np.zeros(1)}
@@ -129,11 +129,50 @@ def test_sharding_accepts_replicate_and_refuses_the_rest():
   assert specs == {"img": {"embedding": {"kernel": (None,) * 4, "bias": (None,)}}, "t": (None,)}
   assert sh.infer_sharding(params) == specs                                       # default strategy
   assert sh.infer_sharding(params, [("img/.*", "replicate")]) == specs            # unmatched leaves stay replicated
-  for bad in ("fsdp(axis='data')", "shard_dim('data', 0)", "logical_partitioning", "replicate|fsdp(axis='data')"):
+  assert not sh.is_sharded(specs)
+  for bad in ("shard_dim('data', 0)", "logical_partitioning"):
     with pytest.raises(NotImplementedError, match="replicated"):
       sh.infer_sharding(params, [(".*", bad)])
   with pytest.raises(KeyError):
     sh.infer_sharding(params, [(".*", "bogus")])
+  # fsdp (sharding.py:104-139): the largest axis the device count divides, tensors above min_size_to_shard_mb only
+  class Mesh:   # the rank group stands in for the device mesh: only its size matters
+    size = 8
+  big = {"mlp": {"kernel": np.zeros((768, 3072), np.float32), "bias": np.zeros(3072, np.float32)},
+         "odd": np.zeros((1023, 1025), np.float32), "qkv": np.zeros((768, 12, 64), np.float32)}
+  sp = sh.infer_sharding(big, [(".*", "fsdp(axis='data')")], Mesh())
+  assert sp == {"mlp": {"kernel": (None, "data"), "bias": (None,)},      # 9 MiB: cut along 3072; the bias is 12 KiB
+                "odd": (None, None),                                      # nothing divisible by 8: stays replicated
+                "qkv": (None, None, None)}                                # 2.25 MiB <= 4 MiB: stays replicated
+  assert sh.is_sharded(sp)
+  sp1 = sh.infer_sharding(big, [(".*", "fsdp(axis='data', min_size_to_shard_mb=1)")], Mesh())
+  assert sp1["qkv"] == ("data", None, None) and sp1["odd"] == (None, None)
+  with pytest.raises(ValueError, match="can't be fully replicated"):          # replicate after fsdp on the same leaf
+    sh.infer_sharding(big, [(".*", "fsdp(axis='data')|replicate")], Mesh())
   from ml_collections import ConfigDict
-  with pytest.raises(NotImplementedError):
-    sh.check_config(ConfigDict(dict(sharding_strategy=[(".*", "fsdp(axis='data')")])), params)
+  assert sh.is_sharded(sh.check_config(ConfigDict(dict(sharding_strategy=[(".*", "fsdp(axis='data')")])), big, Mesh()))
+
+
+def test_fsdp_placement_builds_the_sharded_optimizer(dry):
+  """config.sharding_strategy = [(".*", "fsdp(axis='data')")] -> optimizer moments only for the own 1/N slice of
+  the flat buffer, the update through reduce_scatter / all_gather (dp.Comm; identities in a one-rank job), no
+  gradient all-reduce by the trainer.  Host logic on the dry-run kernels; arithmetic: tests/test_dp_two_ranks_gpu.py."""
+  from big_vision.trainers.proj.image_text import siglip as trainer
+  from big_vision.models.proj.image_text import two_towers
+  from ml_collections import ConfigDict
+  tower = dict(width=128, depth=1, mlp_dim=256, num_heads=2)
+  model = two_towers.Model(image=dict(tower, patch_size=(16, 16), pool_type="map"), text=dict(tower, vocab_size=50),
+                           out_dim=(None, 64), temperature_init=10.0, bias_init=-10.0)
+  image, text = torch.zeros((4, 32, 32, 3)), torch.ones((4, 8), dtype=torch.int32)
+  c = ConfigDict(dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
+                      schedule=dict(decay_type="cosine", warmup_steps=2),
+                      sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)")]))
+  state, _ = trainer.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
+  opt = state["opt"]
+  assert opt.sharded and (opt.lo, opt.hi) == (0, state["params"].store.trainable_count) and opt.mu.numel() == opt.S
+  dry.clear()
+  state, meas = trainer.make_update_fn(model, c)(state, None, {"image": image, "labels": text})
+  assert dry["bv_adam_step"] == 1 and opt.count == 1 and {"l2_grads", "l2_params", "l2_updates"} <= set(meas)
+  c2 = ConfigDict(dict(c.to_dict(), optax_name="big_vision.scale_by_adafactor"))
+  with pytest.raises(NotImplementedError, match="fsdp placement with scale_by_adafactor"):
+    trainer.make_train_state(model, c2, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")

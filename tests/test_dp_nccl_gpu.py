@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out, force):
+def _worker(rank, world, port, out, force, kw=None):
   sys.path.insert(0, ROOT)
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,21 +33,22 @@ def _worker(rank, world, port, out, force):
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
   n = 8 // world
   dev = torch.device("cuda", rank)
-  loss, gn, grads, params = T._step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev))
+  loss, gn, grads, params = T._step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev), **(kw or {}))
   digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
-  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest))
+  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest,
+           {k: v.numpy() for k, v in params.items()} if (rank == 0 and kw) else None))
   comm.barrier()
   torch.distributed.destroy_process_group()
 
 
-def _run(world, force):
+def _run(world, force, kw=None):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "tests"))
   import test_dp_two_ranks_gpu as T
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
   port = T._free_port()
-  procs = [ctx.Process(target=_worker, args=(r, world, port, out, force)) for r in range(world)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, out, force, kw)) for r in range(world)]
   for p in procs:
     p.start()
   res = {}
@@ -66,7 +67,7 @@ def _check(res, dev):
   from big_vision_amd import dp
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
   loss1, gn1, g1, _ = T._step(dp.Comm(), image.to(dev), text.to(dev))
-  loss2, gn2, g2, _ = res[0]
+  loss2, gn2, g2 = res[0][:3]
   assert abs(loss2 - loss1) <= 1e-4 * abs(loss1), (loss1, loss2)
   assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
   gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
@@ -79,6 +80,32 @@ def _check(res, dev):
 def test_rccl_call_path_on_one_gpu(dev):
   sys.path.insert(0, os.path.join(ROOT, "tests"))
   _check(_run(1, force=True), dev)
+
+
+def test_fsdp_placement_over_rccl_on_one_gpu(dev):
+  """config.sharding_strategy fsdp on a ONE-rank RCCL group with the collectives forced on: reduce_scatter_tensor
+  of the gradients and all_gather_into_tensor of the updated parameters really go through ProcessGroupNCCL
+  (over one rank both are the identity), the sharded Adam step runs on the slice [0, P): the parameters after the
+  step must be the replicated single-process step's (up to the sign of an Adam update of a ~0 gradient: the bias
+  gradients are summed with fp32 atomics, run-to-run order noise; one update = lr = 1e-3)."""
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import bv_oracle as O
+  import test_dp_two_ranks_gpu as T
+  from big_vision_amd import dp
+  res = _run(1, force=True, kw=T.FSDP)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  loss1, gn1, g1, p1 = T._step(dp.Comm(), image.to(dev), text.to(dev), schedule=T.FSDP["schedule"])
+  loss2, gn2, _, _, params2 = res[0]
+  assert abs(loss2 - loss1) <= 1e-6 * abs(loss1) and abs(gn2 - gn1) <= 1e-5 * gn1
+  gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
+  moved = 0
+  for k, v in p1.items():
+    d = (v - torch.from_numpy(params2[k])).abs()
+    assert d.max().item() <= 2e-3 + 1e-6, (k, d.max().item())
+    if g1[k].norm().item() >= 1e-3 * gnorm:
+      assert (d > 1e-6).double().mean().item() <= 0.02, (k, (d > 1e-6).double().mean().item())
+    moved += int((d <= 1e-9).sum().item())
+  assert moved > 0.9 * sum(v.numel() for v in p1.values())      # >90 % of all parameters agree to the last bit
 
 
 def test_two_ranks_over_rccl(dev):

@@ -76,20 +76,26 @@ def _worker(rank, world, port, out, kw):
   digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
   # numpy arrays are pickled by value (torch tensors would travel as shared-memory handles that
   # die with this process)
-  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest))
+  out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest,
+           {k: v.numpy() for k, v in params.items()} if (rank == 0 and "sharding_strategy" in kw) else None))
   comm.barrier()
   torch.distributed.destroy_process_group()
 
 
+FSDP = dict(sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)")],
+            schedule=dict(decay_type="cosine", warmup_steps=0))      # no warm-up: the first step really moves the weights
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2), dict(loss_fn="softmax"),
-                                dict(loss_fn="sigmoid")])
+                                dict(loss_fn="sigmoid"), FSDP])
 def test_two_ranks_match_single_process(dev, kw):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import bv_oracle as O
   from big_vision_amd import dp
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
-  loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev), **({"loss_fn": kw["loss_fn"]} if "loss_fn" in kw else {}))
+  single_kw = {k: kw[k] for k in ("loss_fn", "schedule") if k in kw}      # same trainer / schedule, replicated, one process
+  loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev), **single_kw)
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
   port = _free_port()
@@ -103,11 +109,24 @@ def test_two_ranks_match_single_process(dev, kw):
   for p in procs:
     p.join(60)
     assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
-  loss2, gn2, g2, p2 = res[0]
+  loss2, gn2, g2, p2, params2 = res[0]
   assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(loss1), "ranks disagree on the global loss"
   assert abs(loss2 - loss1) <= 1e-4 * abs(loss1), (loss1, loss2)
   assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
+  assert res[0][3] == res[1][3], "replicated parameters diverged between the ranks after the update"
+  if "sharding_strategy" in kw:
+    # "fsdp" placement: each rank's gradient buffer holds its PARTIAL sums (the optimizer reduce-scatters them),
+    # each rank updated its own slice of the flat buffer and all-gathered the rest: the parameters after the
+    # step must be the single-process step's.  Adam's first update is lr * g / (|g| + eps): a gradient that is
+    # ~0 up to summation order may flip its sign, one update = lr = 1e-3.
+    assert abs(res[0][1] - res[1][1]) <= 1e-9 * gn1, "ranks disagree on the global gradient norm"
+    gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
+    for k, v in p1.items():
+      d = (v - torch.from_numpy(params2[k])).abs()
+      assert d.max().item() <= 2e-3 + 1e-6, (k, d.max().item())
+      if g1[k].norm().item() >= 1e-3 * gnorm:     # (tensors whose gradient is noise - the key bias - move by noise / (noise + eps))
+        assert (d > 1e-6).double().mean().item() <= 0.05, (k, (d > 1e-6).double().mean().item())
+    return
   gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
   for k, v in g1.items():
     assert (v - torch.from_numpy(g2[k])).norm().item() <= 2e-2 * max(v.norm().item(), 1e-2 * gnorm), k
-  assert res[0][3] == res[1][3], "replicated parameters diverged between the ranks after the update"
