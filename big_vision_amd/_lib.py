@@ -87,6 +87,13 @@ PROTOTYPES = {
 PROTOTYPES["bv_adafactor_leaf"] = [P, P, P, c_int, P, P, P, c_int, P, c_float, c_float, c_float, c_float,
                                    c_float, c_float, c_float, P, P]
 
+# collectives for non-Python hosts (csrc/comm.cpp; the Python host uses torch.distributed, dp.py)
+PROTOTYPES.update({
+    "bv_comm_version": [P], "bv_comm_unique_id": [P], "bv_comm_init": [P, c_int, c_int, P], "bv_comm_destroy": [P],
+    "bv_comm_all_gather": [P, P, P, c_long, c_int, P], "bv_comm_reduce_scatter": [P, P, P, c_long, c_int, P],
+    "bv_comm_all_reduce_bucket": [P, P, c_long, c_long, c_int, P],
+})
+
 RESTYPES = {"bv_gemm_workspace_bytes": c_long}   # everything else returns an int status
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)

@@ -383,6 +383,33 @@ int bv_adafactor_leaf(float* params, const float* grads, void* momentum, int mom
                       float decay, float eps, float mom, float lr_eff, float wd, float sched,
                       double* stats, void* stream);
 
+/* ------------------------------------------------------- Collectives (RCCL) ----
+ * The exchange steps of the data-parallel step for hosts that do not go through torch.distributed (the
+ * Python host does: big_vision_amd/dp.py issues the same collectives through ProcessGroupNCCL = RCCL):
+ *   all_gather of the local text embeddings for the global-batch loss
+ *       (trainers/proj/image_text/_deprecated_contrastive.py:67-77,122; siglip.py:287-306 under a device mesh)
+ *   reduce_scatter of their gradients (the transpose of that gather)
+ *   bucketed all_reduce(SUM) of the flat fp32 gradient buffer (pmean of grads :343-344; sharding.py:83-101)
+ *   reduce_scatter / all_gather of the flat buffer for the "fsdp" placement (sharding.py:104-139)
+ * RCCL is bound at run time (dlopen): an RCCL already in the process is reused, libbvhip.so loads without one.
+ * One communicator per process = per GPU (the calling thread's current HIP device).  id: BV_COMM_ID_BYTES
+ * bytes created by rank 0 and carried to the other ranks by the host.  Counts are ELEMENTS of `dtype`.
+ * The calls are asynchronous on `stream`. */
+#define BV_COMM_ID_BYTES 128
+#define BV_COMM_F32 0
+#define BV_COMM_BF16 1
+#define BV_COMM_F64 2
+int bv_comm_version(int* version);                       /* RCCL version code, e.g. 22606 */
+int bv_comm_unique_id(void* id_out /* BV_COMM_ID_BYTES */);
+int bv_comm_init(const void* id, int rank, int world, void** comm_out);
+int bv_comm_destroy(void* comm);
+int bv_comm_all_gather(void* comm, const void* send, void* recv /* world * count_per_rank */, long count_per_rank,
+                       int dtype, void* stream);
+int bv_comm_reduce_scatter(void* comm, const void* send /* world * count_per_rank */, void* recv, long count_per_rank,
+                           int dtype, void* stream);
+/* in-place SUM of buf[0 .. count) in buckets of bucket_elems elements (0 = one message) */
+int bv_comm_all_reduce_bucket(void* comm, void* buf, long count, long bucket_elems, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

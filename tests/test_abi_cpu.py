@@ -66,3 +66,17 @@ def test_product_never_imports_the_oracle():
       if f.endswith((".py", ".hip", ".cpp", ".h")):
         txt = open(os.path.join(d, f)).read()
         assert "bv_oracle" not in txt and "import oracle" not in txt, os.path.join(d, f)
+
+
+def test_comm_layer_binds_rccl_at_run_time():
+  """bv_comm_* (csrc/comm.cpp) has no link-time RCCL dependency: the library loads on a host without a GPU and the
+  first call binds the RCCL that is already in the process (PyTorch's) - one RCCL per process."""
+  import ctypes
+  import subprocess
+  from big_vision_amd import _lib
+  lib = _lib.load()
+  v = ctypes.c_int(0)
+  assert lib.bv_comm_version(ctypes.byref(v)) == 0 and v.value >= 20000, lib.bv_last_error()
+  needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+  assert "rccl" not in needed.lower(), "libbvhip.so must not link RCCL"
+  assert lib.bv_comm_init(None, 0, 1, None) != 0 and b"bad arguments" in lib.bv_last_error()

@@ -132,3 +132,37 @@ def test_bench_stdout_is_one_json_line_with_rccl_in_the_loop():
   assert len(lines) == 1, r.stdout
   line = json.loads(lines[0])
   assert line["n_gpus"] == 1 and line["config"]["global_batch"] == 32 and math.isfinite(line["value"])
+
+
+def test_bv_comm_c_layer_on_one_rank(dev):
+  """include/bvhip.h `bv_comm_*` (init / all_gather / reduce_scatter / all_reduce_bucket / destroy):
+  the collectives of the step as C entry points over RCCL, bound at run time to the RCCL already in the process.
+  One-rank communicator on the MI355X box: every call really goes through RCCL and must be the identity."""
+  import ctypes
+  from big_vision_amd import _lib
+  lib = _lib.load()
+  ver = ctypes.c_int(0)
+  assert lib.bv_comm_version(ctypes.byref(ver)) == 0 and ver.value >= 20000, lib.bv_last_error()
+  uid = ctypes.create_string_buffer(128)
+  assert lib.bv_comm_unique_id(uid) == 0, lib.bv_last_error()
+  comm = ctypes.c_void_p()
+  torch.cuda.set_device(dev)
+  assert lib.bv_comm_init(uid, 0, 1, ctypes.byref(comm)) == 0, lib.bv_last_error()
+  try:
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(4096, device=dev)
+    y = torch.empty_like(x)
+    assert lib.bv_comm_all_gather(comm, x.data_ptr(), y.data_ptr(), x.numel(), 0, s) == 0, lib.bv_last_error()
+    z = torch.empty_like(x)
+    assert lib.bv_comm_reduce_scatter(comm, x.data_ptr(), z.data_ptr(), x.numel(), 0, s) == 0, lib.bv_last_error()
+    w = x.clone()
+    assert lib.bv_comm_all_reduce_bucket(comm, w.data_ptr(), w.numel(), 1000, 0, s) == 0, lib.bv_last_error()   # 5 buckets
+    b = x.to(torch.bfloat16)
+    b2 = torch.empty_like(b)
+    assert lib.bv_comm_all_gather(comm, b.data_ptr(), b2.data_ptr(), b.numel(), 1, s) == 0, lib.bv_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x) and torch.equal(z, x) and torch.equal(w, x) and torch.equal(b2, b)
+    assert lib.bv_comm_all_gather(comm, x.data_ptr(), y.data_ptr(), 0, 0, s) != 0      # empty message is refused
+    assert b"bad arguments" in lib.bv_last_error()
+  finally:
+    assert lib.bv_comm_destroy(comm) == 0
