@@ -104,7 +104,8 @@ def pmc_traffic(world, micro):
 # clearly separate object ("bf16_stream": value, ms_per_step and the worst per-tensor gradient rel-L2 the
 # -m gpu step tests measured for that mode), never as `value`.
 RESIDUAL_STREAM = "float32"
-BF16_STREAM_PARITY = ("profiles/r03_parity_report.jsonl", "bf16 stream: siglip B/16 n=32 microbatch=8 light")
+# the -m gpu case that runs exactly the bf16 object's mode: B/16 + text-B through micro-batches with gelu(h)-free contexts
+BF16_STREAM_PARITY = ("profiles/r03_parity_report.jsonl", "siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, bfloat16 stream")
 
 
 # siglip.make_update_fn's state_cache["light"] -> what a kept micro-batch context holds

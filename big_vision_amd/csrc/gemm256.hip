@@ -412,16 +412,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     __builtin_amdgcn_s_setprio(0);                                                             \
   } while (0)
 
+  // PROBE 12 / 13 (timing only, tools/probes/gemm_r3_probe.hip): the same loop with HALF the workgroup
+  // barriers - 12 drops the one behind every MFMA segment, 13 the one in front of it
 #define BV_MID()                                          \
   do {                                                    \
-    __builtin_amdgcn_s_barrier();                         \
+    if (PROBE != 13) __builtin_amdgcn_s_barrier();        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_sched_barrier(0);                    \
   } while (0)
-#define BV_END()                             \
-  do {                                       \
-    __builtin_amdgcn_sched_barrier(0);       \
-    __builtin_amdgcn_s_barrier();            \
+#define BV_END()                                          \
+  do {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    if (PROBE != 12) __builtin_amdgcn_s_barrier();        \
   } while (0)
 
   // ---- prologue: B(0), A(0), B(1) in flight; K-tile 0 must have landed.
