@@ -3,7 +3,7 @@
 # arithmetic, with the bf16-stream object and the CPU baseline), the rank shapes of N = 2 / 4 / 8 on one GPU, the N = 8
 # shape with the one-rank RCCL collectives in the loop, rocprofv3 kernel stats of the bench command and of the n = 512
 # shape, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE, counters only - never combined with tracing domains).
-#   bash tools/gpu_final.sh [notests] [slow]
+#   bash tools/gpu_final.sh [notests] [slow] [yard]     (slow: the full-depth L/16@336 case; yard: the vendor GEMM yardstick)
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
@@ -30,6 +30,7 @@ find $O/stats512 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kerne
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
 python tools/pmc_summary.py $F $W --microbatch=2048 --n_gpus=1 > $O/pmc_traffic.json 2> $O/pmc_summary.err
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+timeout 900 python tools/bench_configs.py c2 c4 c5 c5b --steps 5 > $O/bench_configs.jsonl 2> $O/bench_configs.err; cut -c1-200 $O/bench_configs.jsonl
 if [[ " $* " == *" yard "* ]]; then
   timeout 500 python tools/gemm_yardstick.py > $O/gemm_yardstick.txt 2> $O/gemm_yardstick.err; tail -12 $O/gemm_yardstick.txt | cut -c1-160
 fi
