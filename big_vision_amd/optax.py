@@ -402,7 +402,9 @@ class Optimizer:
             "l2_updates": torch.sqrt(self.stats[1])}
 
   def _full_moment(self, t):
-    """Sharded moments as the full flat buffer every rank would hold when replicated (checkpointing)."""
+    """Sharded moments as the full flat buffer every rank would hold when replicated (checkpointing).  A
+    COLLECTIVE on N > 1 ranks: `state_tree()` / `u.save_train_state` must be entered by every rank (write the
+    file on one)."""
     if not self.sharded:
       return t
     n_tr = self.store.trainable_count

@@ -173,6 +173,19 @@ def test_fsdp_placement_builds_the_sharded_optimizer(dry):
   dry.clear()
   state, meas = trainer.make_update_fn(model, c)(state, None, {"image": image, "labels": text})
   assert dry["bv_adam_step"] == 1 and opt.count == 1 and {"l2_grads", "l2_params", "l2_updates"} <= set(meas)
+  # checkpoints hold WHOLE moments (gathered over the ranks on save - a collective: every rank calls it - and
+  # sliced on load), in the same optax naming as the replicated optimizer
+  import big_vision.utils as u
+  opt.mu.copy_(torch.arange(opt.mu.numel(), dtype=torch.float32).to(opt.mu.dtype) % 7)
+  flat = dict(u.tree_flatten_with_names(opt.state_tree())[0])
+  n_tr = state["params"].store.trainable_count
+  assert sum(v.numel() for k, v in flat.items() if k.startswith("1/0/1/")) <= n_tr and int(flat["1/0/0"]) == 1
+  before = opt.mu.clone()
+  opt.mu.zero_()
+  opt.load_state_tree(flat)
+  keep = dict(u.tree_flatten_with_names(opt._moment_tree(opt._full_moment(opt.mu)))[0])
+  want = dict(u.tree_flatten_with_names(opt._moment_tree(opt._full_moment(before)))[0])
+  assert all(torch.equal(keep[k], want[k]) for k in want)
   c2 = ConfigDict(dict(c.to_dict(), optax_name="big_vision.scale_by_adafactor"))
   with pytest.raises(NotImplementedError, match="fsdp placement with scale_by_adafactor"):
     trainer.make_train_state(model, c2, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
