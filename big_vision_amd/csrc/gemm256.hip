@@ -370,9 +370,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     }
   };
 
+  // PROBE 14 / 15 (timing only): 14 = STATIC priority (waves 4-7 raise theirs once, no per-segment flips:
+  // MI355X_MICROARCH.md, VALU arbitration item 4), 15 = no s_setprio at all
+  if (PROBE == 14 && wr == 1) __builtin_amdgcn_s_setprio(1);
 #define BV_MFMA_QUAD(I0, J0)                                                                   \
   do {                                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
+    if (PROBE != 14 && PROBE != 15) __builtin_amdgcn_s_setprio(1);                             \
     if constexpr (PROBE == 11) {                                                               \
       if (first) {                                                                             \
         _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2)                                       \
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
           acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
               bfg[(J0) + j][1], af[i][1], acc[(I0) + i][(J0) + j], 0, 0, 0);                   \
     }                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                             \
+    if (PROBE != 14 && PROBE != 15) __builtin_amdgcn_s_setprio(0);                             \
   } while (0)
 
   // PROBE 12 / 13 (timing only, tools/probes/gemm_r3_probe.hip): the same loop with HALF the workgroup

@@ -112,15 +112,17 @@ int main(int argc, char** argv) {
       t_ge = tf(BV_EPI_GELU_BWD_EMIT, 0, auxb, c1, colsum);
       t_mul = tf(BV_EPI_MUL, 0, auxb, nullptr, colsum);
     }
-    float p0 = 1e30f, p11 = 1e30f, p12 = 1e30f, p13 = 1e30f;
+    float p0 = 1e30f, p11 = 1e30f, p12 = 1e30f, p13 = 1e30f, p14 = 1e30f, p15 = 1e30f;
     for (int rep = 0; rep < 2; ++rep) {
       p0 = fminf(p0, time_ms([&] { launch_plain<8>(a, b, c0, s.M, s.N, s.K); }, it));
       p11 = fminf(p11, time_ms([&] { launch_plain<11>(a, b, c0, s.M, s.N, s.K); }, it));
       p12 = fminf(p12, time_ms([&] { launch_plain<12>(a, b, c0, s.M, s.N, s.K); }, it));
       p13 = fminf(p13, time_ms([&] { launch_plain<13>(a, b, c0, s.M, s.N, s.K); }, it));
+      p14 = fminf(p14, time_ms([&] { launch_plain<14>(a, b, c0, s.M, s.N, s.K); }, it));
+      p15 = fminf(p15, time_ms([&] { launch_plain<15>(a, b, c0, s.M, s.N, s.K); }, it));
     }
-    printf("%-28s | %5.0f %6.0f %6.0f %6.0f %7.0f %6.0f %8.0f %6.0f | %8.0f %8.0f  x%.3f | half barriers: no END %5.0f  no MID %5.0f\n", s.name, t_bias, t_r32, t_r16, t_g,
-           t_gd, t_gb, t_ge, t_mul, fl / p0 / 1e9, fl / p11 / 1e9, p0 / p11, fl / p12 / 1e9, fl / p13 / 1e9);
+    printf("%-28s | %5.0f %6.0f %6.0f %6.0f %7.0f %6.0f %8.0f %6.0f | %8.0f %8.0f  x%.3f | half barriers: no END %5.0f  no MID %5.0f | setprio: static %5.0f  none %5.0f\n", s.name, t_bias, t_r32, t_r16, t_g,
+           t_gd, t_gb, t_ge, t_mul, fl / p0 / 1e9, fl / p11 / 1e9, p0 / p11, fl / p12 / 1e9, fl / p13 / 1e9, fl / p14 / 1e9, fl / p15 / 1e9);
     fflush(stdout);
   }
   hipError_t e = hipGetLastError();
