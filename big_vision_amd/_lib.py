@@ -87,6 +87,9 @@ PROTOTYPES = {
 PROTOTYPES["bv_adafactor_leaf"] = [P, P, P, c_int, P, P, P, c_int, P, c_float, c_float, c_float, c_float,
                                    c_float, c_float, c_float, P, P]
 
+PROTOTYPES["bv_adafactor_step"] = [P, P, P, c_int, P, P, c_int, c_long, c_long, c_long, c_long, P, P, c_float, c_float,
+                                   c_float, c_float, P, c_int, P, P]
+
 # collectives for non-Python hosts (csrc/comm.cpp; the Python host uses torch.distributed, dp.py)
 PROTOTYPES.update({
     "bv_comm_version": [P], "bv_comm_unique_id": [P], "bv_comm_init": [P, c_int, c_int, P], "bv_comm_destroy": [P],

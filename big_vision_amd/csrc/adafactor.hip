@@ -145,7 +145,174 @@ __global__ __launch_bounds__(256) void af_update_kernel(float* __restrict__ p, c
   }
 }
 
+// ---- batched form: ALL leaves of a step in four launches (blockIdx.y = leaf).  A B/16 + text-B model has
+// ~440 leaves; one launch group per leaf is ~1.5 k tiny launches per step (6 ms of launch overhead: 6 % of a
+// 512-pair step).  The table lives in device memory; a workgroup whose blockIdx.x lies beyond its leaf's extent
+// (the grid is sized for the largest leaf) or whose leaf is of the other kind returns at once.
+struct AfSched { float v[BV_MAX_SCHED]; };
+
+__device__ __forceinline__ AfView af_view_of(const bv_af_leaf& L) {
+  AfView v;
+  v.off = L.off; v.B1 = L.B1; v.B2 = L.B2; v.R = L.R; v.C = L.C;
+  v.sB1 = L.sB1; v.sB2 = L.sB2; v.sR = L.sR; v.sC = L.sC;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void af_rows_batched(const float* __restrict__ g, const bv_af_leaf* __restrict__ leaves,
+                                                       float* __restrict__ state, const double* gsq,
+                                                       float clip_norm, float decay, float eps) {
+  __shared__ float sh[4];
+  const bv_af_leaf L = leaves[blockIdx.y];
+  const long B = (long)L.B1 * L.B2;
+  if (!L.factored || blockIdx.x >= B * L.R) return;
+  const AfView v = af_view_of(L);
+  float* v_row = state + L.soff;
+  const int br = blockIdx.x;
+  const int r = br % v.R, b = br / v.R;
+  const int b2 = b % v.B2, b1 = b / v.B2;
+  const float cf = clip_factor(gsq, clip_norm);
+  const float* base = g + v.off + b1 * v.sB1 + b2 * v.sB2 + r * v.sR;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < v.C; c += 256) {
+    const float x = base[c * v.sC] * cf;
+    acc += x * x + eps;
+  }
+  const float s = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) v_row[br] = decay * v_row[br] + (1.f - decay) * (s / (float)v.C);
+}
+
+__global__ __launch_bounds__(256) void af_cols_batched(const float* __restrict__ g, const bv_af_leaf* __restrict__ leaves,
+                                                       float* __restrict__ state, const double* gsq,
+                                                       float clip_norm, float decay, float eps) {
+  const bv_af_leaf L = leaves[blockIdx.y];
+  if (!L.factored) return;
+  const AfView v = af_view_of(L);
+  const long B = (long)v.B1 * v.B2;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * v.C) return;
+  float* v_col = state + L.soff + B * v.R;
+  const int c = (int)(i % v.C), b = (int)(i / v.C);
+  const int b2 = b % v.B2, b1 = b / v.B2;
+  const float cf = clip_factor(gsq, clip_norm);
+  const float* base = g + v.off + b1 * v.sB1 + b2 * v.sB2 + c * v.sC;
+  float acc = 0.f;
+  for (int r = 0; r < v.R; ++r) {
+    const float x = base[r * v.sR] * cf;
+    acc += x * x + eps;
+  }
+  v_col[i] = decay * v_col[i] + (1.f - decay) * (acc / (float)v.R);
+}
+
+__global__ __launch_bounds__(256) void af_rcm_batched(const bv_af_leaf* __restrict__ leaves, float* __restrict__ state) {
+  __shared__ float sh[4];
+  const bv_af_leaf L = leaves[blockIdx.y];
+  const long B = (long)L.B1 * L.B2;
+  if (!L.factored || blockIdx.x >= B) return;
+  const float* v_row = state + L.soff;
+  float* rcm = state + L.soff + B * L.R + B * L.C;
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < L.R; r += 256) acc += v_row[(long)blockIdx.x * L.R + r];
+  const float s = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) rcm[blockIdx.x] = s / (float)L.R;
+}
+
+template <bool MOM_BF16>
+__global__ __launch_bounds__(256) void af_update_batched(float* __restrict__ p, const float* __restrict__ g,
+                                                         void* __restrict__ mom, bf16* __restrict__ shadow,
+                                                         const bv_af_leaf* __restrict__ leaves,
+                                                         float* __restrict__ state, const double* gsq,
+                                                         float clip_norm, float decay, float eps, float momentum,
+                                                         AfSched sched, double* __restrict__ stats) {
+  __shared__ float sh[4];
+  const bv_af_leaf L = leaves[blockIdx.y];
+  const AfView v = af_view_of(L);
+  const long B = (long)v.B1 * v.B2;
+  const long total = B * v.R * v.C;
+  if ((long)blockIdx.x * 256 >= total) return;          // (uniform per workgroup: the reductions below are safe)
+  const float* v_row = state + L.soff;
+  const float* v_col = v_row + B * v.R;
+  const float* rcm = v_col + B * v.C;
+  float* vfull = state + L.soff;
+  const float cf = clip_factor(gsq, clip_norm);
+  const float sc = sched.v[L.sched_idx];
+  float sp = 0.f, su = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int r, c;
+    long b;
+    if (L.r_fast) { r = (int)(i % v.R); const long t = i / v.R; c = (int)(t % v.C); b = t / v.C; }
+    else { c = (int)(i % v.C); const long t = i / v.C; r = (int)(t % v.R); b = t / v.R; }
+    const int b2 = (int)(b % v.B2), b1 = (int)(b / v.B2);
+    const long e = v.off + b1 * v.sB1 + b2 * v.sB2 + r * v.sR + c * v.sC;
+    const float gc = g[e] * cf;
+    float u;
+    if (L.factored) {
+      const float rf = rsqrtf(v_row[b * v.R + r] / rcm[b]);
+      const float cfac = rsqrtf(v_col[b * v.C + c]);
+      u = gc * rf * cfac;
+    } else {
+      const long vi = (b * v.R + r) * v.C + c;
+      const float nv = decay * vfull[vi] + (1.f - decay) * (gc * gc + eps);
+      vfull[vi] = nv;
+      u = gc * rsqrtf(nv);
+    }
+    if (momentum > 0.f) {
+      float m;
+      if constexpr (MOM_BF16) m = (float)reinterpret_cast<bf16*>(mom)[e];
+      else m = reinterpret_cast<float*>(mom)[e];
+      m = momentum * m + (1.f - momentum) * u;
+      if constexpr (MOM_BF16) reinterpret_cast<bf16*>(mom)[e] = (bf16)m;
+      else reinterpret_cast<float*>(mom)[e] = m;
+      u = m;
+    }
+    const float pv = p[e];
+    const float upd = -sc * (L.lr_eff * u + L.wd * pv);
+    const float pn = pv + upd;
+    p[e] = pn;
+    if (shadow) shadow[e] = (bf16)pn;
+    sp += pn * pn;
+    su += upd * upd;
+  }
+  const float a = block_sum_256(sp, sh);
+  const float b_ = block_sum_256(su, sh);
+  if (threadIdx.x == 0 && stats) {
+    atomicAdd(stats + 0, (double)a);
+    atomicAdd(stats + 1, (double)b_);
+  }
+}
+
 }  // namespace
+
+// The whole Adafactor step of a model: the leaves of bv_adafactor_leaf as a device table, four launches.
+// max_rows = max over factored leaves of B*R, max_cols = max B*C, max_b = max B, max_total = max B*R*C over
+// all leaves (grid extents; host-computed once per model).
+extern "C" int bv_adafactor_step(float* params, const float* grads, void* momentum, int mom_bf16, void* shadow_bf16,
+                                 const bv_af_leaf* leaves, int nleaves, long max_rows, long max_cols, long max_b,
+                                 long max_total, float* state, const double* gsq, float clip_norm, float decay,
+                                 float eps, float mom, const float* sched, int nsched, double* stats, void* stream) {
+  BV_REQUIRE(nleaves > 0 && nleaves <= 65535 && leaves != nullptr, "bv_adafactor_step: bad leaf table (%d)", nleaves);
+  BV_REQUIRE(nsched >= 1 && nsched <= BV_MAX_SCHED && sched != nullptr, "bv_adafactor_step: 1..%d schedule values", BV_MAX_SCHED);
+  BV_REQUIRE(clip_norm <= 0.f || gsq != nullptr, "bv_adafactor_step: clipping needs gsq");
+  BV_REQUIRE(max_total > 0, "bv_adafactor_step: empty model");
+  hipStream_t s = (hipStream_t)stream;
+  AfSched sc;
+  for (int i = 0; i < BV_MAX_SCHED; ++i) sc.v[i] = i < nsched ? sched[i] : 0.f;
+  if (max_rows > 0) {
+    hipLaunchKernelGGL(af_rows_batched, dim3((unsigned)max_rows, nleaves), dim3(256), 0, s, grads, leaves, state, gsq,
+                       clip_norm, decay, eps);
+    hipLaunchKernelGGL(af_cols_batched, dim3((unsigned)((max_cols + 255) / 256), nleaves), dim3(256), 0, s, grads, leaves,
+                       state, gsq, clip_norm, decay, eps);
+    hipLaunchKernelGGL(af_rcm_batched, dim3((unsigned)max_b, nleaves), dim3(256), 0, s, leaves, state);
+  }
+  long gsz = (max_total + 1023) / 1024;
+  if (gsz > 1024) gsz = 1024;
+  if (mom_bf16)
+    hipLaunchKernelGGL((af_update_batched<true>), dim3((unsigned)gsz, nleaves), dim3(256), 0, s, params, grads, momentum,
+                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats);
+  else
+    hipLaunchKernelGGL((af_update_batched<false>), dim3((unsigned)gsz, nleaves), dim3(256), 0, s, params, grads, momentum,
+                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats);
+  return bv_check_launch("bv_adafactor_step");
+}
 
 // One leaf of the Adafactor step.  view = {off, B1, B2, R, C, sB1, sB2, sR, sC} (9 longs; unfactored
 // leaves pass any view that enumerates their elements).  state: factored -> v_row [B*R], v_col [B*C],

@@ -279,6 +279,25 @@ class Optimizer:
                                  sched=sched_idx_of_leaf[extn], B=B, R=R, C=C))
       off_state += (n_state + 3) // 4 * 4
     self.af_state = torch.zeros(max(4, off_state), device=dev, dtype=torch.float32)
+    # device table of all leaves (struct bv_af_leaf, include/bvhip.h) for the batched step: four launches per
+    # step instead of up to four per leaf
+    AF_LEAF = np.dtype([("off", np.int64), ("sB1", np.int64), ("sB2", np.int64), ("sR", np.int64), ("sC", np.int64),
+                        ("soff", np.int64), ("B1", np.int32), ("B2", np.int32), ("R", np.int32), ("C", np.int32),
+                        ("factored", np.int32), ("sched_idx", np.int32), ("r_fast", np.int32), ("pad_", np.int32),
+                        ("lr_eff", np.float32), ("wd", np.float32)], align=True)
+    assert AF_LEAF.itemsize == 88, AF_LEAF.itemsize
+    tab = np.zeros(len(self.af_leaves), AF_LEAF)
+    mx = dict(rows=0, cols=0, b=0, total=0)
+    for i, lf in enumerate(self.af_leaves):
+      off, B1, B2, R, C, sB1, sB2, sR, sC = (int(x) for x in lf["view"])
+      tab[i] = (off, sB1, sB2, sR, sC, lf["soff"], B1, B2, R, C, int(lf["factored"]), lf["sched"], int(sR < sC), 0,
+                lf["lr_eff"], lf["wd"])
+      B = B1 * B2
+      if lf["factored"]:
+        mx["rows"], mx["cols"], mx["b"] = max(mx["rows"], B * R), max(mx["cols"], B * C), max(mx["b"], B)
+      mx["total"] = max(mx["total"], B * R * C)
+    self.af_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+    self.af_max = mx
     self.mu = torch.zeros(st.trainable_count, device=dev, dtype=mom_dtype) if self.af["momentum"] > 0 else None
     self.nu = None
     self.count = 0
@@ -294,11 +313,10 @@ class Optimizer:
     self.gsq.zero_()
     ops.sqnorm_(st.grad, self.gsq)
     self.stats.zero_()
-    for lf in self.af_leaves:
-      ops.adafactor_leaf_(st.master, st.grad, self.mu, st.shadow, lf["view"],
-                          self.af_state[lf["soff"]:lf["soff"] + lf["n_state"]], lf["factored"], self.gsq,
-                          self.clip_norm, decay, af["eps"], af["momentum"], lf["lr_eff"], lf["wd"],
-                          sched[lf["sched"]], self.stats)
+    mx = self.af_max
+    ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table, len(self.af_leaves), mx["rows"],
+                        mx["cols"], mx["b"], mx["total"], self.af_state, self.gsq, self.clip_norm, decay, af["eps"],
+                        af["momentum"], sched, self.stats)
     self.count = k + 1
     st.shadow_version += 1
     return {"l2_grads": torch.sqrt(self.gsq[0]),

@@ -383,6 +383,24 @@ int bv_adafactor_leaf(float* params, const float* grads, void* momentum, int mom
                       float decay, float eps, float mom, float lr_eff, float wd, float sched,
                       double* stats, void* stream);
 
+/* The same for ALL leaves of a model in four launches (a B/16 + text-B model has ~440 leaves: one launch group per
+ * leaf is ~1.5 k tiny launches per step).  `leaves`: DEVICE table, one entry per leaf = the view of
+ * bv_adafactor_leaf + soff (offset of the leaf's statistics in `state`) + its hyper-parameters; sched: HOST array of
+ * this step's schedule values, indexed by sched_idx; max_*: grid extents (max over the factored leaves of B*R, B*C,
+ * B; max over all leaves of B*R*C). */
+typedef struct {
+  long off;               /* element offset of the view origin in params / grads / momentum / shadow */
+  long sB1, sB2, sR, sC;  /* strides of the view (elements) */
+  long soff;              /* element offset of this leaf's statistics in `state` */
+  int B1, B2, R, C;
+  int factored, sched_idx, r_fast, pad_;
+  float lr_eff, wd;
+} bv_af_leaf;
+int bv_adafactor_step(float* params, const float* grads, void* momentum, int mom_bf16, void* shadow_bf16,
+                      const bv_af_leaf* leaves, int nleaves, long max_rows, long max_cols, long max_b, long max_total,
+                      float* state, const double* gsq, float clip_norm, float decay, float eps, float mom,
+                      const float* sched /*host*/, int nsched, double* stats, void* stream);
+
 /* ------------------------------------------------------- Collectives (RCCL) ----
  * The exchange steps of the data-parallel step for hosts that do not go through torch.distributed (the
  * Python host does: big_vision_amd/dp.py issues the same collectives through ProcessGroupNCCL = RCCL):

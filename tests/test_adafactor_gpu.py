@@ -58,3 +58,44 @@ def test_two_adafactor_steps_match_the_oracle(dev, frozen):
     l2u = math.sqrt(sum((upd[k].double() ** 2).sum().item() for k in p_after))
     assert abs(meas["l2_updates"].item() - l2u) <= 2e-3 * l2u
     assert math.isfinite(meas["training_loss"].item())
+
+
+def test_batched_step_equals_the_per_leaf_entry(dev):
+  """bv_adafactor_step (all leaves of a model in four launches, device leaf table) against bv_adafactor_leaf called
+  leaf by leaf on cloned buffers: parameters, momentum, statistics and the bf16 shadow must be bit-identical (same
+  arithmetic per element; only the fp64 statistics atomics are summed in another order)."""
+  from big_vision_amd import ops
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+  model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+  c = ConfigDict()
+  c.lr, c.wd, c.total_steps, c.grad_clip_norm = 1e-2, 1e-2, 10, 1.0
+  c.optax_name = "big_vision.scale_by_adafactor"
+  c.schedule = dict(decay_type="cosine", warmup_steps=0)
+  c.lr_mults = [("txt/.*", 0.5), (".*", 1.0)]
+  state, _ = siglip.make_train_state(model, c, (8, 64, 64, 3), (8, 16), rng=0, total_steps=10)
+  opt, st = state["opt"], state["params"].store
+  g = torch.Generator(device=dev).manual_seed(5)
+  st.ensure_grad().copy_(torch.randn(st.grad.shape, generator=g, device=dev) * 1e-2)
+  # a second, independent copy of every buffer for the per-leaf path
+  m2, mu2, sh2, af2 = st.master.clone(), opt.mu.clone(), st.shadow.clone(), opt.af_state.clone()
+  for step in range(2):
+    k = opt.count
+    sched = [fn(k) for fn in opt.schedule_fns]
+    decay = min(opt.af["beta2_cap"], 1.0 - (float(k - opt.af["decay_offset"]) + 1.0) ** (-opt.af["decay_rate"]))
+    gsq = torch.zeros(1, device=dev, dtype=torch.float64)
+    ops.sqnorm_(st.grad, gsq)
+    stats2 = torch.zeros(2, device=dev, dtype=torch.float64)
+    for lf in opt.af_leaves:
+      ops.adafactor_leaf_(m2, st.grad, mu2, sh2, lf["view"], af2[lf["soff"]:lf["soff"] + lf["n_state"]], lf["factored"], gsq,
+                          opt.clip_norm, decay, opt.af["eps"], opt.af["momentum"], lf["lr_eff"], lf["wd"], sched[lf["sched"]],
+                          stats2)
+    meas = opt.step()
+    torch.cuda.synchronize()
+    n = st.trainable_count
+    assert torch.equal(st.master[:n], m2[:n]), f"step {step}: parameters differ"
+    assert torch.equal(opt.mu, mu2) and torch.equal(opt.af_state, af2) and torch.equal(st.shadow[:n], sh2[:n])
+    assert abs(meas["l2_updates"].item() - math.sqrt(stats2[1].item())) <= 1e-9 * math.sqrt(stats2[1].item())
