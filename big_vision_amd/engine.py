@@ -167,6 +167,9 @@ class _W:
     self.bf, self.f32, self.grad = sh, ma, g
     self.store = store
     self._t, self._t_ver = None, -1
+    # frozen tensors (config.schedule None: the image tower of LiT) change only on init / load, not at every
+    # optimizer step: their transposed image is rebuilt against store.static_version
+    self.frozen = name in store.frozen
     # input width not a multiple of 8 (the 14 x 14 x 3 = 588 stem of So400m/14): the GEMM operands are
     # padded to kpad columns / rows of zeros (16-byte operand loads); the activations arrive padded
     self.kpad = None
@@ -177,7 +180,7 @@ class _W:
     """[out][in] bf16 image of a 2-D (in,out) kernel, re-transposed only when the
     shadow changed (once per optimizer step): lets the forward projections run
     on the k-major ("NT") GEMM path."""
-    ver = self.store.shadow_version
+    ver = self.store.static_version if self.frozen else self.store.shadow_version
     if self._t_ver != ver:
       if self.kpad:
         if self._t is None:

@@ -140,6 +140,7 @@ class ParamStore:
     self.ext_index = {k: [l for _, l in sorted(v)] for k, v in self.ext_index.items()}
     self._shadow_dirty = True
     self.shadow_version = 0   # bumped whenever the bf16 shadow changes (cast / optimizer step)
+    self.static_version = 0   # bumped only by a full cast (init / load): the version of the FROZEN tensors, which an optimizer step never touches
 
   # ------------------------------------------------------------ accessors --
   def _buf(self, buf):
@@ -257,6 +258,7 @@ class ParamStore:
       ops.cast_bf16(self.master, self.shadow)
       self._shadow_dirty = False
       self.shadow_version += 1
+      self.static_version += 1
 
   def mark_dirty(self):
     self._shadow_dirty = True

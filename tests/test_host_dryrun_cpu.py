@@ -289,3 +289,24 @@ def test_context_kinds_full_then_gelu_free_then_light(dry):
   calls.clear()
   fn(state, None, batch)
   assert calls["bv_layernorm_fwd_bf16x"] == (2 * BLOCKS + 2) * 4 + 2 * BLOCKS * 4 and calls["bv_layernorm_bwd_y"] == 0
+
+
+def test_frozen_tower_weights_are_transposed_once(dry):
+  """LiT (schedule [("img/.*", None), ...]): the frozen image tower's [out][in] weight images are rebuilt only when
+  the store is re-cast (init / load), not after every optimizer step - the trainable text tower's are."""
+  calls, _ = dry
+  fn, state, batch = _setup(_cfg(schedule=[("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]))
+  calls.clear()
+  state, _ = fn(state, None, batch)
+  first = calls["bv_transpose_bf16"]
+  calls.clear()
+  state, _ = fn(state, None, batch)
+  second = calls["bv_transpose_bf16"]
+  assert 0 < second < first, (first, second)
+  calls.clear()
+  state, _ = fn(state, None, batch)
+  assert calls["bv_transpose_bf16"] == second
+  state["params"].store.mark_dirty()          # what load_tree() does: every image is stale again
+  calls.clear()
+  state, _ = fn(state, None, batch)
+  assert calls["bv_transpose_bf16"] == first
