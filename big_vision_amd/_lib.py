@@ -66,6 +66,7 @@ PROTOTYPES = {
     "bv_cast_bf16": [P, P, c_long, P],
     "bv_cast_f32": [P, P, c_long, P],
     "bv_transpose_bf16": [P, P, c_int, c_int, c_long, c_long, P],
+    "bv_transpose_bf16_batched": [P, c_int, c_int, P],
     "bv_concat_cls": [P, P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_fwd": [P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_bwd": [P, P, c_int, c_int, c_int, P],

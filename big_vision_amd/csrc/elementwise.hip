@@ -411,6 +411,35 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+// Table-driven form: one launch transposes every listed matrix (the ~100 projection kernels of the two
+// towers after an optimizer step: one launch instead of one per weight).  A workgroup finds its matrix by
+// bisection over the tile prefix `tile0`.
+__global__ __launch_bounds__(256) void transpose_bf16_batched_kernel(const bv_tr_leaf* __restrict__ tab, int nleaves) {
+  __shared__ uint16_t tile[64][66];
+  int lo = 0, hi = nleaves - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const bv_tr_leaf e = tab[lo];
+  const int t = blockIdx.x - e.tile0;
+  const int r0 = (t / e.tiles_x) * 64, c0 = (t % e.tiles_x) * 64;
+  const uint16_t* src = (const uint16_t*)e.src;
+  uint16_t* dst = (uint16_t*)e.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    if (r0 + r < e.rows && c0 + tx < e.cols) tile[r][tx] = src[(long)(r0 + r) * e.lds + c0 + tx];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    if (c0 + c < e.cols && r0 + tx < e.rows) dst[(long)(c0 + c) * e.ldd + r0 + tx] = tile[tx][c];
+  }
+}
+
 __global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long count) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) y[i] = tanhf(x[i]);
 }
@@ -443,6 +472,14 @@ extern "C" int bv_transpose_bf16(const void* src, void* dst, int rows, int cols,
   hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      (const uint16_t*)src, (uint16_t*)dst, rows, cols, lds, ldd);
   return bv_check_launch("bv_transpose_bf16");
+}
+
+extern "C" int bv_transpose_bf16_batched(const bv_tr_leaf* leaves, int nleaves, int total_tiles, void* stream) {
+  BV_REQUIRE(leaves && nleaves > 0 && total_tiles > 0, "bv_transpose_bf16_batched: empty table (nleaves=%d tiles=%d)",
+             nleaves, total_tiles);
+  hipLaunchKernelGGL(transpose_bf16_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, leaves,
+                     nleaves);
+  return bv_check_launch("bv_transpose_bf16_batched");
 }
 
 // models/vit.py:212-217 — im2col of the stride-P VALID patch conv.

@@ -15,6 +15,57 @@ namespace {
 
 constexpr int MAXV = 8;  // float4 per lane -> D <= 2048
 
+// Streaming accesses of the fp32-stream kernels.  Every activation these kernels touch is read or written once
+// per launch.  NT bit 0 marks the loads, bit 1 the stores non-temporal (tools/probes/ln_probe.hip, all four
+// combinations on the step's shapes): streams far larger than the 256 MB memory-side cache gain 3-5 % from both
+// (NT = 3: fwd 5.5 -> 5.8 TB/s, bwd 5.3 -> 5.6 on 401 408 x 768); when the inputs can still be cache-resident
+// (32 768 x 768: 100 MB) non-temporal LOADS lose 15 %, so the host picks NT = 2 there (ln_nt_for).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int NT>
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+  if constexpr ((NT & 1) != 0) {
+    const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <int NT>
+__device__ __forceinline__ uint2 ld_stream_bf4(const bf16* p) {
+  if constexpr ((NT & 1) != 0) {
+    const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return make_uint2(t.x, t.y);
+  } else {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+}
+template <int NT>
+__device__ __forceinline__ void st_stream4(float* p, const float4& v) {
+  if constexpr ((NT & 2) != 0) {
+    f32x4_t t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+template <int NT>
+__device__ __forceinline__ void st_stream_bf4(bf16* p, const uint2& v) {
+  if constexpr ((NT & 2) != 0) {
+    u32x2_t t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x2_t*>(p));
+  } else {
+    *reinterpret_cast<uint2*>(p) = v;
+  }
+}
+// rows x D fp32 activations: larger than what the memory-side cache can still hold from the producer?
+inline int ln_nt_for(long rows, int D) { return rows * (long)D * 4 > (192L << 20) ? 3 : 2; }
+
+// NV = float4 per lane and row (D <= 256 * NV).  A wave normalises TWO rows per trip: both rows' loads are
+// issued before either reduction (tools/probes/ln_fwd_probe.hip on 401 408 x 768: one row per trip 5.2 TB/s,
+// two 5.5, two with streaming accesses 5.8; four rows, or scale / bias held in registers across the trips, cost
+// occupancy and fall to 3.8-4.2).  The grid cap matters as much: 2048 workgroups 4.4 TB/s, 8192 5.7.
+template <int NV, int NT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ bias,
@@ -26,46 +77,60 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const float inv_d = 1.0f / (float)D;
-  for (int r = wave_global; r < rows; r += nwaves) {
-    const float* xr = x + ((long)r * row_stride + row_offset) * D;
-    float4 v[MAXV];
-    float s = 0.f, ss = 0.f;
+  for (int r0 = wave_global; r0 < rows; r0 += 2 * nwaves) {
+    float4 v[2][NV];
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
-      const int c = lane * 4 + it * 256;
-      if (c < D) {
-        v[it] = *reinterpret_cast<const float4*>(xr + c);
-        s += v[it].x + v[it].y + v[it].z + v[it].w;
-        ss += v[it].x * v[it].x + v[it].y * v[it].y + v[it].z * v[it].z + v[it].w * v[it].w;
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + j * nwaves;
+      if (r >= rows) continue;
+      const float* xr = x + ((long)r * row_stride + row_offset) * D;
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) v[j][it] = ld_stream4<NT>(xr + c);
       }
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
-    const float mean = s * inv_d;
-    const float var = fmaxf(ss * inv_d - mean * mean, 0.f);
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0) {
-      if (mean_o) mean_o[r] = mean;
-      if (rstd_o) rstd_o[r] = rstd;
-    }
 #pragma unroll
-    for (int it = 0; it < MAXV; ++it) {
-      const int c = lane * 4 + it * 256;
-      if (c < D) {
-        const float4 g = *reinterpret_cast<const float4*>(scale + c);
-        const float4 b = *reinterpret_cast<const float4*>(bias + c);
-        float4 o;
-        o.x = (v[it].x - mean) * rstd * g.x + b.x;
-        o.y = (v[it].y - mean) * rstd * g.y + b.y;
-        o.z = (v[it].z - mean) * rstd * g.z + b.z;
-        o.w = (v[it].w - mean) * rstd * g.w + b.w;
-        if (y_bf) {
-          uint2 p;
-          p.x = pack_bf2(o.x, o.y);
-          p.y = pack_bf2(o.z, o.w);
-          *reinterpret_cast<uint2*>(y_bf + (long)r * D + c) = p;
+    for (int j = 0; j < 2; ++j) {
+      const int r = r0 + j * nwaves;
+      if (r >= rows) continue;
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+          s += v[j][it].x + v[j][it].y + v[j][it].z + v[j][it].w;
+          ss += v[j][it].x * v[j][it].x + v[j][it].y * v[j][it].y + v[j][it].z * v[j][it].z + v[j][it].w * v[j][it].w;
         }
-        if (y_f) *reinterpret_cast<float4*>(y_f + (long)r * D + c) = o;
+      }
+      s = wave_sum(s);
+      ss = wave_sum(ss);
+      const float mean = s * inv_d;
+      const float var = fmaxf(ss * inv_d - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + eps);
+      if (lane == 0) {
+        if (mean_o) mean_o[r] = mean;
+        if (rstd_o) rstd_o[r] = rstd;
+      }
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < D) {
+          const float4 g = *reinterpret_cast<const float4*>(scale + c);
+          const float4 b = *reinterpret_cast<const float4*>(bias + c);
+          float4 o;
+          o.x = (v[j][it].x - mean) * rstd * g.x + b.x;
+          o.y = (v[j][it].y - mean) * rstd * g.y + b.y;
+          o.z = (v[j][it].z - mean) * rstd * g.z + b.z;
+          o.w = (v[j][it].w - mean) * rstd * g.w + b.w;
+          if (y_bf) {
+            uint2 p;
+            p.x = pack_bf2(o.x, o.y);
+            p.y = pack_bf2(o.z, o.w);
+            st_stream_bf4<NT>(y_bf + (long)r * D + c, p);
+          }
+          if (y_f) st_stream4<NT>(y_f + (long)r * D + c, o);
+        }
       }
     }
   }
@@ -74,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // NV = float4 per lane and row (D <= 256 * NV): the per-column partials live in registers, so
 // the ViT widths (768 -> 3, 1024 -> 4) get their own instantiation (3x fewer VGPRs than the
 // generic NV = 8, more rows in flight per CU).
-template <bool DY_F32, int NV>
+template <bool DY_F32, int NV, int NT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ scale,
@@ -111,14 +176,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
       if (c < D) {
         float4 d;
         if constexpr (DY_F32) {
-          d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + (long)r * D + c);
+          d = ld_stream4<NT>(reinterpret_cast<const float*>(dy_) + (long)r * D + c);
         } else {
-          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(dy_) + (long)r * D + c);
+          const uint2 u = ld_stream_bf4<NT>(reinterpret_cast<const bf16*>(dy_) + (long)r * D + c);
           d = make_float4(bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y));
         }
-        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 xv = ld_stream4<NT>(xr + c);
         const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-        dr[it] = dres ? *reinterpret_cast<const float4*>(dres + xrow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dr[it] = dres ? ld_stream4<NT>(dres + xrow * D + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         xh[it] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
                              (xv.w - mean) * rstd);
         if (y_out) {
@@ -134,7 +199,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           uint2 pk;
           pk.x = pack_bf2(o.x, o.y);
           pk.y = pack_bf2(o.z, o.w);
-          *reinterpret_cast<uint2*>(y_out + (long)r * D + c) = pk;
+          st_stream_bf4<NT>(y_out + (long)r * D + c, pk);
         }
         g[it] = make_float4(d.x * sc.x, d.y * sc.y, d.z * sc.z, d.w * sc.w);
         s1 += g[it].x + g[it].y + g[it].z + g[it].w;
@@ -156,13 +221,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         o.z = rstd * (g[it].z - s1 - xh[it].z * s2);
         o.w = rstd * (g[it].w - s1 - xh[it].w * s2);
         o.x += dr[it].x; o.y += dr[it].y; o.z += dr[it].z; o.w += dr[it].w;
-        *reinterpret_cast<float4*>(dx + xrow * D + c) = o;
+        st_stream4<NT>(dx + xrow * D + c, o);
         po[it].x += o.x; po[it].y += o.y; po[it].z += o.z; po[it].w += o.w;
         if (dx_bf) {
           uint2 p;
           p.x = pack_bf2(o.x, o.y);
           p.y = pack_bf2(o.z, o.w);
-          *reinterpret_cast<uint2*>(dx_bf + xrow * D + c) = p;
+          st_stream_bf4<NT>(dx_bf + xrow * D + c, p);
         }
       }
     }
@@ -570,10 +635,16 @@ extern "C" int bv_layernorm_fwd(const float* x, const float* scale, const float*
   BV_REQUIRE(D % 4 == 0 && D <= 256 * MAXV, "bv_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 256 * MAXV);
   BV_REQUIRE(row_stride >= 1 && row_offset >= 0 && row_offset < row_stride, "bv_layernorm_fwd: bad row_stride/offset");
   BV_REQUIRE(y_bf16 || y_f32, "bv_layernorm_fwd: no output requested");
-  int grid = (rows + 3) / 4;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, bias,
-                     (bf16*)y_bf16, y_f32, mean, rstd, rows, D, row_stride, row_offset, eps);
+  int grid = (rows + 7) / 8;          // 4 waves per workgroup, 2 rows per wave and trip
+  if (grid > 8192) grid = 8192;
+  const int nt = ln_nt_for(rows, D);
+#define BV_LN_FWD(NV, NT)                                                                                        \
+  hipLaunchKernelGGL((ln_fwd_kernel<NV, NT>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, scale, bias,      \
+                     (bf16*)y_bf16, y_f32, mean, rstd, rows, D, row_stride, row_offset, eps)
+  if (D <= 768) { if (nt == 3) BV_LN_FWD(3, 3); else BV_LN_FWD(3, 2); }
+  else if (D <= 1024) { if (nt == 3) BV_LN_FWD(4, 3); else BV_LN_FWD(4, 2); }
+  else { if (nt == 3) BV_LN_FWD(MAXV, 3); else BV_LN_FWD(MAXV, 2); }
+#undef BV_LN_FWD
   return bv_check_launch("bv_layernorm_fwd");
 }
 
@@ -601,18 +672,19 @@ extern "C" int bv_layernorm_bwd_y(const void* dy, int dy_is_f32, const float* x,
   BV_REQUIRE(mean && rstd && dx, "bv_layernorm_bwd: mean/rstd/dx required");
   const int nv = D <= 768 ? 3 : (D <= 1024 ? 4 : MAXV);
   int grid = (rows + 3) / 4;
-  const int max_grid = nv <= 4 ? 1024 : 512;   // workgroups resident per CU: 4 / 2
+  const int max_grid = nv <= 4 ? 768 : 512;   // workgroups per CU: 3 / 2 (ln_probe: 768 5.6 TB/s, 1024 5.5, 1280 4.3)
   if (grid > max_grid) grid = max_grid;
   const size_t shmem = sizeof(float) * 12 * D;
-#define BV_LN_BWD(F32, NV)                                                                              \
-  hipLaunchKernelGGL((ln_bwd_kernel<F32, NV>), dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x, \
-                     scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D,     \
+  const int nt = ln_nt_for(rows, D);
+#define BV_LN_BWD(F32, NV, NT)                                                                              \
+  hipLaunchKernelGGL((ln_bwd_kernel<F32, NV, NT>), dim3(grid), dim3(256), shmem, (hipStream_t)stream, dy, x, \
+                     scale, mean, rstd, dres, dx, (bf16*)dx_bf16, dscale, dbias, dx_colsum, rows, D,         \
                      row_stride, row_offset, bias, (bf16*)y_bf16)
-  if (dy_is_f32) {
-    if (nv == 3) BV_LN_BWD(true, 3); else if (nv == 4) BV_LN_BWD(true, 4); else BV_LN_BWD(true, MAXV);
-  } else {
-    if (nv == 3) BV_LN_BWD(false, 3); else if (nv == 4) BV_LN_BWD(false, 4); else BV_LN_BWD(false, MAXV);
-  }
+#define BV_LN_BWD_NV(F32, NT)                                                                               \
+  do { if (nv == 3) BV_LN_BWD(F32, 3, NT); else if (nv == 4) BV_LN_BWD(F32, 4, NT); else BV_LN_BWD(F32, MAXV, NT); } while (0)
+  if (dy_is_f32) { if (nt == 3) BV_LN_BWD_NV(true, 3); else BV_LN_BWD_NV(true, 2); }
+  else { if (nt == 3) BV_LN_BWD_NV(false, 3); else BV_LN_BWD_NV(false, 2); }
+#undef BV_LN_BWD_NV
 #undef BV_LN_BWD
   return bv_check_launch("bv_layernorm_bwd");
 }

@@ -19,6 +19,7 @@ bf16 (fp32 MFMA accumulate).  No autograd graph is built.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import List, Optional
 
 import torch
@@ -179,17 +180,55 @@ class _W:
   def bf_t(self):
     """[out][in] bf16 image of a 2-D (in,out) kernel, re-transposed only when the
     shadow changed (once per optimizer step): lets the forward projections run
-    on the k-major ("NT") GEMM path."""
+    on the k-major ("NT") GEMM path.  The first use transposes this weight alone and enrols it in the
+    store's batch; after that the first stale weight of a step refreshes every enrolled image in ONE
+    launch (_Twins)."""
     ver = self.store.static_version if self.frozen else self.store.shadow_version
     if self._t_ver != ver:
-      if self.kpad:
-        if self._t is None:
-          self._t = torch.zeros((self.bf.shape[1], self.kpad), device=self.bf.device, dtype=BF16)
-        ops.transpose_bf16(self.bf, self._t[:, :self.bf.shape[0]])
+      if self._t is None:
+        K, N = self.bf.shape
+        self._t = (torch.zeros((N, self.kpad), device=self.bf.device, dtype=BF16) if self.kpad
+                   else torch.empty((N, K), device=self.bf.device, dtype=BF16))
+        ops.transpose_bf16(self.bf, self._t[:, :K])
+        self._t_ver = ver
+        _Twins.of(self.store).add(self)
       else:
-        self._t = ops.transpose_bf16(self.bf, self._t)
-      self._t_ver = ver
+        _Twins.of(self.store).refresh(self.frozen, ver)
     return self._t
+
+
+class _Twins:
+  """The transposed bf16 images (_W.bf_t) of one store's projection kernels, refreshed together: ~100
+  weights of the two towers in one table-driven launch (ops.transpose_bf16_batched) instead of one 10 us
+  launch each - 1 ms of a 96 ms step at n = 512.  Trainable and frozen weights form separate batches (a
+  frozen image changes only with store.static_version).  The device table holds raw addresses: the batch
+  keeps the tensors it names alive and is rebuilt when a member joins or dies."""
+
+  def __init__(self):
+    self.members = {False: [], True: []}     # frozen? -> [weakref to _W]
+    self.batch = {False: None, True: None}   # frozen? -> (table, n, tiles, tensors kept alive)
+
+  @staticmethod
+  def of(store) -> "_Twins":
+    tw = getattr(store, "_twins", None)
+    if tw is None:
+      tw = store._twins = _Twins()
+    return tw
+
+  def add(self, w: _W):
+    self.members[w.frozen].append(weakref.ref(w))
+    self.batch[w.frozen] = None
+
+  def refresh(self, frozen: bool, ver: int):
+    live = [w for w in (r() for r in self.members[frozen]) if w is not None]
+    if self.batch[frozen] is None or len(live) != len(self.members[frozen]):
+      self.members[frozen] = [weakref.ref(w) for w in live]
+      pairs = [(w.bf, w._t[:, :w.bf.shape[0]]) for w in live]
+      self.batch[frozen] = ops.transpose_table(pairs, live[0].bf.device) + (pairs,)
+    table, n, tiles, _ = self.batch[frozen]
+    ops.transpose_bf16_batched(table, n, tiles)
+    for w in live:
+      w._t_ver = ver
 
 
 def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):

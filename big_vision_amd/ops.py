@@ -4,6 +4,7 @@ PyTorch is used only for device memory and the HIP stream; every function here
 enqueues hand-written HIP kernels on torch's current stream.  There is no
 eager/PyTorch fallback: non-GPU tensors raise.
 """
+import numpy as np
 import torch
 
 from big_vision_amd import _lib
@@ -304,6 +305,33 @@ def transpose_bf16(x, out=None):
   ldd = _rowmajor2d(out, "transpose.out")
   _lib.call("bv_transpose_bf16", _p(x), _p(out), rows, cols, lds, ldd, _stream())
   return out
+
+
+TR_LEAF = np.dtype([("src", np.uint64), ("dst", np.uint64), ("lds", np.int64), ("ldd", np.int64), ("rows", np.int32),
+                    ("cols", np.int32), ("tile0", np.int32), ("tiles_x", np.int32)])   # struct bv_tr_leaf (include/bvhip.h)
+
+
+def transpose_table(pairs, device):
+  """Device table for transpose_bf16_batched from [(src [rows, cols], dst [cols, >= rows])] (bf16, row-major).
+  Returns (table tensor, number of entries, total 64 x 64 tiles); the table holds raw addresses: the caller
+  keeps the tensors alive and rebuilds it when one of them is re-allocated."""
+  tab = np.zeros(len(pairs), TR_LEAF)
+  tiles = 0
+  for i, (src, dst) in enumerate(pairs):
+    _chk(src, BF16, "transpose.x")
+    _chk(dst, BF16, "transpose.out")
+    lds, ldd = _rowmajor2d(src, "transpose.x"), _rowmajor2d(dst, "transpose.out")
+    rows, cols = src.shape
+    if dst.shape[0] != cols or ldd < rows:
+      raise ValueError(f"transpose_table: dst {tuple(dst.shape)} does not hold the transpose of {tuple(src.shape)}")
+    tx = (cols + 63) // 64
+    tab[i] = (src.data_ptr(), dst.data_ptr(), lds, ldd, rows, cols, tiles, tx)
+    tiles += tx * ((rows + 63) // 64)
+  return torch.from_numpy(tab.view(np.uint8).copy()).to(device), len(pairs), tiles
+
+
+def transpose_bf16_batched(table, nleaves, tiles):
+  _lib.call("bv_transpose_bf16_batched", _p(table), nleaves, tiles, _stream())
 
 
 def concat_cls(cls, x, n, L, D):

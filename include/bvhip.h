@@ -275,6 +275,17 @@ int bv_cast_f32(const void* x_bf16, float* y, long count, void* stream);
  * projections (models/vit.py:72,77,93-98) on the k-major GEMM path. */
 int bv_transpose_bf16(const void* src, void* dst, int rows, int cols, long lds, long ldd,
                       void* stream);
+/* The same for a table of matrices in ONE launch (all projection kernels of the towers after an optimizer
+ * step).  `leaves`: device array; tile0 = number of 64x64 tiles of the entries before this one (ascending),
+ * tiles_x = ceil(cols / 64); total_tiles = sum over entries of ceil(rows / 64) * tiles_x. */
+typedef struct bv_tr_leaf {
+  const void* src;
+  void* dst;
+  long lds, ldd;
+  int rows, cols;
+  int tile0, tiles_x;
+} bv_tr_leaf;
+int bv_transpose_bf16_batched(const bv_tr_leaf* leaves, int nleaves, int total_tiles, void* stream);
 /* y[i][0] = cls, y[i][1+l] = x[i][l] (cls-token concat, models/vit.py:223-225), fp32. */
 int bv_concat_cls(const float* cls, const float* x, float* y, int n, int L, int D, void* stream);
 

@@ -291,22 +291,36 @@ def test_context_kinds_full_then_gelu_free_then_light(dry):
   assert calls["bv_layernorm_fwd_bf16x"] == (2 * BLOCKS + 2) * 4 + 2 * BLOCKS * 4 and calls["bv_layernorm_bwd_y"] == 0
 
 
-def test_frozen_tower_weights_are_transposed_once(dry):
-  """LiT (schedule [("img/.*", None), ...]): the frozen image tower's [out][in] weight images are rebuilt only when
-  the store is re-cast (init / load), not after every optimizer step - the trainable text tower's are."""
+def test_weight_images_refresh_in_one_launch_and_frozen_ones_once(dry):
+  """The [out][in] bf16 images of the projection kernels (engine._W.bf_t): transposed one by one when first used,
+  then all trainable ones in ONE table-driven launch per optimizer step.  LiT (schedule [("img/.*", None), ...]):
+  the frozen image tower's images are rebuilt only when the store is re-cast (init / load)."""
   calls, _ = dry
   fn, state, batch = _setup(_cfg(schedule=[("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]))
   calls.clear()
   state, _ = fn(state, None, batch)
   first = calls["bv_transpose_bf16"]
-  calls.clear()
-  state, _ = fn(state, None, batch)
-  second = calls["bv_transpose_bf16"]
-  assert 0 < second < first, (first, second)
-  calls.clear()
-  state, _ = fn(state, None, batch)
-  assert calls["bv_transpose_bf16"] == second
+  assert first > BLOCKS * 4 and calls["bv_transpose_bf16_batched"] == 0      # >= qkv, out, fc1, fc2 per block
+  for _ in range(2):
+    calls.clear()
+    state, _ = fn(state, None, batch)
+    assert calls["bv_transpose_bf16"] == 0 and calls["bv_transpose_bf16_batched"] == 1     # the text tower's
   state["params"].store.mark_dirty()          # what load_tree() does: every image is stale again
   calls.clear()
   state, _ = fn(state, None, batch)
-  assert calls["bv_transpose_bf16"] == first
+  assert calls["bv_transpose_bf16"] == 0 and calls["bv_transpose_bf16_batched"] == 2       # trainable + frozen
+
+
+def test_batched_transpose_table_layout(dry):
+  """ops.transpose_table packs struct bv_tr_leaf (include/bvhip.h): 48 bytes, ascending tile prefix."""
+  assert ops.TR_LEAF.itemsize == 48
+  a, at = torch.zeros((100, 130), dtype=torch.bfloat16), torch.zeros((130, 104), dtype=torch.bfloat16)
+  b, bt = torch.zeros((64, 64), dtype=torch.bfloat16), torch.zeros((64, 64), dtype=torch.bfloat16)
+  table, n, tiles = ops.transpose_table([(a, at[:, :100]), (b, bt)], "cpu")
+  rec = table.numpy().view(ops.TR_LEAF)
+  assert (n, tiles) == (2, 2 * 3 + 1)
+  assert [int(x) for x in rec["tile0"]] == [0, 6] and [int(x) for x in rec["tiles_x"]] == [3, 1]
+  assert (int(rec["lds"][0]), int(rec["ldd"][0]), int(rec["rows"][0]), int(rec["cols"][0])) == (130, 104, 100, 130)
+  assert int(rec["src"][1]) == b.data_ptr() and int(rec["dst"][1]) == bt.data_ptr()
+  with pytest.raises(ValueError):
+    ops.transpose_table([(a, bt)], "cpu")

@@ -681,3 +681,56 @@ def test_transpose_bf16(dev, rows, cols):
   assert torch.equal(y, x.t().contiguous())
   wide = rnd((rows, cols + 8), dev, 4, dtype=BF16)
   assert torch.equal(ops.transpose_bf16(wide[:, :cols]), wide[:, :cols].t().contiguous())
+
+
+def test_transpose_bf16_batched(dev):
+  """One launch for a table of matrices (ragged shapes, a padded destination pitch, a strided source): every
+  destination is bit-equal to the transpose, pad columns and neighbours untouched."""
+  from big_vision_amd import ops
+  shapes = [(768, 2304), (64, 64), (70, 130), (3072, 768), (588, 1152), (1, 8), (768, 768)]
+  pairs, checks = [], []
+  for i, (rows, cols) in enumerate(shapes):
+    src = rnd((rows, cols + (8 if i % 2 else 0)), dev, 10 + i, dtype=BF16)[:, :cols]
+    pitch = (rows + 7) // 8 * 8 + (8 if i % 3 == 0 else 0)
+    dst = torch.full((cols, pitch), 7.0, device=dev, dtype=BF16)
+    pairs.append((src, dst[:, :rows]))
+    checks.append((src, dst, rows))
+  table, n, tiles = ops.transpose_table(pairs, dev)
+  ops.transpose_bf16_batched(table, n, tiles)
+  for src, dst, rows in checks:
+    assert torch.equal(dst[:, :rows], src.t())
+    assert bool((dst[:, rows:] == 7.0).all())
+
+
+def test_weight_images_follow_the_optimizer(dev):
+  """engine._W.bf_t after an optimizer step (one batched refresh) == the transpose of the new bf16 shadow, for every
+  projection kernel of both towers."""
+  import bv_oracle as O
+  from big_vision_amd import engine
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2)
+  model = two_towers.Model(image=dict(cfg, patch_size=(16, 16), pool_type="map"), text=dict(cfg, vocab_size=100),
+                           out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+  c = ConfigDict()
+  c.lr, c.wd, c.optax_name, c.total_steps, c.grad_clip_norm = 1e-2, 1e-2, "scale_by_adam", 10, 1.0
+  c.schedule = dict(decay_type="cosine", warmup_steps=0)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  image, text = image.to(dev), text.to(dev)
+  state, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=0, total_steps=10)
+  fn = siglip.make_update_fn(model, c)
+  store = state["params"].store
+  seen = []
+  for step in range(3):
+    state, _ = fn(state, None, {"image": image, "labels": text})
+    tw = engine._Twins.of(store)
+    ws = [r() for r in tw.members[False]]
+    assert len(ws) >= 4 * 4 and all(w is not None for w in ws)
+    store.refresh_shadow()
+    ws[0].bf_t()              # first stale image of the "next step": refreshes all of them
+    for w in ws:
+      assert w._t_ver == store.shadow_version
+      assert torch.equal(w._t[:, :w.bf.shape[0]], w.bf.t()), w.name
+    seen.append(ws[0]._t.float().clone())
+  assert not torch.equal(seen[0], seen[1]), "the optimizer did not move the weights: the test checks nothing"
