@@ -93,6 +93,20 @@ def _worker(rank, world, port, n, E, out):
   sync.launch(0, 1000); sync.finish()      # (state was reset by finish)
   buf2_sync = dp.GradSync(comm, buf2); buf2_sync.finish()
   assert torch.equal(buf2, base * sum(r + 1 for r in range(world)))
+  # ---- sharded optimizer ("fsdp" placement): reduce_scatter of the flat gradient buffer into per-rank slices,
+  # all_gather of the updated slices; the buffer length is not a multiple of the slice length
+  nflat, S = 1003, 512
+  ranks_sum = sum(r + 1 for r in range(world))
+  part = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
+  mine = comm.reduce_scatter_flat(part, S)
+  tot = torch.zeros(world * S, dtype=torch.float64)
+  tot[:nflat] = torch.arange(nflat, dtype=torch.float64) * ranks_sum
+  assert torch.equal(mine, tot[rank * S:(rank + 1) * S]), "reduce_scatter_flat: slice r = elements [r*S, (r+1)*S) of the sum"
+  lo, hi = rank * S, min((rank + 1) * S, nflat)
+  params = torch.full((nflat,), -1.0, dtype=torch.float64)
+  params[lo:hi] = mine[:hi - lo] + 1.0          # "update" of this rank's slice only
+  comm.all_gather_flat_(params, lo, hi, S)
+  assert torch.equal(params, tot[:nflat] + 1.0), "all_gather_flat_: every rank must end with every slice"
   comm.barrier()
   out.put((rank, loss.item()))
   dist.destroy_process_group()
@@ -122,3 +136,7 @@ def test_single_process_comm_is_identity():
   assert c.all_gather_rows(x) is x and c.reduce_scatter_rows(x) is x
   c.all_reduce_sum_(x); c.all_reduce_scalars_(x); c.barrier()
   assert torch.equal(x, torch.arange(6.0).view(3, 2))
+  flat = torch.arange(5.0)
+  assert torch.equal(c.reduce_scatter_flat(flat, 8), torch.tensor([0., 1., 2., 3., 4., 0., 0., 0.]))
+  c.all_gather_flat_(flat, 0, 5, 8)
+  assert torch.equal(flat, torch.arange(5.0))
