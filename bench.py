@@ -388,6 +388,7 @@ def main():
                                "activation contexts in HBM)")
                               if n > args.microbatch else "none",
                  "parallelism": f"dp{world}", "final_loss": loss,
+                 "img_per_sec_per_core": value / world,   # the reference's own rate figure (utils.py:506, Chrono.tick)
                  "peak_hbm_gb": round(r["peak"] / 1e9, 1),
                  "host_enqueue_ms_idle_gpu": host_unblocked_ms,
                  "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * host_dt / args.steps},
