@@ -136,7 +136,8 @@ def test_sgemm_strided(dev):
 
 
 # ------------------------------------------------------------- LayerNorm -----
-@pytest.mark.parametrize("rows,D", [(1568, 768), (37, 128), (64, 1024), (9, 384)])
+# (70 001 x 768 fp32 = 215 MB: above the size at which the kernels switch to non-temporal loads, layernorm.hip ln_nt_for)
+@pytest.mark.parametrize("rows,D", [(1568, 768), (37, 128), (64, 1024), (9, 384), (70001, 768)])
 def test_layernorm(dev, rows, D):
   from big_vision_amd import ops
   x = rnd((rows, D), dev, 1, 2.0) + 0.5
