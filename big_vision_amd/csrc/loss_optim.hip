@@ -289,6 +289,27 @@ struct AdamArgs {
   float sched[BV_MAX_SCHED];
 };
 
+// Streaming accesses of the optimizer pass: master weights, gradients and moments are each touched once per step
+// and are far larger than any cache (the bf16 shadow is what the next forward reads: plain stores).
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+  const f32x4_nt t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint2 ldnt2(const uint32_t* p) {
+  const u32x2_nt t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_nt*>(p));
+  return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ void stnt4(float* p, const float4& v) {
+  f32x4_nt t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+}
+__device__ __forceinline__ void stnt2(uint32_t* p, const uint2& v) {
+  u32x2_nt t; t.x = v.x; t.y = v.y;
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x2_nt*>(p));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, long nchunks) {
   __shared__ double shd[2][256];
   float clip = 1.f;
@@ -305,15 +326,15 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, long nchunks) {
     const bv_adam_seg hp = a.segs[a.chunk_seg[c]];
     const float sched = a.sched[hp.sched_idx & (BV_MAX_SCHED - 1)];
     const long i = c * 1024 + threadIdx.x * 4;
-    const float4 p4 = *reinterpret_cast<const float4*>(a.p + i);
-    const float4 g4 = *reinterpret_cast<const float4*>(a.g + i);
-    const float4 v4 = *reinterpret_cast<const float4*>(a.nu + i);
+    const float4 p4 = ldnt4(a.p + i);
+    const float4 g4 = ldnt4(a.g + i);
+    const float4 v4 = ldnt4(a.nu + i);
     float m[4];
     if (a.mu_bf16) {
-      const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(a.mu) + i);
+      const uint2 u = ldnt2(reinterpret_cast<const uint32_t*>(reinterpret_cast<const bf16*>(a.mu) + i));
       m[0] = bflo(u.x); m[1] = bfhi(u.x); m[2] = bflo(u.y); m[3] = bfhi(u.y);
     } else {
-      const float4 m4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.mu) + i);
+      const float4 m4 = ldnt4(reinterpret_cast<const float*>(a.mu) + i);
       m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
     }
     float p[4] = {p4.x, p4.y, p4.z, p4.w};
@@ -332,15 +353,15 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a, long nchunks) {
     }
     sp += (double)cp;
     su += (double)cu;
-    *reinterpret_cast<float4*>(a.p + i) = make_float4(p[0], p[1], p[2], p[3]);
-    *reinterpret_cast<float4*>(a.nu + i) = make_float4(v[0], v[1], v[2], v[3]);
+    stnt4(a.p + i, make_float4(p[0], p[1], p[2], p[3]));
+    stnt4(a.nu + i, make_float4(v[0], v[1], v[2], v[3]));
     if (a.mu_bf16) {
       uint2 u;
       u.x = pack_bf2(m[0], m[1]);
       u.y = pack_bf2(m[2], m[3]);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(a.mu) + i) = u;
+      stnt2(reinterpret_cast<uint32_t*>(reinterpret_cast<bf16*>(a.mu) + i), u);
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.mu) + i) = make_float4(m[0], m[1], m[2], m[3]);
+      stnt4(reinterpret_cast<float*>(a.mu) + i, make_float4(m[0], m[1], m[2], m[3]));
     }
     if (a.shadow) {
       uint2 u;
