@@ -3,7 +3,7 @@
 # arithmetic, with the bf16-stream object and the CPU baseline), the rank shapes of N = 2 / 4 / 8 on one GPU, the N = 8
 # shape with the one-rank RCCL collectives in the loop, rocprofv3 kernel stats of the bench command and of the n = 512
 # shape, and the two --pmc passes (FETCH_SIZE / WRITE_SIZE, counters only - never combined with tracing domains).
-#   bash tools/gpu_final.sh [notests] [slow] [yard]     (slow: the full-depth L/16@336 case; yard: the vendor GEMM yardstick)
+#   bash tools/gpu_final.sh [notests] [slow] [yard]     (slow: the full-depth L/16@336 case; yard: the vendor yardsticks - GEMM, fused epilogues, attention, LayerNorm / Adam, whole step)
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
@@ -33,5 +33,9 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.cs
 timeout 900 python tools/bench_configs.py c2 c4 c5 c5b --steps 5 > $O/bench_configs.jsonl 2> $O/bench_configs.err; cut -c1-200 $O/bench_configs.jsonl
 if [[ " $* " == *" yard "* ]]; then
   timeout 500 python tools/gemm_yardstick.py > $O/gemm_yardstick.txt 2> $O/gemm_yardstick.err; tail -12 $O/gemm_yardstick.txt | cut -c1-160
+  timeout 200 python tools/gemm_epilogue_yardstick.py > $O/gemm_epilogue_yardstick.txt 2> /dev/null
+  timeout 200 python tools/attn_yardstick.py > $O/attn_yardstick.txt 2> /dev/null
+  timeout 200 python tools/hbm_yardstick.py > $O/hbm_yardstick.txt 2> /dev/null
+  timeout 400 python tools/step_yardstick.py --batch 512 1024 256 > $O/step_yardstick.jsonl 2> /dev/null; cut -c1-200 $O/step_yardstick.jsonl
 fi
 ls -la $O
