@@ -31,6 +31,7 @@ PROTOTYPES = {
     "bv_gemm_pre_issue": [c_int],
     "bv_gemm_roll": [c_int],
     "bv_gemm_reserve_cus": [c_int],
+    "bv_gemm256_calls": [c_int],
     "bv_set_workspace": [P, c_long],
     "bv_set_stream_workspace": [P, P, c_long],
     "bv_gemm_workspace_bytes": [c_int, c_int, c_int],
@@ -98,7 +99,7 @@ PROTOTYPES.update({
     "bv_comm_all_reduce_bucket": [P, P, c_long, c_long, c_int, P],
 })
 
-RESTYPES = {"bv_gemm_workspace_bytes": c_long}   # everything else returns an int status
+RESTYPES = {"bv_gemm_workspace_bytes": c_long, "bv_gemm256_calls": c_long}   # everything else returns an int status
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)
 

@@ -1257,6 +1257,8 @@ static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1;
 // The data-parallel trainer reserves as many CUs as RCCL has channels for the backward, where the
 // per-block gradient all-reduces run beside the GEMMs (dp.py).
 static int g_reserve = 0;
+static long g_calls[3] = {0, 0, 0};   // bv_gemm256_calls: all / multi-tile walks / multi-tile walks with a fused epilogue
+extern "C" long bv_gemm256_calls(int which) { return which >= 0 && which < 3 ? g_calls[which] : -1; }
 extern "C" int bv_gemm_reserve_cus(int n) {
   const int old = g_reserve;
   if (n >= 0) g_reserve = n > 128 ? 128 : n;
@@ -1394,6 +1396,11 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   const int cus = 256 - g_reserve;
   dim3 grid(nwork < cus ? nwork : cus), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
+  ++g_calls[0];
+  if (nwork > (int)grid.x) {
+    ++g_calls[1];
+    if ((epilogue != BV_EPI_NONE && epilogue != BV_EPI_ATOMIC) || colsum) ++g_calls[2];
+  }
   // rolling-epilogue kernel: k-major, at least two K-tiles per tile, the epilogues it implements
   const bool roll = km && nk >= 2 && !colsum &&
                     (((g_roll & 2) && epilogue == BV_EPI_NONE && !out_f32) ||

@@ -123,6 +123,12 @@ int bv_gemm_roll(int mask);
  * Its workgroups fill a CU, so kernels that must run BESIDE it (RCCL collectives overlapping the
  * backward) need CUs of their own; the data-parallel trainer reserves one per RCCL channel. */
 int bv_gemm_reserve_cus(int n);
+/* Diagnostics for the parity suite: launches bv_gemm_bf16[_colsum] has put on the 256x256 kernels since the
+ * library was loaded.  which = 0: all of them; 1: only launches in which a persistent workgroup walks more than
+ * one tile (work items > workgroups); 2: those of (1) with a fused epilogue (anything but BV_EPI_NONE /
+ * BV_EPI_ATOMIC) or fused column sums.  Tests assert that a case really ran where it claims to
+ * (tests/test_siglip_step_gpu.py::test_b16_depth2_n64_image_tower_on_gemm256). */
+long bv_gemm256_calls(int which);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,

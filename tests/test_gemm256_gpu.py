@@ -259,3 +259,100 @@ def test_reserved_cus_change_nothing_but_the_grid(dev, fast):
   assert torch.equal(y0, y1)
   close(g1, g0, 1e-5, 1e-3, "dW with 4 reserved CUs")
   close(g0, a.float().T @ dy.float(), 1e-4, 2e-2, "dW")
+
+
+# ---- round 4: every fused epilogue the step uses, at shapes where each persistent
+# workgroup walks 2-4 tiles (588-783 tiles on 256 CUs: DMA ring across tile boundaries, XCD work order,
+# rolling epilogue, atomics-based column sums over 49-261 M-tiles), against fp64 - full matrices, not spot
+# checks.  The shapes are the image tower's at n = 64 (12 544 = 49 x 256 token rows) and the longest
+# rolling walk of the suite (66 816 rows, N = K = 768).  With 4 CUs reserved the same again (the grid an
+# overlapped backward leaves to the GEMMs, dp.reserve_cus_for_collectives).
+MULTI_TILE_SHAPES = [(12544, 3072, 768), (12544, 768, 3072), (12544, 2304, 768), (66816, 768, 768)]
+
+
+def _gelu_tanh64(h):
+  return torch.nn.functional.gelu(h, approximate="tanh")
+
+
+def _dgelu_tanh64(h):
+  h = h.detach().clone().requires_grad_(True)
+  _gelu_tanh64(h).sum().backward()
+  return h.grad
+
+
+def _rel_l2(a, b):
+  return ((a.double() - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("reserve", [0, 4])
+@pytest.mark.parametrize("M,N,K", MULTI_TILE_SHAPES)
+def test_fused_epilogues_multi_tile_vs_fp64(dev, fast, M, N, K, reserve):
+  from big_vision_amd import ops, _lib
+  lib = _lib.load()
+  x = rnd((M, K), dev, 31, dtype=BF16)
+  w = rnd((N, K), dev, 32, 1.0 / K ** 0.5, dtype=BF16)
+  b = rnd((N,), dev, 33)
+  kw = dict(a_kmajor=True, b_kmajor=True)
+  acc = x.double() @ w.double().T            # fp64 product of the bf16-rounded operands
+  pre = acc + b.double()
+  res = rnd((M, N), dev, 34, 2.0)
+  hh = rnd((M, N), dev, 35, dtype=BF16)       # a stored pre-activation (light contexts)
+  L = 196
+  pos = rnd((L, N), dev, 36)
+  old = lib.bv_gemm_reserve_cus(reserve)
+  try:
+    # plain +bias (QKV / dX shapes), bf16 and fp32 outputs
+    close(ops.gemm(x, w, bias=b, out_dtype=F32, **kw), pre, 1e-4, 2e-3, "bias f32")
+    close(ops.gemm(x, w, bias=b, out_dtype=BF16, **kw), pre, 1e-2, 1e-2, "bias bf16")
+    # +residual on the fp32 stream (the rolling kernel) and on the bf16 stream
+    y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
+    close(y, pre + res.double(), 1e-4, 2e-3, "residual f32")
+    assert torch.equal(y, ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)), \
+        "residual f32: run-to-run difference"
+    resb = res.to(BF16)
+    close(ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_RESIDUAL, aux=resb, **kw), pre + resb.double(),
+          1e-2, 2e-2, "residual bf16")
+    # + position embedding (stem epilogue): aux row = token row mod L
+    if M % L == 0:
+      y = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=L, **kw)
+      close(y, pre + pos.double().repeat(M // L, 1), 1e-4, 2e-3, "pos")
+    # forward GELU: both outputs (h rounded to bf16, g = gelu of that rounded h)
+    g = torch.empty((M, N), device=dev, dtype=BF16)
+    h = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g, **kw)
+    close(h, pre, 1e-2, 1e-2, "gelu: h")
+    close(g, _gelu_tanh64(h.double()), 1e-2, 1e-2, "gelu: g")
+    # forward GELU_GD: g and gelu'(pre) from the fp32 pre-activation
+    g4 = torch.empty((M, N), device=dev, dtype=BF16)
+    d4 = torch.empty((M, N), device=dev, dtype=BF16)
+    ops.gemm(x, w, bias=b, out=g4, epilogue=ops.EPI_GELU_GD, out2=d4, **kw)
+    close(g4, _gelu_tanh64(pre), 1e-2, 1e-2, "gelu_gd: g")
+    close(d4, _dgelu_tanh64(pre), 1e-2, 1e-2, "gelu_gd: g'")
+    # backward GELU' x aux (+ emitted gelu, + fused column sums = the Dense_0 bias gradient)
+    ref_bwd = acc * _dgelu_tanh64(hh.double())
+    csref = ref_bwd.sum(0)
+    cstol = 2e-3 * ref_bwd.abs().sum(0).max().item()
+    cs = torch.ones((N,), device=dev, dtype=F32)
+    g2 = torch.empty((M, N), device=dev, dtype=BF16)
+    o = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=hh, out2=g2, colsum=cs, **kw)
+    close(o, ref_bwd, 1e-2, 2e-2, "gelu' emit: dX")
+    close(g2, _gelu_tanh64(hh.double()), 1e-2, 1e-2, "gelu' emit: g")
+    close(cs, 1.0 + csref, 1e-3, cstol, "gelu' emit: column sums")
+    assert _rel_l2(cs - 1.0, csref) < 5e-3, "gelu' emit: column sums rel-L2"
+    cs = torch.zeros((N,), device=dev, dtype=F32)
+    o2 = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=hh, colsum=cs, **kw)
+    assert torch.equal(o2, o), "GELU_BWD and GELU_BWD_EMIT disagree on dX"
+    close(cs, csref, 1e-3, cstol, "gelu': column sums")
+    # the emitted activation has the forward's bits
+    g3 = torch.empty((M, N), device=dev, dtype=BF16)
+    ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=h, out2=g3, **kw)
+    assert torch.equal(g3, g), "re-emitted gelu(h) differs from the forward's"
+    # backward MUL (full contexts) + fused column sums
+    dd = _dgelu_tanh64(hh.double()).to(BF16)
+    ref_mul = acc * dd.double()
+    cs = torch.zeros((N,), device=dev, dtype=F32)
+    o5 = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_MUL, aux=dd, colsum=cs, **kw)
+    close(o5, ref_mul, 1e-2, 2e-2, "mul: dX")
+    close(cs, ref_mul.sum(0), 1e-3, 2e-3 * ref_mul.abs().sum(0).max().item(), "mul: column sums")
+    assert _rel_l2(cs, ref_mul.sum(0)) < 5e-3, "mul: column sums rel-L2"
+  finally:
+    lib.bv_gemm_reserve_cus(old)
