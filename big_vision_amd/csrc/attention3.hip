@@ -911,10 +911,18 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
 // the common sequence lengths (64 text tokens; 196/197 at 224 px; 256/257; 441 at 336 px; 576 at
 // 384 px), the next instantiated size otherwise.
 static int g_a3cfg = 0;
-// A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel
+static int g_a5_off = 0;   // 1: keep the two-launch backward also where the one-launch kernel (attention5.hip) applies
+// attention5.hip: the backward in one launch (unmasked, L <= 64 or 193..208); -100 = shape not covered
+int bv_attn5_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
+                 int L, int H, void* stream);
+// A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel;
+// +32 / +64 = 32-key dK/dV kernels; +128 = two-launch backward instead of attention5.hip
 extern "C" int bv_attn_tune(int cfg) {
-  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0);
-  if (cfg >= 0) { g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); g_a4_dkv = (cfg & 64) ? 2 : (cfg & 32) ? 1 : 0; }
+  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0) | (g_a5_off ? 128 : 0);
+  if (cfg >= 0) {
+    g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); g_a4_dkv = (cfg & 64) ? 2 : (cfg & 32) ? 1 : 0;
+    g_a5_off = (cfg & 128) != 0;
+  }
   return old;
 }
 
@@ -933,6 +941,10 @@ int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n,
 int bv_attn3_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                  float* dbias, const int* kv_len, int n, int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (!kv_len && !g_a5_off) {
+    const int rc = bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, dbias, n, L, H, stream);
+    if (rc != -100) return rc;
+  }
   if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
   if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
   if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);

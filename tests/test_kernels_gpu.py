@@ -361,6 +361,46 @@ def _attention_case(dev, n, L, H):
   assert_close(db, 0.5 + cs, 2e-2, 2e-2 * g.abs().sum(0).max().item(), "fused qkv bias grad")
 
 
+@pytest.mark.parametrize("n,L,H", [(48, 196, 12), (40, 197, 12), (160, 64, 12), (30, 208, 4), (300, 33, 3)])
+def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
+  """attention5.hip (the backward in one launch: persistent workgroups, loader waves prefetching the next
+  (sample, head) pair) on more pairs than workgroups, so every workgroup walks 2-3 pairs: vs fp64 on the same
+  bf16 inputs, vs the two-launch kernels of attention3.hip (bv_attn_tune(128)), run-to-run bit-equal (the delta
+  partials are summed in a fixed order), and the fused q/k/v bias gradients."""
+  from big_vision_amd import ops, _lib
+  lib = _lib.load()
+  qkv = rnd((n * L, 3 * H * 64), dev, 21, 1.5, dtype=BF16)
+  d_o = rnd((n * L, H * 64), dev, 22, dtype=BF16)
+  o, lse = ops.attn_fwd(qkv, n, L, H)
+  qr = qkv.double().requires_grad_(True)
+  o_ref, _ = _attn_ref(qr, n, L, H)
+  o_ref.backward(d_o.double())
+  g = qr.grad
+  db = torch.zeros((3 * H * 64,), device=dev)
+  d5 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
+  d5b = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+  assert torch.equal(d5, d5b), "run-to-run / dbias-variant difference"
+  old = lib.bv_attn_tune(-1)
+  lib.bv_attn_tune(old | 128)
+  try:
+    db3 = torch.zeros((3 * H * 64,), device=dev)
+    d3 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db3)
+  finally:
+    lib.bv_attn_tune(old)
+  gmax = g.abs().max().item()
+  assert_close(d5, g, 3e-2, 3e-2 * gmax, "one-launch dqkv vs fp64")
+  gv = g.view(n * L, 3, H * 64)
+  for j, name in enumerate(("dq", "dk", "dv")):
+    r5 = ((d5.double().view(n * L, 3, -1)[:, j] - gv[:, j]).norm() / gv[:, j].norm()).item()
+    r3 = ((d3.double().view(n * L, 3, -1)[:, j] - gv[:, j]).norm() / gv[:, j].norm()).item()
+    print(f"rel-L2 {name}: one launch {r5:.5f}, two launches {r3:.5f}")
+    assert r5 <= max(1.15 * r3, 6e-3), (name, r5, r3)
+  cs = g.sum(0)
+  tol = 2e-2 * g.abs().sum(0).max().item()
+  assert_close(db, cs, 2e-2, tol, "one-launch bias gradients vs fp64")
+  assert_close(db, db3, 2e-2, tol, "one-launch vs two-launch bias gradients")
+
+
 def test_attention_peaked_softmax(dev):
   """One key dominates each row (large logits): exercises the max-subtraction."""
   from big_vision_amd import ops
