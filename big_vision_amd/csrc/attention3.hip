@@ -912,16 +912,20 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
 // 384 px), the next instantiated size otherwise.
 static int g_a3cfg = 0;
 static int g_a5_off = 0;   // 1: keep the two-launch backward also where the one-launch kernel (attention5.hip) applies
+extern int g_a5_bias_dpp;  // attention5.hip
 // attention5.hip: the backward in one launch (unmasked, L <= 64 or 193..208); -100 = shape not covered
 int bv_attn5_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
                  int L, int H, void* stream);
 // A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel;
-// +32 / +64 = 32-key dK/dV kernels; +128 = two-launch backward instead of attention5.hip
+// +32 / +64 = 32-key dK/dV kernels; +128 = two-launch backward instead of attention5.hip; +256 = attention5.hip
+// reduces the bias gradients with DPP column sums instead of the identities
 extern "C" int bv_attn_tune(int cfg) {
-  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0) | (g_a5_off ? 128 : 0);
+  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0) | (g_a5_off ? 128 : 0) |
+                  (g_a5_bias_dpp ? 256 : 0);
   if (cfg >= 0) {
     g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); g_a4_dkv = (cfg & 64) ? 2 : (cfg & 32) ? 1 : 0;
     g_a5_off = (cfg & 128) != 0;
+    g_a5_bias_dpp = (cfg & 256) != 0;
   }
   return old;
 }

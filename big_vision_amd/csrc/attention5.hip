@@ -29,19 +29,78 @@
 // PL = R * 8 + 64.  The 1b store (lane = key, 4 consecutive q) is a ds_write_b64 whose 16-lane groups cover 128
 // contiguous bytes; the phase-2 transposed read (ds_read_b64_tr_b16: 16 lanes fetch a [4 keys][16 q] block) touches
 // 4 planes x 32 contiguous bytes per lane group of 16, planes 16 dwords apart mod 64 banks: conflict-free both ways.
+#include <type_traits>
 #include "attn_common.h"
 #include "bvhip_internal.h"
 #ifndef A5_UNROLL_1A
 #define A5_UNROLL_1A 1
 #endif
+// A5_ABL != 0 only in tools/probes/attn5_probe.hip (ablations, results are garbage): 1 = no phase 1a loop, 2 = no
+// phase 1b loop, 4 = no phase 2 loop, 16 = no global stores, 32 = the loader waves load nothing; A5_STAMPS: s_memtime
+// stamps of waves 0 / KF-1 / KF (first loader) of four mid-launch workgroups
+#ifndef A5_ABL
+#define A5_ABL 0
+#endif
+// schedule knobs (swept by tools/probes/attn5_probe.hip; the defaults are the measured best)
+#ifndef A5_UNROLL_1B
+#define A5_UNROLL_1B 1
+#endif
+#ifndef A5_UNROLL_P2
+#define A5_UNROLL_P2 2
+#endif
+#ifndef A5_SB_1B
+#define A5_SB_1B 1      // sched_barrier between the two fragments of a phase-1b pair and in front of its MFMA block
+#endif
+#ifdef A5_STAMPS
+__device__ long* g_a5_stamps;
+#define A5_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if (lane == 0 && (wave == 0 || wave == KF - 1 || wave == KF) && blockIdx.x >= 100 && blockIdx.x < 104 && \
+        pair == blockIdx.x + 2 * stride)                                                              \
+      g_a5_stamps[((blockIdx.x - 100) * 3 + (wave == 0 ? 0 : wave == KF - 1 ? 1 : 2)) * 16 + (k)] =   \
+          __builtin_amdgcn_s_memtime();                                                               \
+  } while (0)
+#else
+#define A5_STAMP(k)
+#endif
+
+int g_a5_bias_dpp = 0;   // 1: bias gradients by DPP column sums also where the identities apply (A/B, bv_attn_tune bit 256)
 
 namespace {
 using namespace bvattn;
+// register arrays of 16-byte pieces: a first-class vector type (arrays of HIP's uint4 STRUCT were left in scratch memory)
+typedef unsigned int a5_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void a5_drain(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
   // wait states between the last MFMAs of a loop and VALU reads of their results behind control flow
   // (hipcc pads the hazard inside a basic block only, see attention3.hip)
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// An opaque copy of a lane-dependent value.  Every phase derives its LDS / global addresses from its own copy of the
+// lane id, so hipcc cannot hoist two dozen address registers out of the pair loop and keep them live through the
+// phases that sit at the 128-VGPR line (it spilled them to scratch and reloaded them in front of MFMAs).
+__device__ __forceinline__ int a5_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// Sum over the four 16-lane rows of a wave (every lane gets the total): two lane-swap VALU operations instead of two
+// ds_bpermute round trips through the LDS crossbar.  Inline asm: the builtins of ROCm 7.2 drop the second result
+// (__builtin_amdgcn_permlane32_swap(x, y)[1] reads the FIRST destination register - checked in the ISA).
+//   v_permlane32_swap a, b: a' = {a.lanes 0-31, b.lanes 0-31}, b' = {a.lanes 32-63, b.lanes 32-63}
+//   v_permlane16_swap a, b: a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}
+__device__ __forceinline__ float a5_xsum4(float x) {
+#ifdef A5_XSUM_SHFL
+  return xsum4(x);
+#else
+  float a = x, b = x;
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  x = a + b;
+  a = x; b = x;
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+#endif
 }
 
 // transposed read of a dS^T plane tile: lane lr of a 16-lane group receives keys (row4 .. row4 + 3) of query
@@ -72,21 +131,54 @@ struct A5 {
   static constexpr int OFF_LSE = OFF_DS + KF * TS;
   static constexpr int OFF_DEL = OFF_LSE + R * 4;
   static constexpr int OFF_RED = OFF_DEL + R * 4;
-  static constexpr int LDS = OFF_RED + KF * 192 * 4;
-  static_assert(KF * 4 * R * 4 <= KF * TS, "delta partials overlay the dS^T tiles");
-  static_assert(NT <= 1024 && R <= NTC && 192 <= NTC, "workgroup shape");
+  static constexpr int RED = KF * 192 * 4 > KF * R * 4 ? KF * 192 * 4 : KF * R * 4;   // column sums | delta partials [KF][R]
+  static constexpr int OFF_CSO = OFF_RED + RED;
+  static constexpr int OFF_CST = OFF_CSO + NTL * 8 * 4;   // per loader lane: column sums of its 8-column chunk of dO
+  static constexpr int LDS = OFF_CST + 64 * 4;            // their totals of the current pair, [64]
+  static_assert(NT <= 1024 && R * 4 == NTC && 192 <= NTC && TS >= 2048, "workgroup shape");
+  static_assert(NTL % 8 == 0, "a loader lane keeps one column chunk");
 };
+
+// 16 rows x 64 columns of fp32 accumulators in MFMA C layout (lane (lr, lg): row lr, columns d * 16 + 4 lg .. + 3 of
+// acc[d]) -> bf16 -> a wave-private 2 KiB LDS image -> whole 128-byte rows -> global, 16 bytes per lane.  The scattered
+// form (sixteen 8-byte stores per lane, 32 bytes per row and instruction) is store-ISSUE bound: ~10 k cycles per
+// (sample, head) pair, a quarter of the first version of this kernel (profiles/r04_attn5_probe.txt).
+__device__ __forceinline__ void a5_store_rows(char* S, const f32x4 (&acc)[4], float mul, bf16* base, long ld, int row0,
+                                              int L, int lane, bool enable) {
+  const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint2 w;
+    w.x = pack_bf2(acc[d][0] * mul, acc[d][1] * mul);
+    w.y = pack_bf2(acc[d][2] * mul, acc[d][3] * mul);
+    *reinterpret_cast<uint2*>(S + lr * 128 + (((d * 2 + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8) = w;
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(S + row * 128 + ((ch ^ (row & 7)) << 4));
+    if (enable && row0 + row < L) *reinterpret_cast<uint4*>(base + (long)(row0 + row) * ld + ch * 8) = v;
+  }
+}
 
 // Workgroup = KF compute waves + LW loader waves.  The loader waves own the NEXT pair's Q / dO tiles (in registers,
 // loaded right after the current pair's tiles became visible, i.e. in flight during the whole pair) and write them
 // into the LDS tiles as soon as those are free (dO after phase 1b, Q after phase 2): the compute waves sit at the
 // 128-VGPR line of four waves per SIMD and cannot hold 17 prefetch registers on top of K, V, two accumulator sets
 // and the fragment operands (first version: 29-74 spilled VGPRs).  Every wave passes the same six barriers per pair.
-template <int KF, int LW, bool DBIAS>
+// BM: 0 = no bias gradients; 1 = column sums of dq / dk / dv by DPP reductions (any L; A/B only); 3 = the k and v
+// identities below + DPP column sums of dq (L % 16 == 0); 2 = all three by identities, for L % 16 != 0 (a padded
+// query column exists):
+//   sum_j dK_j = 0 exactly (shift invariance of the softmax: what autodiff produces there is rounding noise);
+//   sum_j dV_j = sum_i dO_i (rows of P sum to 1): column sums of the dO tile, taken by the loader waves from the
+//               registers they hold it in;
+//   sum_i dQ_i = scale * sum_j cs_j K_j with cs_j = sum_i dS_ij: every key-owning wave keeps cs of its keys in one
+//               register and plants it (bf16) in the LAST, padded, query column of the dS^T image - phase 2 then
+//               computes exactly this product as column R - 1 of dQ^T, for free.
+template <int KF, int LW, int BM>
 __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* __restrict__ qkv,
                                                                    const bf16* __restrict__ d_o,
                                                                    const float* __restrict__ lse,
-                                                                   float* __restrict__ delta,
                                                                    bf16* __restrict__ dqkv,
                                                                    float* __restrict__ dbias, int L, int H,
                                                                    int npairs, float scale) {
@@ -95,11 +187,13 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;                 // Q tile; K tile in phase 2
   char* Gt = smem + C::OFF_G;      // dO tile
-  char* dSt = smem + C::OFF_DS;    // KF dS^T tiles; the delta partials [KF][4][R] of phase 1a overlay them
-  float* dpart = reinterpret_cast<float*>(dSt);
+  char* dSt = smem + C::OFF_DS;    // KF tiles: P (bf16, [q][key] planes) after phase 1a, dS^T ([key][q] planes) after 1b
   float* lse_s = reinterpret_cast<float*>(smem + C::OFF_LSE);
   float* del_s = reinterpret_cast<float*>(smem + C::OFF_DEL);
-  float* red = reinterpret_cast<float*>(smem + C::OFF_RED);   // [KF waves][3][64] column sums of dq / dk / dv
+  float* red = reinterpret_cast<float*>(smem + C::OFF_RED);   // BM 1: [KF waves][3][64] column sums; BM 2: [64] (dq)
+  float* dpart = red;              // phase 1a -> reduction: [KF][R] partials of delta (the column sums come later)
+  float* cso = reinterpret_cast<float*>(smem + C::OFF_CSO);   // BM 2: [loader lane][8] column sums of its dO pieces
+  float* cst = reinterpret_cast<float*>(smem + C::OFF_CST);   // BM 2: [64] column sums of the pair's dO = v-bias gradient
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
@@ -109,80 +203,144 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
 
   if (wave >= KF) {
     // ================================================================ loader waves ==========================
-    const int ll = tid - C::NTC;
-    uint4 pq[NPL], pg[NPL];
+    const int ll0 = tid - C::NTC;
+    a5_u32x4 pq[NPL], pg[NPL];
     float pl[(R + NTL - 1) / NTL];
-    auto load_tiles = [&](int pair) {
+    auto load_tiles = [&](int pair) __attribute__((always_inline)) {
       const int i = pair / H, h = pair % H;
-      const bf16* qb_ = qkv + (long)i * L * ld + h * DH;
-      const bf16* dob_ = d_o + (long)i * L * ldo + h * DH;
+      // wave-uniform 64-bit bases + 32-bit lane offsets (a tile spans < 1 MB): one address register per piece
+      const char* qb_ = reinterpret_cast<const char*>(qkv + (long)i * L * ld + h * DH);
+      const char* dob_ = reinterpret_cast<const char*>(d_o + (long)i * L * ldo + h * DH);
+      const uint32_t ldb = (uint32_t)ld * 2u, ldob = (uint32_t)ldo * 2u;
+      const int ll = a5_opaque(ll0);   // per-pair address arithmetic instead of 40 hoisted (and spilled) registers
 #pragma unroll
       for (int j = 0; j < NPL; ++j) {
-        const int idx = ll + j * NTL, row = idx >> 3, pc = idx & 7;
-        pq[j] = make_uint4(0, 0, 0, 0);
-        pg[j] = make_uint4(0, 0, 0, 0);
-        if (row < L) {   // rows >= L (and pieces beyond the tile) stay zero
-          pq[j] = *reinterpret_cast<const uint4*>(qb_ + (long)row * ld + pc * 8);
-          pg[j] = *reinterpret_cast<const uint4*>(dob_ + (long)row * ldo + pc * 8);
-        }
+        // branch-free: rows >= L re-read row L - 1 and are zeroed when they are USED (put_tile / put_cso) - with a
+        // branch per piece hipcc spilled the first pieces right behind their loads (a vmcnt wait in front of B2)
+        const int idx = ll + j * NTL, row = min(idx >> 3, L - 1), pc = idx & 7;
+        pq[j] = *reinterpret_cast<const a5_u32x4*>(qb_ + ((uint32_t)row * ldb + (uint32_t)pc * 16u));
+        pg[j] = *reinterpret_cast<const a5_u32x4*>(dob_ + ((uint32_t)row * ldob + (uint32_t)pc * 16u));
       }
 #pragma unroll
       for (int j = 0; j < (R + NTL - 1) / NTL; ++j) {
         const int q = ll + j * NTL;
         // rows >= L: lse = +inf makes P = exp2(-inf) = 0 without an explicit query mask
-        pl[j] = q < L ? lse[(long)pair * L + q] * LOG2E : INFINITY;
+        pl[j] = q < L ? lse[(long)pair * L + q] : INFINITY;
       }
     };
-    auto put_tile = [&](char* T, const uint4 (&pc_)[NPL]) {
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const int idx = ll + j * NTL, row = idx >> 3, pc = idx & 7;
-        if (idx < R * 8) *reinterpret_cast<uint4*>(T + row * 128 + ((pc ^ t64_swz(row)) << 4)) = pc_[j];
+    // rows >= L of a tile are zeroed ONCE (zero_pad_rows) and then left alone - nobody else writes them (the K rows
+    // that overlay the Q tile in phase 2 are zero there too), so the steady-state put needs no select (a select per
+    // piece cost the loader its registers: spills right behind the loads, i.e. a vmcnt wait in front of B2)
+    // (a macro, one expansion per register array: an array handed to a lambda BY REFERENCE stays in scratch memory)
+#define A5_PUT_TILE(T, arr)                                                                               \
+  do {                                                                                                    \
+    const int ll_ = a5_opaque(ll0);                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NPL; ++j) {                                                     \
+      const int idx = ll_ + j * NTL, row = idx >> 3, pc = idx & 7;                                        \
+      if (row < L) *reinterpret_cast<a5_u32x4*>((T) + row * 128 + ((pc ^ t64_swz(row)) << 4)) = arr[j];  \
+    }                                                                                                     \
+  } while (0)
+    auto zero_pad_rows = [&](char* T) __attribute__((always_inline)) {   // once, before the first put
+      for (int idx = ll0; idx < R * 8; idx += NTL) {
+        const int row = idx >> 3, pc = idx & 7;
+        if (row >= L) *reinterpret_cast<uint4*>(T + row * 128 + ((pc ^ t64_swz(row)) << 4)) = make_uint4(0, 0, 0, 0);
       }
     };
-    auto put_lse = [&]() {
+    auto put_lse = [&]() __attribute__((always_inline)) {
+      const int ll = a5_opaque(ll0);
 #pragma unroll
       for (int j = 0; j < (R + NTL - 1) / NTL; ++j) {
         const int q = ll + j * NTL;
-        if (q < R) lse_s[q] = pl[j];
+        // base-2 units; clamped from below so that exp2(0 - lse) of a PADDED key (k = v = 0: S = 0) stays finite
+        // instead of being masked per score (real rows: S c - lse <= 0 always; -120 is never reached by data)
+        if (q < R) lse_s[q] = fmaxf(pl[j] * LOG2E, -120.f);
+      }
+    };
+    // column sums of the dO tile held in pg: every piece of a lane is the same 8-column chunk (NTL % 8 == 0), so a
+    // lane sums its pieces in registers and leaves 8 partial sums; the compute side adds the NTL / 8 lanes of a chunk
+    auto put_cso = [&]() __attribute__((always_inline)) {
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 0.f;
+      const int ll = a5_opaque(ll0);
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const float m = ((ll + j * NTL) >> 3) < L ? 1.f : 0.f;   // pieces of rows >= L hold a copy of row L - 1
+        const uint32_t w[4] = {pg[j][0], pg[j][1], pg[j][2], pg[j][3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[2 * e] = __builtin_fmaf(m, bflo(w[e]), a[2 * e]);
+          a[2 * e + 1] = __builtin_fmaf(m, bfhi(w[e]), a[2 * e + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // piece by piece: no hoisted unpacking
+      }
+      float* dst = cso + ll * 8;
+      *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(a[4], a[5], a[6], a[7]);
+    };
+    // totals of the partial sums (one loader wave, behind a barrier that follows put_cso): cst[64].  Called right
+    // behind B1 (the partial sums of THIS pair were written in front of it), off every critical path: the compute waves
+    // read cst behind B6, the partial sums are overwritten behind B5.
+    auto put_cst = [&]() __attribute__((always_inline)) {
+      if (wave == KF) {
+        const int d = a5_opaque(lane), ch = d >> 3, e = d & 7;
+        float t = 0.f;
+#pragma unroll
+        for (int m = 0; m < NTL / 8; ++m) t += cso[(ch + 8 * m) * 8 + e];
+        cst[d] = t;
       }
     };
     int pair = blockIdx.x;
     if (pair < npairs) {
       load_tiles(pair);
-      put_tile(Gt, pg);
+      zero_pad_rows(Gt);
+      zero_pad_rows(Qt);
+      A5_PUT_TILE(Gt, pg);
       put_lse();
-      put_tile(Qt, pq);
+      A5_PUT_TILE(Qt, pq);
+      if constexpr (BM >= 2) put_cso();
     }
     for (; pair < npairs; pair += stride) {
       __syncthreads();   // B1: this pair's tiles are visible
       const int nxt = pair + stride;
-      if (nxt < npairs) load_tiles(nxt);
+      A5_STAMP(0);
+      // issued here, first USED behind B5: a loader wave must not wait for HBM in front of a barrier the compute
+      // waves arrive at earlier (the first version multiplied lse here: every B2 waited ~8 k cycles for the loads)
+      if (nxt < npairs && !(A5_ABL & 32)) load_tiles(nxt);
+      if constexpr (BM >= 2) put_cst();
+      A5_STAMP(1);
       __syncthreads();   // B2
       __syncthreads();   // B3
       __syncthreads();   // B4: the dO tile and lse are free
-      if (nxt < npairs) {
-        put_tile(Gt, pg);
-        put_lse();
-      }
       __syncthreads();   // B5
+      A5_STAMP(5);
+      if (nxt < npairs) {   // under phase 2 of the compute waves
+        A5_PUT_TILE(Gt, pg);
+        put_lse();
+        if constexpr (BM >= 2) put_cso();   // partial column sums of the NEXT pair's dO
+      }
+      A5_STAMP(6);
       __syncthreads();   // B6: the K tile (= Q tile) is free
-      if (nxt < npairs) put_tile(Qt, pq);
+      A5_STAMP(9);
+      if (nxt < npairs) A5_PUT_TILE(Qt, pq);
+      A5_STAMP(10);
     }
     return;
   }
 
   // ================================================================== compute waves ==========================
   bf16x8 k0, k1, v0, v1;
-  auto load_k = [&](int pair) {
+  auto load_k = [&](int pair) __attribute__((always_inline)) {
     const int i = pair / H, h = pair % H;
     const bf16* kb_ = qkv + (long)i * L * ld + (long)H * DH + h * DH;
+    const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
     const int kr = wave * 16 + lr;
     k0 = gfrag(kb_, ld, kr, L, lg * 8); k1 = gfrag(kb_, ld, kr, L, 32 + lg * 8);
   };
-  auto load_v = [&](int pair) {
+  auto load_v = [&](int pair) __attribute__((always_inline)) {
     const int i = pair / H, h = pair % H;
     const bf16* vb_ = qkv + (long)i * L * ld + 2L * H * DH + h * DH;
+    const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
     const int kr = wave * 16 + lr;
     v0 = gfrag(vb_, ld, kr, L, lg * 8); v1 = gfrag(vb_, ld, kr, L, 32 + lg * 8);
   };
@@ -196,40 +354,68 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
     const int i = pair / H, h = pair % H;
     const int nxt = pair + stride;
     __syncthreads();   // B1
+    A5_STAMP(0);
 
-    // ---- phase 1a: partials of delta.  S^T[key = 4 lg + r][q = lr] of (key fragment `wave`, query fragment f)
+    // ---- phase 1a: P^T and the partials of delta.  S^T[key = 4 lg + r][q = lr] of (key fragment `wave`, query
+    // fragment f); the operands of fragment f + 1 are read from the LDS before fragment f is computed.  P goes to the
+    // LDS as bf16 - block (f, wave) of tile f, [q = lr][4 keys of lane group lg] - where phase 1b fetches it back
+    // TRANSPOSED (ds_read_b64_tr_b16: P[q = 4 lg + r][key = lr]) instead of computing S and the exponentials again.
     {
-      const int lim = L - wave * 16 - lg * 4;   // key 4 lg + r of this wave's fragment exists for r < lim
-#pragma unroll A5_UNROLL_1A
-      for (int f = 0; f < KF; ++f) {
-        const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
-        const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
-        const float nl = -lse_s[f * 16 + lr];
+      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      struct Ops { bf16x8 q0, q1, g0, g1; float nl; };
+      auto rd = [&](int f) __attribute__((always_inline)) {
+        Ops o;
+        o.q0 = t64_row(Qt, f * 16 + lr, lg); o.q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
+        o.g0 = t64_row(Gt, f * 16 + lr, lg); o.g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
+        o.nl = -lse_s[f * 16 + lr];
+        return o;
+      };
+      auto go = [&](int f, const Ops& o) __attribute__((always_inline)) {
         f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-        st = mfma16(k0, q0, st);
-        st = mfma16(k1, q1, st);
-        dp = mfma16(v0, g0, dp);
-        dp = mfma16(v1, g1, dp);
+        st = mfma16(k0, o.q0, st);
+        st = mfma16(k1, o.q1, st);
+        dp = mfma16(v0, o.g0, dp);
+        dp = mfma16(v1, o.g1, dp);
+        // padded keys (k = v = 0): S = 0 and P = exp2(-lse) is finite (lse is clamped), dP = 0 exactly: they add
+        // nothing to delta, and whatever they leave in P / dS^T meets zero K rows / is never stored
+        f32x4 e;
         float x = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // padded keys have k = v = 0: S = 0, dP = 0, but exp2(-lse) may overflow: select, branch-free
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, nl));
-          x = __builtin_fmaf(r < lim ? e : 0.f, dp[r], x);
+          e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, o.nl));
+          x = __builtin_fmaf(e[r], dp[r], x);
         }
-        dpart[(wave * 4 + lg) * R + f * 16 + lr] = x;
-        if (f & 1) __builtin_amdgcn_sched_barrier(0);   // bound operand-read hoisting (register pressure)
+        *reinterpret_cast<s16x4*>(dSt + f * TS + lg * PL + (wave * 16 + lr) * 8) = pack4(e);
+        x = a5_xsum4(x);
+        if (lg == 0) dpart[wave * R + f * 16 + lr] = x;
+      };
+      constexpr int NF = (A5_ABL & 1) ? 1 : KF;
+      Ops a = rd(0), b = a;
+#pragma unroll 1
+      for (int f = 0; f < NF; f += 2) {
+        if (f + 1 < NF) b = rd(f + 1);
+        go(f, a);
+        if (f + 1 < NF) {
+          if (f + 2 < NF) a = rd(f + 2);
+          go(f + 1, b);
+        }
       }
     }
+    A5_STAMP(1);
     __syncthreads();   // B2
-    if (tid < R) {     // fixed-order sum of the KF x 4 partials of query row tid: deterministic
+    A5_STAMP(2);
+    {   // fixed-order sum of the KF partials of every query row (four lanes per row, quad reduction): deterministic
+      const int tq = wave * 64 + a5_opaque(lane), row = tq >> 2, part = tq & 3;
       float t = 0.f;
-#pragma unroll 4
-      for (int w = 0; w < KF * 4; ++w) t += dpart[w * R + tid];
-      del_s[tid] = t;
-      if (tid < L) delta[(long)pair * L + tid] = t;
+#pragma unroll
+      for (int w = 0; w < (KF + 3) / 4; ++w)
+        if (w * 4 + part < KF) t += dpart[(w * 4 + part) * R + row];
+      t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
+      t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));
+      if (part == 0) del_s[row] = -t;   // minus delta: phase 1b starts its dP accumulators from it
     }
     __syncthreads();   // B3: delta complete; the partials are dead, the dS^T tiles may be written
+    A5_STAMP(3);
 
     // ---- phase 1b: dV^T, dK^T of this wave's key fragment; dS^T of every (query fragment, key fragment) -> LDS
     f32x4 dk[4], dv[4];
@@ -238,37 +424,43 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       dk[d] = f32x4{0.f, 0.f, 0.f, 0.f};
       dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // BM 2: cs[key = lr] = sum over the queries of the bf16 dS the other products use, accumulated by the matrix
+    // pipe: ones[16 x q] . dS[q][key] - every row of the result is the column sum (one MFMA per fragment pair
+    // instead of four VALU adds per fragment and a cross-lane sum at the end)
+    f32x4 csacc = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      const bool klive = wave * 16 + lr < L;
-      // P and dS of query fragment f against the wave's key fragment: p[r] = P[q = 4 lg + r][key = lr]
-      auto pds = [&](int f, f32x4& p, f32x4& ds) {
-        const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
+      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      // P and dS of query fragment f against the wave's key fragment: pw = bf16 P[q = 4 lg + r][key = lr] (from phase
+      // 1a, transposed read), ds[r] = dS of the same elements.  dP - delta comes out of the MFMA: the accumulator starts
+      // at -delta of its rows.
+      auto pds = [&](int f, s16x4& pw, f32x4& ds) __attribute__((always_inline)) {
         const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + f * 16 + lg * 4);
         const float4 d4 = *reinterpret_cast<const float4*>(del_s + f * 16 + lg * 4);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-        s = mfma16(q0, k0, s);     // D[q = 4 lg + r][key = lr]
-        s = mfma16(q1, k1, s);
-        dp = mfma16(g0, v0, dp);   // dP[q][key] = sum_d dO[q][d] V[key][d]
+        pw = a5_tr<PL>(dSt + f * TS, wave * 16 + 4 * lg, lr);
+        f32x4 dp = f32x4{d4.x, d4.y, d4.z, d4.w};   // -delta of the fragment's rows
+        dp = mfma16(g0, v0, dp);   // dP[q][key] - delta[q],  dP = sum_d dO[q][d] V[key][d]
         dp = mfma16(g1, v1, dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -lv[r]));
-          p[r] = klive ? e : 0.f;          // padded key rows (see phase 1a)
-          ds[r] = p[r] * (dp[r] - dl[r]);
-        }
-        // dS^T[key][q = f * 16 + 4 lg .. + 3]: plane lg of tile f, 8 bytes per key
+        const uint2 w = __builtin_bit_cast(uint2, pw);
+        ds[0] = bflo(w.x) * dp[0]; ds[1] = bfhi(w.x) * dp[1];
+        ds[2] = bflo(w.y) * dp[2]; ds[3] = bfhi(w.y) * dp[3];
+        // dS^T[key][q = f * 16 + 4 lg .. + 3]: plane lg of tile f, 8 bytes per key - the bytes this wave's P block of
+        // the tile occupied (read above; LDS operations of one wave complete in order)
         *reinterpret_cast<s16x4*>(dSt + f * TS + lg * PL + (wave * 16 + lr) * 8) = pack4(ds);
       };
-#pragma unroll 1
-      for (int ip = 0; ip < KF / 2; ++ip) {
-        f32x4 pp[2], ds[2];
+#pragma unroll A5_UNROLL_1B
+      for (int ip = 0; ip < ((A5_ABL & 2) ? 1 : KF / 2); ++ip) {
+        s16x4 pp[2];
+        f32x4 ds[2];
         pds(2 * ip, pp[0], ds[0]);
-        __builtin_amdgcn_sched_barrier(0);   // one fragment's operand reads at a time (register pressure)
+        if (A5_SB_1B) __builtin_amdgcn_sched_barrier(0);   // one fragment's operand reads at a time (register pressure)
         pds(2 * ip + 1, pp[1], ds[1]);
-        const bf16x8 pf = pack8(pp[0], pp[1]), dsf = pack8(ds[0], ds[1]);
-        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(pp[0], pp[1], 0, 1, 2, 3, 4, 5, 6, 7));
+        const bf16x8 dsf = pack8(ds[0], ds[1]);
+        if constexpr (BM == 2) {
+          const s16x8 ones = s16x8{0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};   // bf16 1.0
+          csacc = mfma16(__builtin_bit_cast(bf16x8, ones), dsf, csacc);
+        }
+        if (A5_SB_1B) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const bf16x8 gt = t64_trpair(Gt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
@@ -278,44 +470,44 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         }
       }
       if constexpr (KF & 1) {
-        f32x4 pp, ds;
-        pds(KF - 1, pp, ds);
-        const s16x4 pf = pack4(pp), dsf = pack4(ds);
+        s16x4 pf;
+        f32x4 ds;
+        pds(KF - 1, pf, ds);
+        const s16x4 dsf = pack4(ds);
+        if constexpr (BM == 2) csacc = mfma16k16(s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80}, dsf, csacc);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           dv[d] = mfma16k16(t64_tr(Gt, (KF - 1) * 16 + 4 * lg, d, lr), pf, dv[d]);
           dk[d] = mfma16k16(t64_tr(Qt, (KF - 1) * 16 + 4 * lg, d, lr), dsf, dk[d]);
         }
       }
+      if constexpr (BM == 2) {
+        // cs of key lr (all four lane groups) -> the padded query column R - 1 of the dS^T image: element 3 of
+        // plane 3 of the last tile.  This wave wrote that word itself (zeros: query R - 1 does not exist), LDS
+        // operations of one wave complete in order.
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(csacc));   // MFMA result -> VALU read behind control flow
+        const float cs = csacc[0];
+        if (lg == 0)
+          *reinterpret_cast<bf16*>(dSt + (KF - 1) * TS + 3 * PL + (wave * 16 + lr) * 8 + 6) = (bf16)cs;
+      }
     }
     a5_drain(dk[0], dk[1], dk[2], dk[3]);
     a5_drain(dv[0], dv[1], dv[2], dv[3]);
     if (nxt < npairs) load_v(nxt);   // V is dead: the next pair's rows are in flight from here
+    A5_STAMP(4);
     __syncthreads();   // B4: every dS^T tile complete; nobody reads the Q / dO tiles any more
+    A5_STAMP(5);
 
-    // ---- K fragments -> the Q tile (T64 image, the A operand of phase 2), then this wave's dK / dV rows
+    // ---- K fragments -> the Q tile (T64 image, the A operand of phase 2)
     {
+      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
       const int row = wave * 16 + lr;
       *reinterpret_cast<uint4*>(Qt + row * 128 + ((lg ^ t64_swz(row)) << 4)) = __builtin_bit_cast(uint4, k0);
       *reinterpret_cast<uint4*>(Qt + row * 128 + (((4 + lg) ^ t64_swz(row)) << 4)) = __builtin_bit_cast(uint4, k1);
       if (nxt < npairs) load_k(nxt);   // the next pair's K rows replace the finished ones
-      const bool live = row < L;
-      if (live) {
-        bf16* rowk = dqkv + ((long)i * L + row) * ld + (long)H * DH + h * DH;
-        bf16* rowv = rowk + (long)H * DH;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          uint2 a, b;
-          a.x = pack_bf2(dk[d][0] * scale, dk[d][1] * scale);
-          a.y = pack_bf2(dk[d][2] * scale, dk[d][3] * scale);
-          *reinterpret_cast<uint2*>(rowk + d * 16 + lg * 4) = a;
-          b.x = pack_bf2(dv[d][0], dv[d][1]);
-          b.y = pack_bf2(dv[d][2], dv[d][3]);
-          *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
-        }
-      }
-      if constexpr (DBIAS) {
+      if constexpr (BM == 1) {
         // column sums over this fragment's live keys (fp32, before the bf16 rounding): one row of `red` per wave
+        const bool live = row < L;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -328,16 +520,19 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
           }
       }
     }
+    A5_STAMP(6);
     __syncthreads();   // B5: K tile complete
+    A5_STAMP(7);
 
     // ---- phase 2: dQ^T[d][q] of query fragment `wave` = sum_key K^T[d][key] dS^T[key][q]
     {
-      const char* T = dSt + wave * TS;
+      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      char* T = dSt + wave * TS;
       f32x4 dq[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-      for (int fp = 0; fp < KF / 2; ++fp) {
+#pragma unroll A5_UNROLL_P2
+      for (int fp = 0; fp < ((A5_ABL & 4) ? 1 : KF / 2); ++fp) {
         const int ra = (2 * fp) * 16 + 4 * lg, rb = ra + 16;
         const bf16x8 dsf = a5_trpair<PL>(T, ra, rb, lr);
 #pragma unroll
@@ -350,18 +545,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         for (int d = 0; d < 4; ++d) dq[d] = mfma16k16(t64_tr(Qt, ra, d, lr), dsf, dq[d]);
       }
       a5_drain(dq[0], dq[1], dq[2], dq[3]);
-      const int qrow = wave * 16 + lr;
-      if (qrow < L) {
-        bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          uint2 w;
-          w.x = pack_bf2(dq[d][0] * scale, dq[d][1] * scale);
-          w.y = pack_bf2(dq[d][2] * scale, dq[d][3] * scale);
-          *reinterpret_cast<uint2*>(row + d * 16 + lg * 4) = w;
-        }
-      }
-      if constexpr (DBIAS) {
+      if constexpr (BM == 1 || BM == 3) {
         // padded query rows are exactly 0 (their dS^T columns are)
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -371,24 +555,52 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
             if (lr == 0) red[wave * 192 + d * 16 + lg * 4 + r] = t * scale;
           }
       }
-    }
-    __syncthreads();   // B6: the K tile, the dS^T tiles and `red` are free / complete
-    if constexpr (DBIAS) {
-      // per-(sample, head) column sums -> dbias[i][which][h][:]; the host sums over samples
-      if (tid < 192) {
-        const int which = tid >> 6, d = tid & 63;
-        float t = 0.f;
+      if constexpr (BM == 2) {
+        // column R - 1 of dQ^T (lane lr = 15 of the last wave) = sum_key cs_key K[key][:] = the q-bias gradient / scale
+        if (wave == KF - 1 && lr == 15) {
 #pragma unroll
-        for (int w = 0; w < KF; ++w) t += red[w * 192 + tid];
+          for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[d * 16 + lg * 4 + r] = dq[d][r] * scale;
+        }
+      }
+      // ---- the wave's dQ rows, then its dK / dV rows, through its own (now dead) dS^T tile as whole rows
+      const bool st = !(A5_ABL & 16);
+      bf16* out = dqkv + (long)i * L * ld + h * DH;
+      a5_store_rows(T, dq, scale, out, ld, wave * 16, L, a5_opaque(lane), st);
+      a5_store_rows(T, dk, scale, out + (long)H * DH, ld, wave * 16, L, a5_opaque(lane), st);
+      a5_store_rows(T, dv, 1.0f, out + 2L * H * DH, ld, wave * 16, L, a5_opaque(lane), st);
+    }
+    A5_STAMP(8);
+    __syncthreads();   // B6: the K tile, the dS^T tiles and `red` are free / complete
+    A5_STAMP(9);
+    if constexpr (BM != 0) {
+      // per-(sample, head) column sums -> dbias[i][which][h][:]; the host sums over samples
+      if (wave < 3) {
+        const int which = wave, d = a5_opaque(lane), tid = wave * 64 + d;
+        float t = 0.f;
+        if constexpr (BM == 1) {
+#pragma unroll
+          for (int w = 0; w < KF; ++w) t += red[w * 192 + tid];
+        } else if constexpr (BM == 3) {   // q: column sums of the dQ rows; k: 0; v: column sums of dO
+          if (which == 0) {
+#pragma unroll
+            for (int w = 0; w < KF; ++w) t += red[w * 192 + d];
+          }
+          if (which == 2) t = cst[d];
+        } else {   // q: column R - 1 of dQ^T; k: 0; v: column sums of dO (the loader waves' totals)
+          t = which == 0 ? red[d] : which == 2 ? cst[d] : 0.f;
+        }
         dbias[((long)i * 3 * H + (long)which * H + h) * DH + d] = t;
       }
     }
+    A5_STAMP(10);
   }
 }
 
 template <int KF, int LW>
-int launch_bwd5(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
-                int L, int H, hipStream_t s) {
+int launch_bwd5(const void* qkv, const void* d_o, const float* lse, void* dqkv, float* dbias, int n, int L, int H,
+                hipStream_t s) {
   using C = A5<KF, LW>;
   static int cus = 0;
   if (!cus) {
@@ -396,25 +608,22 @@ int launch_bwd5(const void* qkv, const void* d_o, const float* lse, float* delta
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  // workgroups per CU: LDS (160 KiB) and 4 waves per SIMD at <= 128 VGPRs
+  // workgroups per CU: LDS (160 KiB) and 5 waves per SIMD (<= 96 VGPRs: the KF = 4 instantiations; 13 + 3 waves fill a CU)
   int per_cu = (160 * 1024) / C::LDS;
-  if (per_cu > 16 / (KF + LW)) per_cu = 16 / (KF + LW);
+  if (per_cu > 20 / (KF + LW)) per_cu = 20 / (KF + LW);
   if (per_cu < 1) per_cu = 1;
   const int npairs = n * H;
   const int grid = npairs < cus * per_cu ? npairs : cus * per_cu;
-  if (dbias) {
-    auto kern = attn5_bwd_kernel<KF, LW, true>;
+  auto go = [&](auto kern) __attribute__((always_inline)) {
     if (C::LDS > 65536)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16*)qkv, (const bf16*)d_o, lse, delta,
-                       (bf16*)dqkv, dbias, L, H, npairs, 0.125f);
-  } else {
-    auto kern = attn5_bwd_kernel<KF, LW, false>;
-    if (C::LDS > 65536)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16*)qkv, (const bf16*)d_o, lse, delta,
-                       (bf16*)dqkv, dbias, L, H, npairs, 0.125f);
-  }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS, s, (const bf16*)qkv, (const bf16*)d_o, lse, (bf16*)dqkv,
+                       dbias, L, H, npairs, 0.125f);
+  };
+  if (!dbias) go(attn5_bwd_kernel<KF, LW, 0>);
+  else if (g_a5_bias_dpp) go(attn5_bwd_kernel<KF, LW, 1>);
+  else if (L & 15) go(attn5_bwd_kernel<KF, LW, 2>);
+  else go(attn5_bwd_kernel<KF, LW, 3>);
   return bv_check_launch("bv_attn_bwd(one launch)");
 }
 
@@ -425,7 +634,8 @@ int launch_bwd5(const void* qkv, const void* d_o, const float* lse, float* delta
 int bv_attn5_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
                  int L, int H, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (L <= 64) return launch_bwd5<4, 1>(qkv, d_o, lse, delta, dqkv, dbias, n, L, H, s);
-  if (L > 192 && L <= 208) return launch_bwd5<13, 3>(qkv, d_o, lse, delta, dqkv, dbias, n, L, H, s);
+  (void)delta;   // scratch of the two-launch path; the exact delta never leaves the LDS here
+  if (L <= 64) return launch_bwd5<4, 1>(qkv, d_o, lse, dqkv, dbias, n, L, H, s);
+  if (L > 192 && L <= 208) return launch_bwd5<13, 3>(qkv, d_o, lse, dqkv, dbias, n, L, H, s);
   return -100;
 }

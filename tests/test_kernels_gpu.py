@@ -399,6 +399,20 @@ def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
   tol = 2e-2 * g.abs().sum(0).max().item()
   assert_close(db, cs, 2e-2, tol, "one-launch bias gradients vs fp64")
   assert_close(db, db3, 2e-2, tol, "one-launch vs two-launch bias gradients")
+  # the bias gradients came from the identities (attention5.hip BM = 2 for L % 16 != 0, BM = 3 otherwise): same
+  # again by DPP column sums of dq / dk / dv (BM = 1)
+  lib.bv_attn_tune(old | 256)
+  try:
+    dbd = torch.zeros((3 * H * 64,), device=dev)
+    d5d = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=dbd)
+  finally:
+    lib.bv_attn_tune(old)
+  assert torch.equal(d5d, d5)
+  assert_close(dbd, cs, 2e-2, tol, "one-launch bias gradients (column sums) vs fp64")
+  for j, name in enumerate(("q", "k", "v")):
+    sl = slice(j * H * 64, (j + 1) * H * 64)
+    e_id = (db[sl].double() - cs[sl]).norm().item(); e_cs = (dbd[sl].double() - cs[sl]).norm().item()
+    print(f"{name}-bias gradient: |err| identities {e_id:.3e}, column sums {e_cs:.3e}, |ref| {cs[sl].norm().item():.3e}")
 
 
 def test_attention_peaked_softmax(dev):
