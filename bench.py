@@ -22,6 +22,13 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  same model's full step on a bounded sample of pairs on the
                  host cores (rank 0, N=1 only).  Checker/baseline only — the
                  timed product path never touches oracle/.
+  configs      : (N = 1, after the headline, outside its timed region) the other BASELINE.json
+                 workloads and the per-rank shapes of the headline on this one GPU, a few steps each:
+                 c2 (ViT-B/16 tower fwd+bwd, batch 256), c4_rank (SigLIP L/16@336, the 1024 pairs one of
+                 8 ranks owns), c5b (LiT step with the BERT-base text tower, batch 512), rank512 /
+                 rank1024 (the 4096 / 8 and 4096 / 4 pairs one rank of the headline owns).  Each entry:
+                 value, unit, ms_per_step, steps, roofline_frac (the same GEMM family, live HIP
+                 events), step_frac where the workload's matmul FLOPs are known, peak_hbm_gb.
 """
 import argparse
 import json
@@ -252,6 +259,162 @@ def spawn_ranks(n):
     raise SystemExit(rc)
 
 
+# ------------------------------------------------------------------ other BASELINE workloads (N = 1 `configs` object) --
+MATMUL_GFLOP_PER_PAIR = 139.3       # B/16 + text-B, forward + backward (3 x (35.42 image + 11.02 text + 0.006 loss)), DESIGN.md 4
+MATMUL_GFLOP_PER_IMAGE_B16 = 3 * 35.42
+
+
+def _timed(fn, steps, warmup):
+  """(seconds per step, roofline object of the k-major 256x256 GEMM family over the same timed region)."""
+  from big_vision_amd import _lib
+  for _ in range(warmup):
+    fn()
+  obs = GemmObserver()
+  _lib.observer = obs
+  torch.cuda.synchronize()
+  obs.active = True
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    fn()
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t0) / steps
+  obs.active = False
+  _lib.observer = None
+  launches, ms, flops, nbytes = obs.summary()
+  ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+  roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS,
+          "unit": "TFLOP/s", "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+          "algorithmic_bytes_per_launch": nbytes / max(1, launches), "launches": launches,
+          "avg_launch_us": 1e3 * ms / max(1, launches), "share_of_step_time": ms / (1e3 * dt * steps)}
+  return dt, roof
+
+
+def workload_c2(dev, steps, stream="float32"):
+  """BASELINE configs[1]: ViT-B/16 image tower alone, forward + backward, batch 256."""
+  from big_vision_amd import engine as E
+  from big_vision_amd.models import vit
+  from big_vision_amd.params import ParamStore
+  old = E.set_residual_stream(stream)
+  try:
+    n, res = 256, 224
+    model = vit.Model(None, variant="B/16", pool_type="map")
+    hw = model.grid((n, res, res, 3))
+    store = ParamStore(model.entries("", hw), dev)
+    store.init_random(0); store.refresh_shadow(); store.want_grads = True
+    image = torch.rand((n, res, res, 3), device=dev) * 2 - 1
+    ex = model.executor(store, "", hw)
+
+    def step():
+      store.zero_grad()
+      z, _, ctx = ex.fwd(image, save=True)
+      ex.bwd(ctx, (z / n).contiguous())          # dL/dz of L = 0.5 mean |z|^2 (SURVEY.md App. B)
+    dt, roof = _timed(step, steps, 2)
+  finally:
+    E.set_residual_stream(old)
+  flops = MATMUL_GFLOP_PER_IMAGE_B16 * 1e9 * n
+  return {"metric": "images/sec, ViT-B/16 image tower forward+backward, batch 256 (BASELINE configs[1])",
+          "value": n / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "tflops_algorithmic": flops / dt / 1e12,
+          "step_frac": flops / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS, "roofline": roof,
+          "config": {"workload": "ViT-B/16@224 MAP tower, fwd+bwd, no optimizer", "batch": n, "residual_stream": stream}}
+
+
+def workload_siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label="", text_model=None,
+                    vocab=32_000, stream="float32", comm=None, gflop_per_pair=None):
+  """One SigLIP training step (trainers.proj.image_text.siglip) on n pairs of synthetic data, this device only."""
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, emb), temperature_init=10.0,
+                           bias_init=-10.0 if schedule is None else -2.71,
+                           **({"text_model": text_model} if text_model else {}))
+  config = make_config(20_000)
+  config.microbatch = micro
+  config.residual_stream = stream
+  if schedule is not None:
+    config.schedule = schedule
+  g = torch.Generator(device=dev).manual_seed(1)
+  image = torch.rand((n, res, res, 3), generator=g, device=dev) * 2 - 1
+  text = torch.randint(2, vocab, (n, seq), generator=g, device=dev, dtype=torch.int32)
+  kw = {} if comm is None else {"comm": comm}
+  state, _ = siglip.make_train_state(model, config, (n, res, res, 3), (n, seq), rng=0, total_steps=20_000, device=dev, **kw)
+  fn = siglip.make_update_fn(model, config, **kw)
+  box = {"s": state}
+
+  def step():
+    box["s"], box["m"] = fn(box["s"], None, {"image": image, "labels": text})
+  dt, roof = _timed(step, steps, 2)
+  siglip.check_finite(box["m"])
+  r = {"value": n / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "roofline": roof,
+       "config": {"workload": label, "per_gpu_batch": n, "microbatch": micro, "residual_stream": stream,
+                  "final_loss": float(box["m"]["training_loss"].item())}}
+  if gflop_per_pair:
+    r["step_frac"] = gflop_per_pair * 1e9 * n / dt / 1e12 / BF16_DENSE_PEAK_TFLOPS
+  return r
+
+
+LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=150))]
+
+
+def workload_c4(dev, steps, stream="float32"):
+  """BASELINE configs[3]: SigLIP ViT-L/16@336 + text-L, global batch 8192 on 8 GPUs: ONE rank's 1024 pairs."""
+  r = workload_siglip(dev, steps, dict(variant="L/16", pool_type="map"), dict(variant="L", vocab_size=32_000), 1024,
+                      n=1024, res=336, seq=64, micro=256, stream=stream,
+                      label="SigLIP ViT-L/16@336 + text-L: one rank's 1024 pairs of the global batch 8192 (loss over the "
+                            "local 1024 only: no peers on a single device), micro-batches of 256, Adam+clip+wd+cosine")
+  r["metric"] = "image-text pairs/sec per GPU, SigLIP ViT-L/16@336 training step at 1024 pairs per GPU (BASELINE configs[3])"
+  return r
+
+
+def workload_c5(dev, steps, stream="float32"):
+  r = workload_siglip(dev, steps, dict(variant="B/16", pool_type="tok", head_zeroinit=False),
+                      dict(variant="B", vocab_size=32_000), 768, n=512, res=224, seq=16, micro=2048, schedule=LIT_SCHEDULE,
+                      stream=stream, label="LiT (siglip_lit_coco.py): frozen ViT-B/16 cls-token tower + trainable text-B, "
+                                           "16 tokens, batch 512, text-only backward")
+  r["metric"] = "image-text pairs/sec, LiT locked-image step, batch 512 (BASELINE configs[4])"
+  return r
+
+
+def workload_c5b(dev, steps, stream="float32"):
+  """The literal siglip_lit_coco.py: text_model='proj.flaxformer.bert', config 'base' (:78,84-87)."""
+  r = workload_siglip(dev, steps, dict(variant="B/16", pool_type="tok", head_zeroinit=False),
+                      dict(config="base", head_zeroinit=False), 768, n=512, res=224, seq=16, micro=2048,
+                      schedule=LIT_SCHEDULE, text_model="proj.flaxformer.bert", vocab=30522, stream=stream,
+                      label="LiT (siglip_lit_coco.py as written): frozen ViT-B/16 cls-token tower + trainable BERT-base "
+                            "text tower, 16 tokens, batch 512, text-only backward")
+  r["metric"] = "image-text pairs/sec, LiT locked-image step with the BERT-base text tower, batch 512 (BASELINE configs[4])"
+  return r
+
+
+def workload_rank_shape(dev, steps, n, stream="float32"):
+  """The pairs ONE rank of the headline owns at N = 4096 / n GPUs (single pass, full contexts, loss over the local
+  pairs only: no peers on a single device)."""
+  r = workload_siglip(dev, steps, IMAGE_CFG, TEXT_CFG, EMB, n=n, res=RES, seq=SEQ, micro=MICRO, stream=stream,
+                      gflop_per_pair=MATMUL_GFLOP_PER_PAIR,
+                      label=f"headline model, the {n} pairs one of {GLOBAL_BATCH // n} ranks owns (no collectives)")
+  r["metric"] = f"image-text pairs/sec per GPU at {n} pairs per GPU (rank shape of the headline at N = {GLOBAL_BATCH // n})"
+  return r
+
+
+def configs_object(dev, steps=3):
+  """The `configs` object of the N = 1 line: every entry is measured here, after the headline, on the same device."""
+  import gc
+  out = {}
+  for key, fn in (("c2", lambda: workload_c2(dev, steps)), ("c4_rank", lambda: workload_c4(dev, steps)),
+                  ("c5b", lambda: workload_c5b(dev, steps)), ("rank512", lambda: workload_rank_shape(dev, steps, 512)),
+                  ("rank1024", lambda: workload_rank_shape(dev, steps, 1024))):
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    try:
+      r = fn()
+      out[key] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                  "steps": steps, "roofline_frac": r["roofline"]["frac"], "step_frac": r.get("step_frac"),
+                  "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                  "final_loss": r["config"].get("final_loss")}
+    except Exception as e:   # the headline must not depend on the extra workloads
+      out[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +425,9 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-bf16-stream", action="store_true",
                   help="skip the second (bf16 residual stream) measurement that N = 1 appends as `bf16_stream`")
+  ap.add_argument("--no-configs", action="store_true",
+                  help="skip the `configs` object (the other BASELINE workloads and rank shapes, N = 1 only)")
+  ap.add_argument("--configs-steps", type=int, default=3)
   ap.add_argument("--cpu-sample", type=int, default=16)
   ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
   ap.add_argument("--residual-stream", default=RESIDUAL_STREAM, choices=("float32", "bfloat16"),
@@ -401,7 +567,10 @@ def main():
                         "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src,
+                        "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
+                        # whole step: algorithmic matmul FLOPs of the workload / wall time / peak
+                        "step_frac": (MATMUL_GFLOP_PER_PAIR * 1e9 * args.global_batch * args.steps / dt / 1e12
+                                      / BF16_DENSE_PEAK_TFLOPS),
                         "algorithmic_bytes_per_launch": nbytes / max(1, launches),
                         "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
                         "share_of_step_time": ms / (1e3 * dt)}
@@ -409,8 +578,11 @@ def main():
     line["bf16_stream"] = bf16_line
   if world > 1 or os.environ.get("BV_DP_FORCE_COLLECTIVES") == "1":
     line["rccl"] = rccl_info(comm, dev)
+  if world == 1 and not args.no_configs and args.global_batch == GLOBAL_BATCH:
+    line["configs"] = configs_object(dev, args.configs_steps)
   if world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    line["cpu_baseline"]["samples"] = 1
   sys.stdout.flush()
   os.write(json_fd, (json.dumps(line) + "\n").encode())
 

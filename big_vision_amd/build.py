@@ -3,6 +3,11 @@
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU-only
 build container; the resulting big_vision_amd/libbvhip.so travels to the GPU box
 with the repo snapshot.
+
+Build-time requirements: hipcc and the ROCm headers, including <rccl/rccl.h> (csrc/comm.cpp takes the
+ncclComm_t / ncclDataType_t types and the prototypes of the eight entry points it binds from it).  There
+is NO link-time RCCL dependency: comm.cpp dlopen()s librccl.so at the first bv_comm_* call, so the
+library loads on hosts without RCCL as long as nothing calls those entry points.
 """
 import os
 import shutil

@@ -203,6 +203,25 @@ def init_from_env(backend: str | None = None, overlap_channels: int | None = Non
   return Comm()
 
 
+_warned_uncapped = False
+
+
+def warn_if_overlap_is_uncapped():
+  """The overlapped gradient all-reduce is sized for RESERVED_CUS free CUs; an RCCL communicator created without
+  a channel cap (init_from_env(overlap_channels=...) / NCCL_MAX_NCHANNELS) launches more workgroups than that,
+  which then wait for - or delay - whole GEMM launches.  Same results, not the benchmarked configuration
+  (advisor r3): say so once."""
+  global _warned_uncapped
+  if _warned_uncapped or not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+    return
+  if "NCCL_MAX_NCHANNELS" not in os.environ:
+    _warned_uncapped = True
+    import warnings
+    warnings.warn("overlap_grad_sync with an uncapped RCCL: create the process group with "
+                  f"dp.init_from_env(overlap_channels=dp.RESERVED_CUS) or set NCCL_MAX_NCHANNELS={RESERVED_CUS} "
+                  "(the persistent GEMMs reserve that many CUs for the collectives)")
+
+
 # CUs the persistent 256x256 GEMM leaves to RCCL while gradient all-reduces overlap the backward
 # (bv_gemm_reserve_cus): its workgroups fill a CU, so a collective launched beside it would otherwise
 # wait for - or delay - a whole GEMM launch.  4 keeps the split-K choices of the B/16 shapes intact

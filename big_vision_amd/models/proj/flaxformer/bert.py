@@ -120,18 +120,43 @@ class BertExec:
 
   def _lengths(self, ids):
     """input_mask = (text != 0) (bert.py:55) as a key-padding LENGTH per sample: the attention kernels mask a
-    suffix, so the non-pad tokens must be a prefix (what tokenize-then-pad produces); checked once."""
+    suffix, so the non-pad tokens must be a prefix (what tokenize-then-pad produces).  EVERY batch is checked
+    (advisor r3: a later batch with an inner pad id or an all-pad row must not slip through), without stalling
+    the launch queue: the verdict of batch k is computed on the device, copied to pinned host memory
+    asynchronously and read when batch k + 1 arrives (by then the copy has long completed); `check_pending()`
+    reads the last one (the trainers call it through `model.check` / at the end of a run).  lens is clamped to
+    >= 1 so that even the one unchecked step cannot run an attention row over zero keys."""
+    self.check_pending()
     valid = ids != 0
-    lens = valid.sum(dim=1).to(torch.int32).contiguous()
-    if not self._mask_checked:
-      L = ids.shape[1]
-      prefix = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
-      if not torch.equal(valid, prefix):
-        raise NotImplementedError("BERT input_mask must mark a prefix of the sequence (pad id 0 at the end only)")
-      if int(lens.min()) < 1:
-        raise ValueError("an example without any token (all ids are 0)")
+    lens = valid.sum(dim=1).to(torch.int32)
+    L = ids.shape[1]
+    prefix = torch.arange(L, device=ids.device)[None, :] < lens[:, None]
+    bad = torch.stack([(valid != prefix).any(), (lens < 1).any()]).to(torch.uint8)
+    if ids.is_cuda:
+      host = torch.empty(2, dtype=torch.uint8, pin_memory=True)
+      host.copy_(bad, non_blocking=True)
+      ev = torch.cuda.Event()
+      ev.record()
+      self._pending = (host, ev)
+    else:
+      self._pending = (bad.clone(), None)
+    if not self._mask_checked:   # the very first batch is checked synchronously (nothing is queued yet)
+      self.check_pending()
       self._mask_checked = True
-    return lens
+    return lens.clamp_(min=1).contiguous()
+
+  def check_pending(self):
+    """Raises if the last batch handed to fwd() had an input_mask the kernels cannot express."""
+    pend, self._pending = getattr(self, "_pending", None), None
+    if pend is None:
+      return
+    host, ev = pend
+    if ev is not None:
+      ev.synchronize()
+    if int(host[0]):
+      raise NotImplementedError("BERT input_mask must mark a prefix of the sequence (pad id 0 at the end only)")
+    if int(host[1]):
+      raise ValueError("an example without any token (all ids are 0)")
 
   def fwd(self, text, save=False, collect=False):
     m = self.m

@@ -124,6 +124,10 @@ def layernorm_bwd(dy, x, scale, mean, rstd, *, rows, D, dres=None, dx=None, dx_b
     # bf16 residual stream: dres and dx are bf16 and dx IS the bf16 copy the next GEMM reads; `dx`
     # (the fp32 stream of the other mode) is not written.  Strided calls start from zeros.
     _chk(x, BF16, "layernorm_bwd.x")
+    if y_out is not None:
+      # only the fp32-stream kernel re-emits the forward output (bv_layernorm_bwd_y); silently returning an
+      # uninitialised y_out buffer here was advisor finding r3 #5
+      raise ValueError("layernorm_bwd: y_out is not supported on the bf16 residual stream (re-normalise with layernorm_fwd)")
     if dres is not None:
       _chk(dres, BF16, "layernorm_bwd.dres")
     if dx_bf16 is None:

@@ -106,6 +106,8 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
   assert "mixup" not in config, "Mixup is not supported for SigLIP."
   micro = int(config.get("microbatch", 0) or 0)
   state_cache = {"keep_n": 0, "light": None, "per_ctx": {}}
+  if comm.size > 1 and config.get("overlap_grad_sync", True):
+    dp.warn_if_overlap_is_uncapped()   # the persistent GEMMs leave dp.RESERVED_CUS CUs to RCCL: cap its channels
 
   def update_fn(train_state, rng, batch):
     del rng  # dropout is 0 on this path; kept for signature parity
@@ -201,7 +203,12 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
                  sync=(sync if s == starts[-1] else None))   # gradients are final in the LAST backward only
         del ctx
     else:
-      zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=True)
+      # one pass over the whole per-device batch; config.microbatch_light also applies here (the same context kinds
+      # as the two-pass path: True / "light" = LayerNorm outputs and gelu(h) re-derived by the backward, "g" =
+      # gelu(h) only) - a memory knob that changes no result
+      light_cfg = config.get("microbatch_light", "auto")
+      save = "light" if light_cfg in (True, "light") else ("g" if light_cfg == "g" else True)
+      zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=save)
       norms = [(o_.get("img/norm"), o_.get("txt/norm"))]
       stats, dzimg, dztxt, *lx = loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
       with dp.reserve_cus_for_collectives(comm if sync is not None else None):

@@ -28,7 +28,7 @@ def _worker(rank, world, port, out, force, kw=None):
   import test_dp_two_ranks_gpu as T
   from big_vision_amd import dp
   torch.cuda.set_device(rank)
-  comm = dp.init_from_env(backend="nccl")
+  comm = dp.init_from_env(backend="nccl", overlap_channels=dp.RESERVED_CUS)   # the benchmarked configuration
   assert comm.active and comm.size == world
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
   n = 8 // world
