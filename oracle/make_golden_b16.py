@@ -50,6 +50,59 @@ def make_inputs(dtype=torch.float32, tag="b16"):
   return O.recover_tree(flat), image, text
 
 
+def grad_selection(g, c):
+  """HF parameter gradients (dict name -> tensor) mapped back to the Flax leaf names / layouts: one leaf of every
+  layer kind per tower, from the first, a middle and the last block (the same mapping as oracle/make_golden.py)."""
+  D, H, depth = c["width"], c["num_heads"], c["depth"]
+  Li, Lm, Ll = 0, depth // 2, depth - 1
+  V = lambda i: f"vision_model.encoder.layers.{i}"
+  T = lambda i: f"text_model.encoder.layers.{i}"
+  IB = lambda i: f"img/Transformer/encoderblock_{i}"
+  TB = lambda i: f"txt/Encoder_0/encoderblock_{i}"
+  A = "MultiHeadDotProductAttention_0"
+  return {
+      "img/embedding/kernel": g["vision_model.embeddings.patch_embedding.weight"].permute(2, 3, 1, 0),
+      "img/pos_embedding": g["vision_model.embeddings.position_embedding.weight"][None],
+      f"{IB(Li)}/LayerNorm_0/scale": g[V(Li) + ".layer_norm1.weight"],
+      f"{IB(Li)}/{A}/query/kernel": g[V(Li) + ".self_attn.q_proj.weight"].T.reshape(D, H, D // H),
+      f"{IB(Li)}/{A}/key/bias": g[V(Li) + ".self_attn.k_proj.bias"].reshape(H, D // H),
+      f"{IB(Lm)}/{A}/key/kernel": g[V(Lm) + ".self_attn.k_proj.weight"].T.reshape(D, H, D // H),
+      f"{IB(Lm)}/{A}/out/kernel": g[V(Lm) + ".self_attn.out_proj.weight"].T.reshape(H, D // H, D),
+      f"{IB(Lm)}/MlpBlock_0/Dense_0/kernel": g[V(Lm) + ".mlp.fc1.weight"].T,
+      f"{IB(Ll)}/MlpBlock_0/Dense_1/kernel": g[V(Ll) + ".mlp.fc2.weight"].T,
+      f"{IB(Ll)}/MlpBlock_0/Dense_1/bias": g[V(Ll) + ".mlp.fc2.bias"],
+      f"{IB(Ll)}/LayerNorm_1/bias": g[V(Ll) + ".layer_norm2.bias"],
+      "img/Transformer/encoder_norm/scale": g["vision_model.post_layernorm.weight"],
+      "img/MAPHead_0/probe": g["vision_model.head.probe"],
+      "img/MAPHead_0/MultiHeadDotProductAttention_0/value/kernel":
+          g["vision_model.head.attention.in_proj_weight"][2 * D:].T.reshape(D, H, D // H),
+      "img/MAPHead_0/MlpBlock_0/Dense_0/kernel": g["vision_model.head.mlp.fc1.weight"].T,
+      "txt/Embed_0/embedding": g["text_model.embeddings.token_embedding.weight"],
+      "txt/pos_embedding": g["text_model.embeddings.position_embedding.weight"][None],
+      f"{TB(Li)}/{A}/value/kernel": g[T(Li) + ".self_attn.v_proj.weight"].T.reshape(D, H, D // H),
+      f"{TB(Lm)}/{A}/query/kernel": g[T(Lm) + ".self_attn.q_proj.weight"].T.reshape(D, H, D // H),
+      f"{TB(Lm)}/MlpBlock_0/Dense_0/bias": g[T(Lm) + ".mlp.fc1.bias"],
+      f"{TB(Ll)}/MlpBlock_0/Dense_1/kernel": g[T(Ll) + ".mlp.fc2.weight"].T,
+      f"{TB(Ll)}/LayerNorm_0/scale": g[T(Ll) + ".layer_norm1.weight"],
+      "txt/Encoder_0/encoder_norm/bias": g["text_model.final_layer_norm.bias"],
+      "txt/head/kernel": g["text_model.head.weight"].T,
+      "t": g["logit_scale"],
+      "b": g["logit_bias"],
+  }
+
+
+NPROBE = 48
+
+
+def fingerprint(name, v):
+  """A gradient tensor as a few numbers (the tensors themselves are up to 19 MB in fp64): its sum, its L2 norm and
+  NPROBE entries at flat indices drawn from a generator seeded by the leaf name."""
+  v = v.detach().double().contiguous().view(-1)
+  gen = torch.Generator().manual_seed(sum(name.encode()) * 7919 + v.numel())
+  idx = torch.randint(0, v.numel(), (NPROBE,), generator=gen)
+  return torch.cat([v.sum()[None], v.norm()[None], v[idx]]).numpy()
+
+
 def main(tag="b16"):
   from transformers import SiglipConfig, SiglipModel
   c, IMAGE_CFG, TEXT_CFG = FIXTURES[tag]
@@ -76,8 +129,15 @@ def main(tag="b16"):
     err = (a - b).abs().max().item()
     print(f"oracle(fp64) vs HF(fp64) {name}: max abs err {err:.3e}")
     assert err < 1e-6, name
+  # the BACKWARD at these shapes: HF's autograd gradients of its own loss, fp64, as fingerprints
+  hf.zero_grad()
+  res_g = hf(input_ids=text.long(), pixel_values=image.double().permute(0, 3, 1, 2).contiguous(), return_loss=True)
+  res_g.loss.backward()
+  sel = grad_selection({n: p_.grad for n, p_ in hf.named_parameters()}, c)
+  fps = {"hfgradfp:" + n: fingerprint(n, v) for n, v in sel.items()}
+  print(f"{len(fps)} gradient fingerprints, largest |grad| norm {max(float(f[1]) for f in fps.values()):.3e}")
   dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", f"siglip_hf_{tag}.npz")
-  np.savez_compressed(dst, hf_zimg=res.image_embeds.numpy(), hf_ztxt=res.text_embeds.numpy(),
+  np.savez_compressed(dst, **fps, hf_zimg=res.image_embeds.numpy(), hf_ztxt=res.text_embeds.numpy(),
                       hf_logits=res.logits_per_image.numpy(), hf_loss=res.loss.numpy(),
                       param_checksum=np.asarray(sum(float(v.double().sum()) for _, v in O.tree_flatten_with_names(params))),
                       **{"cfg_" + k: np.asarray(v) for k, v in c.items()})
