@@ -389,32 +389,46 @@ class Optimizer:
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
 
+  def grad_sync(self, overlap=True):
+    """The gradient reduction object a trainer drives during the backward of a sharded step (dp.GradShardSync:
+    every final range is summed onto the rank that owns it); None on one rank."""
+    from big_vision_amd import dp
+    if not self.sharded or self.comm is None or not self.comm.active:
+      return None
+    return dp.GradShardSync(self.comm, self.store.grad, self.S, self.store.trainable_count)
+
   def _sharded_adam_step(self):
-    """"fsdp" placement: gradients arrive UNREDUCED (this rank's partial sums).  reduce_scatter -> this rank's
-    slice of the summed gradient -> global clip norm from the slices' square norms -> the fused Adam kernel on
-    the slice (same kernel, same per-chunk hyper-parameter table, offset pointers) -> all_gather of the updated
-    fp32 parameters -> bf16 shadow refreshed locally.  Per step and rank this moves (N-1)/N x 4 B x P each way -
-    exactly the bytes of the all-reduce it replaces - and runs 1/N of the optimizer kernel and of its state."""
+    """"fsdp" placement.  The trainer has summed every gradient range onto its OWNER during the backward
+    (grad_sync() / dp.GradShardSync, overlapped with the remaining GEMMs like the all-reduce of the replicated
+    path): st.grad[lo:hi] is this rank's slice of the global gradient, in place.  Then: global clip norm from the
+    slices' square norms -> the fused Adam kernel on the slice (same kernel, same per-chunk hyper-parameter table,
+    offset pointers; it also refreshes the bf16 shadow of the slice) -> in-place exchange of the updated fp32
+    slices -> bf16 shadow of the slices this rank does NOT own (two casts: the frozen tail and the own slice are
+    left alone, static_version does not move, so transposed images of frozen towers are not rebuilt - advisor r3).
+    Per step and rank this moves (N-1)/N x 4 B x P each way - the bytes of the all-reduce it replaces - runs 1/N
+    of the optimizer kernel and holds 1/N of its state; no staging copies."""
     st, comm = self.store, self.comm
     n_tr, S, lo, hi = st.trainable_count, self.S, self.lo, self.hi
     n_own = hi - lo
     k = self.count
     sched = [fn(k) for fn in self.schedule_fns]
-    g_own = comm.reduce_scatter_flat(st.grad[:n_tr], S)              # [S]; beyond n_own: zeros
     self.gsq.zero_()
     if n_own:
-      ops.sqnorm_(g_own[:n_own], self.gsq)
+      ops.sqnorm_(st.grad[lo:hi], self.gsq)
     comm.all_reduce_scalars_(self.gsq)
     self.stats.zero_()
     if n_own:
-      ops.adam_step_(st.master[lo:hi], g_own[:n_own], self.mu[:n_own], self.nu[:n_own], st.shadow[lo:hi], self.segs,
+      ops.adam_step_(st.master[lo:hi], st.grad[lo:hi], self.mu[:n_own], self.nu[:n_own], st.shadow[lo:hi], self.segs,
                      self.chunk_seg[lo // 1024:], n_own, sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
                      1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
     comm.all_reduce_scalars_(self.stats)
-    comm.all_gather_flat_(st.master[:n_tr], lo, hi, S)                 # every rank's slice into every rank's master
+    comm.broadcast_slices_(st.master[:n_tr], S)          # every rank's updated slice into every rank's master
     self.count = k + 1
-    st.mark_dirty()          # the kernel refreshed the shadow of the own slice only
-    st.refresh_shadow()
+    if comm.active:
+      for a, b in ((0, lo), (hi, n_tr)):
+        if b > a:
+          ops.cast_bf16(st.master[a:b], st.shadow[a:b])
+    st.shadow_version += 1     # the trainable prefix changed; frozen tensors (static_version) did not
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}

@@ -121,8 +121,10 @@ def make_update_fn(model, config, comm=None):
     logits, _, ctx = ex.fwd(images, save=True)
     acc = torch.zeros(1, device=images.device, dtype=torch.float64)
     dlogits = loss_kernel(logits.contiguous(), labels, acc, want_grad=True, n_global=n * comm.size)
-    # ("fsdp" placement: the optimizer reduce-scatters the unreduced gradients itself)
-    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and not getattr(opt, "sharded", False)) else None
+    # ("fsdp" placement: every range is summed onto its owner only, dp.GradShardSync)
+    sync = None
+    if comm.size > 1:
+      sync = opt.grad_sync() if getattr(opt, "sharded", False) else dp.GradSync(comm, store.grad)
     ex.bwd(ctx, dlogits)
     if sync is not None:
       sync.finish()

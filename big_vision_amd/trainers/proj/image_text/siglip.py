@@ -126,9 +126,10 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     t_param = store.t("t")
     b_param = store.t("b") if "b" in store.entries else None
     # N > 1: the gradient all-reduce overlaps the (last) backward, see dp.GradSync
-    # "fsdp" placement: the optimizer reduce-scatters the gradients itself (optax._sharded_adam_step)
+    # "fsdp" placement: every gradient range is summed onto its owner only (dp.GradShardSync), same overlap
     sharded = getattr(opt, "sharded", False)
-    sync = dp.GradSync(comm, store.grad) if (comm.size > 1 and config.get("overlap_grad_sync", True) and not sharded) else None
+    overlap = comm.size > 1 and config.get("overlap_grad_sync", True)
+    sync = (opt.grad_sync() if sharded else dp.GradSync(comm, store.grad)) if overlap else None
 
     if micro and n > micro:
       assert n % micro == 0, f"per-device batch {n} not divisible by microbatch {micro}"
@@ -224,7 +225,11 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     # DP: sum partial gradients and the loss shares (pmean of the reference).
     if sync is not None:
       sync.finish()
-    elif not sharded:
+    elif sharded:
+      late = opt.grad_sync()       # overlap_grad_sync = False: the whole buffer after the backward
+      if late is not None:
+        late.finish()
+    else:
       comm.all_reduce_sum_(store.grad)
     loss = stats[:1].clone()
     comm.all_reduce_scalars_(loss)

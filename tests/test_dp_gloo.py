@@ -107,6 +107,20 @@ def _worker(rank, world, port, n, E, out):
   params[lo:hi] = mine[:hi - lo] + 1.0          # "update" of this rank's slice only
   comm.all_gather_flat_(params, lo, hi, S)
   assert torch.equal(params, tot[:nflat] + 1.0), "all_gather_flat_: every rank must end with every slice"
+  # ---- the same through the trainer-facing objects: GradShardSync sums every range onto its owner only (in
+  # place, ranges handed over early + the complement in finish()), broadcast_slices_ exchanges the updated slices
+  part = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
+  buf = torch.cat([part, torch.full((7,), -5.0, dtype=torch.float64)])   # 7 frozen elements behind the trainable prefix
+  ssync = dp.GradShardSync(comm, buf, S, nflat)
+  ssync.launch(400, 700)          # straddles the slice boundary at 512: two owners
+  ssync.launch(0, 100)
+  ssync.finish()
+  assert torch.equal(buf[lo:hi], tot[lo:hi]), "GradShardSync: the own slice must hold the global sum"
+  assert torch.equal(buf[nflat:], torch.full((7,), -5.0, dtype=torch.float64)), "frozen tail touched"
+  params = torch.full((nflat,), -1.0, dtype=torch.float64)
+  params[lo:hi] = buf[lo:hi] + 1.0
+  comm.broadcast_slices_(params, S)
+  assert torch.equal(params, tot[:nflat] + 1.0), "broadcast_slices_: every rank must end with every slice"
   comm.barrier()
   out.put((rank, loss.item()))
   dist.destroy_process_group()

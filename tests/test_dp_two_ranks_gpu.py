@@ -37,7 +37,8 @@ def _config(**kw):
   c.grad_clip_norm = 1.0
   c.total_steps = 10
   for k, v in kw.items():
-    c[k] = v
+    if k != "extra_steps":   # test-only knob of _step
+      c[k] = v
   return c
 
 
@@ -52,11 +53,23 @@ def _step(comm, image, text, **kw):
   config = _config(**kw)
   state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, comm=comm,
                                      total_steps=config.total_steps)
-  state, meas = siglip.make_update_fn(model, config, comm=comm)(state, None, {"image": image, "labels": text})
+  fn = siglip.make_update_fn(model, config, comm=comm)
+  state, meas = fn(state, None, {"image": image, "labels": text})
   torch.cuda.synchronize()
   store = state["params"].store
   grads = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
   params = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
+  more = int(kw.get("extra_steps", 0))
+  if more:   # further steps on the same batch; `more_digest` = a hash of every parameter's BITS after them
+    for _ in range(more):
+      state, meas2 = fn(state, None, {"image": image, "labels": text})
+    torch.cuda.synchronize()
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in u.tree_flatten_with_names(state["params"])[0]:
+      h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    sh = store.shadow.detach().cpu().view(torch.int16).numpy().tobytes()
+    params["__bits__"] = (h.hexdigest(), hashlib.sha256(sh).hexdigest(), float(meas2["training_loss"].item()))
   return meas["training_loss"].item(), meas["l2_grads"].item(), grads, params
 
 
@@ -73,7 +86,9 @@ def _worker(rank, world, port, out, kw):
   n = 8 // world
   dev = torch.device("cuda:0")
   loss, gn, grads, params = _step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev), **kw)
+  bits = params.pop("__bits__", None)
   digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
+  digest["__bits__"] = bits
   # numpy arrays are pickled by value (torch tensors would travel as shared-memory handles that
   # die with this process)
   out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest,
@@ -83,7 +98,8 @@ def _worker(rank, world, port, out, kw):
 
 
 FSDP = dict(sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)")],
-            schedule=dict(decay_type="cosine", warmup_steps=0))      # no warm-up: the first step really moves the weights
+            schedule=dict(decay_type="cosine", warmup_steps=0),      # no warm-up: the first step really moves the weights
+            extra_steps=2)      # 3 steps in all: the ranks' fp32 masters AND bf16 shadows must stay bit-identical
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2), dict(loss_fn="softmax"),
@@ -95,6 +111,7 @@ def test_two_ranks_match_single_process(dev, kw):
   from big_vision_amd import dp
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
   single_kw = {k: kw[k] for k in ("loss_fn", "schedule") if k in kw}      # same trainer / schedule, replicated, one process
+  kw = dict(kw)
   loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev), **single_kw)
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
@@ -115,6 +132,12 @@ def test_two_ranks_match_single_process(dev, kw):
   assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
   assert res[0][3] == res[1][3], "replicated parameters diverged between the ranks after the update"
   if "sharding_strategy" in kw:
+    # three sharded steps (reduce-to-owner overlapped with the backward, Adam on the own slice, in-place exchange,
+    # partial shadow refresh): every parameter bit and every bf16 shadow bit agrees between the ranks
+    b0, b1 = res[0][3]["__bits__"], res[1][3]["__bits__"]
+    assert b0 is not None and b0[0] == b1[0], "fp32 parameters differ between the ranks after 3 sharded steps"
+    assert b0[1] == b1[1], "bf16 shadows differ between the ranks after 3 sharded steps"
+    assert abs(b0[2] - b1[2]) <= 1e-6 * abs(b0[2]) and b0[2] < loss1, (b0[2], loss1)
     # "fsdp" placement: each rank's gradient buffer holds its PARTIAL sums (the optimizer reduce-scatters them),
     # each rank updated its own slice of the flat buffer and all-gathered the rest: the parameters after the
     # step must be the single-process step's.  Adam's first update is lr * g / (|g| + eps): a gradient that is
