@@ -34,6 +34,7 @@ def _worker(rank, world, port, out, force, kw=None):
   n = 8 // world
   dev = torch.device("cuda", rank)
   loss, gn, grads, params = T._step(comm, image[rank * n:(rank + 1) * n].to(dev), text[rank * n:(rank + 1) * n].to(dev), **(kw or {}))
+  params.pop("__bits__", None)   # (bit digests of the multi-step FSDP case of test_dp_two_ranks_gpu)
   digest = {k: (v.sum().item(), v.abs().sum().item()) for k, v in params.items()}
   out.put((rank, loss, gn, {k: v.numpy() for k, v in grads.items()} if rank == 0 else None, digest,
            {k: v.numpy() for k, v in params.items()} if (rank == 0 and kw) else None))
@@ -83,9 +84,10 @@ def test_rccl_call_path_on_one_gpu(dev):
 
 
 def test_fsdp_placement_over_rccl_on_one_gpu(dev):
-  """config.sharding_strategy fsdp on a ONE-rank RCCL group with the collectives forced on: reduce_scatter_tensor
-  of the gradients and all_gather_into_tensor of the updated parameters really go through ProcessGroupNCCL
-  (over one rank both are the identity), the sharded Adam step runs on the slice [0, P): the parameters after the
+  """config.sharding_strategy fsdp on a ONE-rank RCCL group with the collectives forced on: the per-range `reduce`
+  of the gradients onto their owner (dp.GradShardSync, on the side stream during the backward) and the `broadcast`
+  of the updated slices really go through ProcessGroupNCCL (over one rank both are the identity), the sharded
+  Adam step runs on the slice [0, P) for three steps (the comparison below is after the first): the parameters after the
   step must be the replicated single-process step's (up to the sign of an Adam update of a ~0 gradient: the bias
   gradients are summed with fp32 atomics, run-to-run order noise; one update = lr = 1e-3)."""
   sys.path.insert(0, os.path.join(ROOT, "tests"))
