@@ -49,7 +49,7 @@ IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 DOMINANT = (("bv_gemm_bf16", "bv_gemm_bf16_colsum"), 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
-PMC_PROFILE = "r03_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
+PMC_PROFILE = "r04_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
 DOMINANT_KERNEL = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
 
 
@@ -90,7 +90,7 @@ class GemmObserver:
 
 def pmc_traffic(world, micro):
   """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
-  THIS command (profiles/r03_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
+  THIS command (profiles/r04_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
   be read from inside the process).  None when the profile does not match the configuration."""
   path = os.path.join(ROOT, "profiles", PMC_PROFILE)
   try:
