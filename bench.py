@@ -112,7 +112,7 @@ def pmc_traffic(world, micro):
 # -m gpu step tests measured for that mode), never as `value`.
 RESIDUAL_STREAM = "float32"
 # the -m gpu case that runs exactly the bf16 object's mode: B/16 + text-B through micro-batches with gelu(h)-free contexts
-BF16_STREAM_PARITY = ("profiles/r03_parity_report.jsonl", "siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, bfloat16 stream")
+BF16_STREAM_PARITY = ("profiles/r04_parity_report.jsonl", "siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, bfloat16 stream")
 
 
 # siglip.make_update_fn's state_cache["light"] -> what a kept micro-batch context holds
