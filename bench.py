@@ -147,7 +147,7 @@ def synthetic_batch(n, dev, seed):
   return image.contiguous(), text.contiguous()
 
 
-def cpu_baseline(sample_pairs):
+def cpu_baseline(sample_pairs, samples=2):
   """Full SigLIP step (fwd + bwd + Adam chain) of the SAME model on the CPU oracle."""
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import bv_oracle as O
@@ -175,12 +175,16 @@ def cpu_baseline(sample_pairs):
     return float(loss.detach())
 
   step(2)  # page in / thread-pool warm-up
-  t0 = time.perf_counter()
-  step(sample_pairs)
-  dt = time.perf_counter() - t0
-  return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-          "sample": f"1 full step (fwd+bwd+Adam) of the same ViT-B/16+text-B model on {sample_pairs} "
-                    f"pairs, fp32 torch-CPU oracle, {dt:.1f} s"}
+  times = []
+  for _ in range(max(1, samples)):
+    t0 = time.perf_counter()
+    step(sample_pairs)
+    times.append(time.perf_counter() - t0)
+  dt = min(times)
+  return {"value": sample_pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "samples": len(times),
+          "sample_seconds": [round(t, 2) for t in times],
+          "sample": f"best of {len(times)} full steps (fwd+bwd+Adam) of the same ViT-B/16+text-B model on {sample_pairs} "
+                    f"pairs each, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
 def bf16_stream_parity():
@@ -582,7 +586,6 @@ def main():
     line["configs"] = configs_object(dev, args.configs_steps)
   if world == 1 and not args.no_cpu_baseline:
     line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-    line["cpu_baseline"]["samples"] = 1
   sys.stdout.flush()
   os.write(json_fd, (json.dumps(line) + "\n").encode())
 
