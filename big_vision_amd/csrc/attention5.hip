@@ -251,9 +251,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
 #pragma unroll
       for (int j = 0; j < (R + NTL - 1) / NTL; ++j) {
         const int q = ll + j * NTL;
-        // base-2 units; clamped from below so that exp2(0 - lse) of a PADDED key (k = v = 0: S = 0) stays finite
-        // instead of being masked per score (real rows: S c - lse <= 0 always; -120 is never reached by data)
-        if (q < R) lse_s[q] = fmaxf(pl[j] * LOG2E, -120.f);
+        if (q < R) lse_s[q] = pl[j] * LOG2E;   // base-2 units
       }
     };
     // column sums of the dO tile held in pg: every piece of a lane is the same 8-column chunk (NTL % 8 == 0), so a
@@ -370,14 +368,18 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         o.nl = -lse_s[f * 16 + lr];
         return o;
       };
+      // Padded keys (rows >= L of the last fragment; k = v = 0) are masked for free: their S^T accumulators START at
+      // -1e30 instead of 0, so exp2 gives P = 0 exactly - for any lse, without a select per score.  Everything
+      // downstream (P in the LDS, dS, cs) is then exactly 0 for them.
+      const int lim = L - wave * 16 - lg * 4;   // key 4 lg + r of this wave's fragment exists for r < lim
+      const f32x4 st0 = f32x4{0 < lim ? 0.f : -1e30f, 1 < lim ? 0.f : -1e30f, 2 < lim ? 0.f : -1e30f,
+                              3 < lim ? 0.f : -1e30f};
       auto go = [&](int f, const Ops& o) __attribute__((always_inline)) {
-        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 st = st0, dp = f32x4{0.f, 0.f, 0.f, 0.f};
         st = mfma16(k0, o.q0, st);
         st = mfma16(k1, o.q1, st);
         dp = mfma16(v0, o.g0, dp);
         dp = mfma16(v1, o.g1, dp);
-        // padded keys (k = v = 0): S = 0 and P = exp2(-lse) is finite (lse is clamped), dP = 0 exactly: they add
-        // nothing to delta, and whatever they leave in P / dS^T meets zero K rows / is never stored
         f32x4 e;
         float x = 0.f;
 #pragma unroll

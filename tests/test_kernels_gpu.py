@@ -415,6 +415,33 @@ def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
     print(f"{name}-bias gradient: |err| identities {e_id:.3e}, column sums {e_cs:.3e}, |ref| {cs[sl].norm().item():.3e}")
 
 
+@pytest.mark.parametrize("L", [196, 197, 33, 64])
+def test_attention_backward_with_hugely_negative_scores(dev, L):
+  """Every score of a row around -250 (lse ~ -245): exp2(-lse) of a PADDED key (k = v = 0, S = 0) would be 2^353 =
+  inf.  The one-launch backward masks padded keys through the accumulator init of S^T (attention5.hip), so it stays
+  finite and exact for any lse; checked against fp64."""
+  from big_vision_amd import ops
+  n, H = 3, 2
+  u = rnd((1, 64), dev, 31)
+  u = u / u.norm() * 32.0
+  q = -2.0 * u + 0.05 * rnd((n * L, H, 64), dev, 32)          # q . k / 8 ~ -256 for every key
+  k = u + 0.05 * rnd((n * L, H, 64), dev, 33)
+  v = rnd((n * L, H, 64), dev, 34)
+  qkv = torch.stack([q, k, v], 1).reshape(n * L, 3 * H * 64).to(BF16)
+  qr = qkv.double().requires_grad_(True)
+  o_ref, lse_ref = _attn_ref(qr, n, L, H)
+  assert lse_ref.max().item() < -150
+  o, lse = ops.attn_fwd(qkv, n, L, H)
+  assert_close(lse, lse_ref, 1e-4, 5e-2, "lse")
+  d_o = rnd((n * L, H * 64), dev, 35, dtype=BF16)
+  o_ref.backward(d_o.double())
+  db = torch.zeros((3 * H * 64,), device=dev)
+  dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
+  assert torch.isfinite(dqkv.float()).all() and torch.isfinite(db).all()
+  g = qr.grad
+  assert_close(dqkv, g, 5e-2, 5e-2 * g.abs().max().item(), "dqkv at lse ~ -245")
+
+
 def test_attention_peaked_softmax(dev):
   """One key dominates each row (large logits): exercises the max-subtraction."""
   from big_vision_amd import ops
