@@ -92,17 +92,21 @@ class Comm:
       dist.all_gather_into_tensor(full, mine, group=self.group)
     flat.copy_(full[:n])
 
-  def broadcast_slices_(self, flat: torch.Tensor, S: int):
-    """In place: slice [r * S, (r + 1) * S) of `flat` (cut at its end) is sent by rank r to everybody - the
-    parameter exchange of the sharded optimizer without staging buffers (size ranks, size broadcasts)."""
+  def broadcast_ranges_(self, flat: torch.Tensor, bounds):
+    """In place: the range [bounds[r], bounds[r + 1]) of `flat` is sent by rank r to everybody - the parameter
+    exchange of the sharded optimizer without staging buffers (size ranks, size broadcasts)."""
     if not self.active:
       return
-    n = flat.numel()
     for r in range(self.size):
-      a, b = min(n, r * S), min(n, (r + 1) * S)
+      a, b = int(bounds[r]), int(bounds[r + 1])
       if b > a:
         src = dist.get_global_rank(self.group, r) if self.group is not None else r
         dist.broadcast(flat[a:b], src=src, group=self.group)
+
+  def broadcast_slices_(self, flat: torch.Tensor, S: int):
+    """broadcast_ranges_ with equal slices of length S (cut at the end of `flat`)."""
+    n = flat.numel()
+    self.broadcast_ranges_(flat, [min(n, r * S) for r in range(self.size + 1)])
 
   # ----------------------------------------------------------------- grads --
   def all_reduce_sum_(self, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
@@ -193,24 +197,28 @@ class GradSync:
 
 
 class GradShardSync(GradSync):
-  """GradSync for the sharded optimizer ("fsdp" placement, optax.Optimizer(shard=True)): rank r OWNS the slice
-  [r * S, (r + 1) * S) of the flat trainable gradient buffer, and a final range is summed onto its owner(s) only
-  (`reduce` per owner, in place) instead of onto every rank - half the bytes of an all-reduce, the other half
-  being the parameter exchange after the update.  Same launch / launch_gaps / finish protocol, so the ranges the
-  backward hands over block by block overlap the remaining GEMMs exactly like the replicated path; no staging
-  copy (round 3 reduce-scattered a zero-padded 813 MB copy after the whole backward).  After finish() the own
-  slice of `flat` holds the global sum; the rest of the buffer holds partial sums nobody reads."""
+  """GradSync for the sharded optimizer ("fsdp" placement, optax.Optimizer(shard=True)): rank r OWNS the range
+  [bounds[r], bounds[r + 1]) of the flat trainable gradient buffer (Adam: equal slices of whole 1024-element chunks;
+  Adafactor: runs of whole tensors), and a final range is summed onto its owner(s) only (`reduce` per owner, in
+  place) instead of onto every rank - half the bytes of an all-reduce, the other half being the parameter exchange
+  after the update.  Same launch / launch_gaps / finish protocol, so the ranges the backward hands over block by
+  block overlap the remaining GEMMs exactly like the replicated path; no staging copy (round 3 reduce-scattered a
+  zero-padded 813 MB copy after the whole backward).  After finish() the own range of `flat` holds the global
+  sum; the rest of the buffer holds partial sums nobody reads."""
 
-  def __init__(self, comm: Comm, flat: torch.Tensor, S: int, n_tr: int, bucket_bytes: int = 256 << 20):
-    super().__init__(comm, flat[:n_tr], bucket_bytes)
-    self.S = int(S)
+  def __init__(self, comm: Comm, flat: torch.Tensor, bounds, bucket_bytes: int = 256 << 20):
+    bounds = [int(b) for b in bounds]
+    assert len(bounds) == comm.size + 1 and bounds[0] == 0 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    super().__init__(comm, flat[:bounds[-1]], bucket_bytes)
+    self.bounds = bounds
 
   def _collective(self, lo: int, hi: int):
+    import bisect
     comm = self.comm
     pos = lo
     while pos < hi:
-      owner = pos // self.S
-      end = min(hi, (owner + 1) * self.S)
+      owner = bisect.bisect_right(self.bounds, pos) - 1
+      end = min(hi, self.bounds[owner + 1])
       dst = dist.get_global_rank(comm.group, owner) if comm.group is not None else owner
       dist.reduce(self.flat[pos:end], dst=dst, group=comm.group)
       pos = end

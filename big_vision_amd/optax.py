@@ -154,9 +154,6 @@ class Optimizer:
       mu_dtype = okw.get("mu_dtype")
       mu_dtype = torch.bfloat16 if str(mu_dtype) in ("bfloat16", "torch.bfloat16") else torch.float32
     elif self.name in ADAFACTOR_NAMES:
-      if self.sharded:
-        raise NotImplementedError("fsdp placement with scale_by_adafactor: the factored statistics are per-leaf "
-                                  "row / column vectors, not sliceable with the flat buffer; use scale_by_adam or replicate")
       self.clip_norm = float(config.get("grad_clip_norm") or 0.0)
       _refuse_per_example_clip(config)
       self.lr = float(config["lr"])
@@ -195,6 +192,7 @@ class Optimizer:
       self.S = (n_tr + N * 1024 - 1) // (N * 1024) * 1024           # slice length, a whole number of 1024-chunks
       self.lo = min(n_tr, r * self.S)
       self.hi = min(n_tr, self.lo + self.S)
+      self.bounds = [min(n_tr, i * self.S) for i in range(N + 1)]
       n_own = self.S
     else:
       self.lo, self.hi, n_own = 0, n_tr, n_tr
@@ -222,6 +220,17 @@ class Optimizer:
     mom_dtype = torch.float32 if str(mdt) in ("float32", "torch.float32") else torch.bfloat16
     self.af_leaves = []
     off_state = 0
+    # "fsdp" placement: rank r owns a run of whole store entries (the factored statistics are per tensor, so the
+    # flat buffer is cut at tensor boundaries: entry e belongs to the rank whose equal share of the trainable
+    # prefix its first element falls into); bounds[r] .. bounds[r + 1] is that run as a flat range
+    if self.sharded:
+      from big_vision_amd import dp
+      self.comm = self.comm or dp.Comm()
+      N, n_tr = self.comm.size, st.trainable_count
+      share = (n_tr + N - 1) // N
+      starts = sorted(e.offset for e in st.entries.values() if e.name not in st.frozen)
+      self.bounds = [0] + [next((o for o in starts if o >= r * share), n_tr) for r in range(1, N)] + [n_tr]
+      self.lo, self.hi = self.bounds[self.comm.rank], self.bounds[self.comm.rank + 1]
     for leaf, (sname, sl) in st.leaf_index.items():
       if sname in st.frozen:
         continue
@@ -276,7 +285,8 @@ class Optimizer:
       extn = st.ext_of[leaf]
       self.af_leaves.append(dict(leaf=leaf, view=view, factored=fd is not None, dims=fd, shape=shape, rest=rest,
                                  soff=off_state, n_state=n_state, lr_eff=self.lr * lr_mult[extn], wd=wd[extn],
-                                 sched=sched_idx_of_leaf[extn], B=B, R=R, C=C))
+                                 sched=sched_idx_of_leaf[extn], B=B, R=R, C=C,
+                                 own=(not self.sharded) or (self.lo <= e.offset < self.hi)))
       off_state += (n_state + 3) // 4 * 4
     self.af_state = torch.zeros(max(4, off_state), device=dev, dtype=torch.float32)
     # device table of all leaves (struct bv_af_leaf, include/bvhip.h) for the batched step: four launches per
@@ -286,9 +296,11 @@ class Optimizer:
                         ("factored", np.int32), ("sched_idx", np.int32), ("r_fast", np.int32), ("pad_", np.int32),
                         ("lr_eff", np.float32), ("wd", np.float32)], align=True)
     assert AF_LEAF.itemsize == 88, AF_LEAF.itemsize
-    tab = np.zeros(len(self.af_leaves), AF_LEAF)
+    own = [lf for lf in self.af_leaves if lf["own"]]   # the leaves this rank updates (all of them when replicated)
+    self.af_nown = len(own)
+    tab = np.zeros(max(1, len(own)), AF_LEAF)
     mx = dict(rows=0, cols=0, b=0, total=0)
-    for i, lf in enumerate(self.af_leaves):
+    for i, lf in enumerate(own):
       off, B1, B2, R, C, sB1, sB2, sR, sC = (int(x) for x in lf["view"])
       tab[i] = (off, sB1, sB2, sR, sC, lf["soff"], B1, B2, R, C, int(lf["factored"]), lf["sched"], int(sR < sC), 0,
                 lf["lr_eff"], lf["wd"])
@@ -306,22 +318,55 @@ class Optimizer:
     self._frozen_sq = None
 
   def _adafactor_step(self):
+    """One fused Adafactor step.  "fsdp" placement: the trainer summed every gradient range onto the rank that owns
+    it (grad_sync(), ranges cut at tensor boundaries); this rank updates its own tensors (its rows of the leaf
+    table), the ranks exchange the updated fp32 ranges in place and cast what they do not own into the bf16 shadow -
+    the same protocol as the sharded Adam step."""
     st, af, k = self.store, self.af, self.count
     sched = [fn(k) for fn in self.schedule_fns]
     t = float(k - af["decay_offset"]) + 1.0
     decay = min(af["beta2_cap"], 1.0 - t ** (-af["decay_rate"]))     # optax.py:196-199
     self.gsq.zero_()
-    ops.sqnorm_(st.grad, self.gsq)
+    lo, hi = (self.lo, self.hi) if self.sharded else (0, st.trainable_count)
+    if hi > lo:
+      ops.sqnorm_(st.grad[lo:hi], self.gsq)
+    if self.sharded:
+      self.comm.all_reduce_scalars_(self.gsq)
     self.stats.zero_()
     mx = self.af_max
-    ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table, len(self.af_leaves), mx["rows"],
-                        mx["cols"], mx["b"], mx["total"], self.af_state, self.gsq, self.clip_norm, decay, af["eps"],
-                        af["momentum"], sched, self.stats)
+    if self.af_nown:
+      ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table, self.af_nown, mx["rows"],
+                          mx["cols"], mx["b"], mx["total"], self.af_state, self.gsq, self.clip_norm, decay, af["eps"],
+                          af["momentum"], sched, self.stats)
+    if self.sharded:
+      comm, n_tr = self.comm, st.trainable_count
+      comm.all_reduce_scalars_(self.stats)
+      comm.broadcast_ranges_(st.master[:n_tr], self.bounds)
+      if comm.active:
+        for a, b in ((0, lo), (hi, n_tr)):
+          if b > a:
+            ops.cast_bf16(st.master[a:b], st.shadow[a:b])
     self.count = k + 1
     st.shadow_version += 1
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
+
+  def _gather_af_state(self):
+    """"fsdp" placement, before the state is read as a whole (checkpoint): every rank's statistics and momentum of
+    the tensors it owns, broadcast in place.  A COLLECTIVE: every rank must enter state_tree()."""
+    if not (self.sharded and self.comm.active):
+      return
+    sb = [0] * (self.comm.size + 1)      # af_state is laid out in leaf order = flat order: owners hold contiguous runs
+    for lf in self.af_leaves:
+      off = int(lf["view"][0])
+      r = max(i for i in range(self.comm.size) if self.bounds[i] <= off)
+      sb[r + 1] = max(sb[r + 1], lf["soff"] + (lf["n_state"] + 3) // 4 * 4)
+    for r in range(1, len(sb)):
+      sb[r] = max(sb[r], sb[r - 1])
+    self.comm.broadcast_ranges_(self.af_state, sb)
+    if self.mu is not None:
+      self.comm.broadcast_ranges_(self.mu[:self.bounds[-1]], self.bounds)
 
   def adafactor_state_numel(self):
     """Elements of the optax FactoredState (count, v_row, v_col, v) this optimizer stands for - the
@@ -395,7 +440,7 @@ class Optimizer:
     from big_vision_amd import dp
     if not self.sharded or self.comm is None or not self.comm.active:
       return None
-    return dp.GradShardSync(self.comm, self.store.grad, self.S, self.store.trainable_count)
+    return dp.GradShardSync(self.comm, self.store.grad, self.bounds)
 
   def _sharded_adam_step(self):
     """"fsdp" placement.  The trainer has summed every gradient range onto its OWNER during the backward
@@ -422,7 +467,7 @@ class Optimizer:
                      self.chunk_seg[lo // 1024:], n_own, sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
                      1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
     comm.all_reduce_scalars_(self.stats)
-    comm.broadcast_slices_(st.master[:n_tr], S)          # every rank's updated slice into every rank's master
+    comm.broadcast_ranges_(st.master[:n_tr], self.bounds)   # every rank's updated slice into every rank's master
     self.count = k + 1
     if comm.active:
       for a, b in ((0, lo), (hi, n_tr)):
@@ -487,6 +532,7 @@ class Optimizer:
 
   def _opt_state_tree(self, cnt):
     if self.name in ADAFACTOR_NAMES:
+      self._gather_af_state()
       return self._af_state_tree(cnt)
     return {"0": cnt, "1": self._moment_tree(self._full_moment(self.mu)), "2": self._moment_tree(self._full_moment(self.nu))}
 

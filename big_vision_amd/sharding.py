@@ -15,16 +15,17 @@ RCCL all-reduce (big_vision_amd/dp.py).  Two placements exist:
   replicate  every axis unsharded on every rank (the default strategy).
   fsdp       `fsdp(axis=..., min_size_to_shard_mb=4)` (:104-139).  `infer_sharding` returns the spec the
              reference would return - the largest axis divisible by the device count of every tensor above the
-             size threshold carries the mesh axis name.  WHAT IS BUILT BEHIND IT (round 3): the state that the
+             size threshold carries the mesh axis name.  WHAT IS BUILT BEHIND IT: the state that the
              reference's FSDP spreads over the devices - parameters' fp32 masters' UPDATE and the optimizer
-             moments - is owned in contiguous 1/N slices of the flat buffer (`optax.Optimizer(shard=True)`):
-             reduce_scatter of the gradients, Adam on the own slice, all_gather of the updated parameters.  It
-             is a slice of the FLAT buffer, not a cut along each tensor's axis: the same bytes per rank, no
-             per-tensor bookkeeping, identical arithmetic (Adam is elementwise; the clip norm is all-reduced).
+             moments - is owned in contiguous ranges of the flat buffer (`optax.Optimizer(shard=True)`): every
+             gradient range is summed onto its owner during the backward (dp.GradShardSync), the owner updates
+             its range, the ranks exchange the updated ranges in place.  Adam: equal 1/N slices of whole
+             1024-element chunks (a slice of the FLAT buffer, not a cut along each tensor's axis: the same bytes
+             per rank, no per-tensor bookkeeping, identical arithmetic - Adam is elementwise, the clip norm is
+             all-reduced).  Adafactor (round 4): runs of WHOLE tensors (its factored statistics are per tensor).
              The gathered parameters stay resident between steps - every kernel of the step reads them and
-             0.8 GB is 0.3 % of the HBM - where XLA would re-gather per use; what is sharded in memory is
-             the optimizer state (2/3 of the train state).  Adafactor's factored statistics do not slice:
-             refused.
+             0.8 GB is 0.3 % of the HBM - where XLA would re-gather per use; what is sharded is the optimizer
+             work and (Adam) the moments.
 `shard_dim` and `logical_partitioning` raise NotImplementedError naming the parameter - instead of silently
 running replicated under a config that asked for something else.
 A spec is a tuple with one entry per array axis (None = not sharded), like the reference's

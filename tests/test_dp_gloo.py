@@ -111,7 +111,7 @@ def _worker(rank, world, port, n, E, out):
   # place, ranges handed over early + the complement in finish()), broadcast_slices_ exchanges the updated slices
   part = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
   buf = torch.cat([part, torch.full((7,), -5.0, dtype=torch.float64)])   # 7 frozen elements behind the trainable prefix
-  ssync = dp.GradShardSync(comm, buf, S, nflat)
+  ssync = dp.GradShardSync(comm, buf, [min(nflat, r * S) for r in range(world + 1)])
   ssync.launch(400, 700)          # straddles the slice boundary at 512: two owners
   ssync.launch(0, 100)
   ssync.finish()
@@ -121,6 +121,17 @@ def _worker(rank, world, port, n, E, out):
   params[lo:hi] = buf[lo:hi] + 1.0
   comm.broadcast_slices_(params, S)
   assert torch.equal(params, tot[:nflat] + 1.0), "broadcast_slices_: every rank must end with every slice"
+  # uneven, tensor-aligned ownership (Adafactor under fsdp): ranges [0, 300), [300, 1003)
+  ub = [0, 300, nflat] if world == 2 else [min(nflat, r * S) for r in range(world + 1)]
+  buf = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
+  us = dp.GradShardSync(comm, buf, ub)
+  us.launch(250, 350)
+  us.finish()
+  assert torch.equal(buf[ub[rank]:ub[rank + 1]], tot[ub[rank]:ub[rank + 1]])
+  pr = torch.full((nflat,), -1.0, dtype=torch.float64)
+  pr[ub[rank]:ub[rank + 1]] = buf[ub[rank]:ub[rank + 1]]
+  comm.broadcast_ranges_(pr, ub)
+  assert torch.equal(pr, tot[:nflat])
   comm.barrier()
   out.put((rank, loss.item()))
   dist.destroy_process_group()

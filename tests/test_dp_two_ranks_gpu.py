@@ -102,15 +102,19 @@ FSDP = dict(sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)
             extra_steps=2)      # 3 steps in all: the ranks' fp32 masters AND bf16 shadows must stay bit-identical
 
 
+# Adafactor under the fsdp placement: ownership by whole tensors (the factored statistics are per tensor)
+FSDP_AF = dict(FSDP, optax_name="big_vision.scale_by_adafactor")
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2), dict(loss_fn="softmax"),
-                                dict(loss_fn="sigmoid"), FSDP])
+                                dict(loss_fn="sigmoid"), FSDP, FSDP_AF])
 def test_two_ranks_match_single_process(dev, kw):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import bv_oracle as O
   from big_vision_amd import dp
   image, text = O.synthetic_batch(1, 8, 64, 16, 100)
-  single_kw = {k: kw[k] for k in ("loss_fn", "schedule") if k in kw}      # same trainer / schedule, replicated, one process
+  single_kw = {k: kw[k] for k in ("loss_fn", "schedule", "optax_name") if k in kw}   # same trainer / schedule / optimizer, replicated, one process
   kw = dict(kw)
   loss1, gn1, g1, p1 = _step(dp.Comm(), image.to(dev), text.to(dev), **single_kw)
   ctx = mp.get_context("spawn")
@@ -144,9 +148,13 @@ def test_two_ranks_match_single_process(dev, kw):
     # ~0 up to summation order may flip its sign, one update = lr = 1e-3.
     assert abs(res[0][1] - res[1][1]) <= 1e-9 * gn1, "ranks disagree on the global gradient norm"
     gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
+    adafactor = "adafactor" in kw.get("optax_name", "")
     for k, v in p1.items():
       d = (v - torch.from_numpy(params2[k])).abs()
-      assert d.max().item() <= 2e-3 + 1e-6, (k, d.max().item())
+      # one update moves a weight by at most lr (Adam) / lr (1 - momentum) (Adafactor: unfactored 1-D leaves are sign-like
+      # on the first step too); a ~0 gradient may flip its sign between the two summation orders
+      step_max = 2.2e-4 if adafactor else 2e-3 + 1e-6
+      assert d.max().item() <= step_max, (k, d.max().item())
       if g1[k].norm().item() >= 1e-3 * gnorm:     # (tensors whose gradient is noise - the key bias - move by noise / (noise + eps))
         assert (d > 1e-6).double().mean().item() <= 0.05, (k, (d > 1e-6).double().mean().item())
     return
