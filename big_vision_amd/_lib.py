@@ -37,6 +37,7 @@ PROTOTYPES = {
     "bv_gemm_workspace_bytes": [c_int, c_int, c_int],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
                          c_float, c_float, P, P],
+    "bv_sgemm_path": [c_int],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_fwd_bf16x": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],

@@ -138,6 +138,10 @@ int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sb
                      float* C, long ldc, int M, int N, int K, float alpha, float beta,
                      const float* log_alpha /*device, optional: alpha *= exp(*log_alpha)*/,
                      void* stream);
+/* A/B switch of bv_sgemm_strided: 1 (default) = the fp32 matrix-pipe kernel (v_mfma_f32_32x32x2_f32) wherever a
+ * 64 x 64 tile is filled, 0 = always the VALU kernel.  Both are k-ordered fmaf chains: identical results.  mfma < 0
+ * only queries; returns the old value. */
+int bv_sgemm_path(int mfma);
 
 /* ------------------------------------------------------------ LayerNorm ----
  * flax nn.LayerNorm(): eps=1e-6, fp32 statistics (models/vit.py:92,103,160,181).

@@ -135,6 +135,36 @@ def test_sgemm_strided(dev):
   assert_close(out2, g.T @ a, 1e-5, 1e-4, "sgemm TN")
 
 
+@pytest.mark.parametrize("n,B,E", [(512, 1024, 768), (300, 700, 136), (1024, 1024, 768)])
+def test_sgemm_matrix_pipe_equals_the_valu_kernel(dev, n, B, E):
+  """The three products of the sigmoid loss (logits = zimg ztxt^T, dzimg = G ztxt, dztxt = G^T zimg) on the fp32 MFMA
+  kernel: bit-identical to the VALU kernel (both are k-ordered fmaf chains), and both match fp64."""
+  from big_vision_amd import ops, _lib
+  lib = _lib.load()
+  zi = rnd((n, E), dev, 1); zt = rnd((B, E), dev, 2); G = rnd((n, B), dev, 3, 0.01)
+  la = torch.tensor([0.7], device=dev)
+
+  def run():
+    raw = torch.empty((n, B), device=dev)
+    ops.sgemm(zi, E, 1, zt, 1, E, raw, n, B, E)
+    dzi = torch.empty((n, E), device=dev)
+    ops.sgemm(G, B, 1, zt, E, 1, dzi, n, E, B, log_alpha=la)
+    dzt = torch.full((B, E), 0.5, device=dev)
+    ops.sgemm(G, 1, B, zi, E, 1, dzt, B, E, n, alpha=2.0, beta=1.0)
+    return raw, dzi, dzt
+  new = run()
+  old = lib.bv_sgemm_path(0)
+  try:
+    ref = run()
+  finally:
+    lib.bv_sgemm_path(old)
+  for a, b, name in zip(new, ref, ("logits", "dzimg", "dztxt")):
+    assert torch.equal(a, b), f"{name}: matrix-pipe kernel differs from the VALU kernel"
+  assert_close(new[0], zi.double() @ zt.double().T, 1e-5, 1e-4, "logits vs fp64")
+  assert_close(new[1], math.exp(0.7) * (G.double() @ zt.double()), 1e-5, 1e-4, "dzimg vs fp64")
+  assert_close(new[2], 0.5 + 2.0 * (G.double().T @ zi.double()), 1e-5, 1e-4, "dztxt vs fp64")
+
+
 # ------------------------------------------------------------- LayerNorm -----
 # (70 001 x 768 fp32 = 215 MB: above the size at which the kernels switch to non-temporal loads, layernorm.hip ln_nt_for)
 @pytest.mark.parametrize("rows,D", [(1568, 768), (37, 128), (64, 1024), (9, 384), (70001, 768)])
