@@ -187,5 +187,11 @@ def test_fsdp_placement_builds_the_sharded_optimizer(dry):
   want = dict(u.tree_flatten_with_names(opt._moment_tree(opt._full_moment(before)))[0])
   assert all(torch.equal(keep[k], want[k]) for k in want)
   c2 = ConfigDict(dict(c.to_dict(), optax_name="big_vision.scale_by_adafactor"))
-  with pytest.raises(NotImplementedError, match="fsdp placement with scale_by_adafactor"):
-    trainer.make_train_state(model, c2, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
+  # Adafactor under fsdp (round 4): ownership by whole tensors - on one rank, every leaf is this rank's
+  state2, _ = trainer.make_train_state(model, c2, tuple(image.shape), tuple(text.shape), rng=0, device="cpu")
+  opt2 = state2["opt"]
+  assert opt2.sharded and opt2.bounds == [0, state2["params"].store.trainable_count]
+  assert opt2.af_nown == len(opt2.af_leaves) and all(lf["own"] for lf in opt2.af_leaves)
+  dry.clear()
+  state2, meas2 = trainer.make_update_fn(model, c2)(state2, None, {"image": image, "labels": text})
+  assert dry["bv_adafactor_step"] == 1 and opt2.count == 1
