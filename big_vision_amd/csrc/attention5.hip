@@ -33,7 +33,7 @@
 #include "attn_common.h"
 #include "bvhip_internal.h"
 #ifndef A5_UNROLL_1A
-#define A5_UNROLL_1A 1
+#define A5_UNROLL_1A 16   // fully unrolled (like 1b and phase 2): every LDS address is a base register + an immediate
 #endif
 // A5_ABL != 0 only in tools/probes/attn5_probe.hip (ablations, results are garbage): 1 = no phase 1a loop, 2 = no
 // phase 1b loop, 4 = no phase 2 loop, 16 = no global stores, 32 = the loader waves load nothing; A5_STAMPS: s_memtime
@@ -41,15 +41,16 @@
 #ifndef A5_ABL
 #define A5_ABL 0
 #endif
-// schedule knobs (swept by tools/probes/attn5_probe.hip; the defaults are the measured best)
+// schedule knobs (swept by tools/probes/attn5_probe.hip -> profiles/r04_attn5_schedule_sweep.txt; the defaults are the
+// measured best: all three loops fully unrolled, -5 % against rolled loops with running address adds)
 #ifndef A5_UNROLL_1B
-#define A5_UNROLL_1B 1
+#define A5_UNROLL_1B 16
 #endif
 #ifndef A5_UNROLL_P2
-#define A5_UNROLL_P2 2
+#define A5_UNROLL_P2 16
 #endif
 #ifndef A5_SB_1B
-#define A5_SB_1B 1      // sched_barrier between the two fragments of a phase-1b pair and in front of its MFMA block
+#define A5_SB_1B 0      // 1: sched_barrier between the two fragments of a phase-1b pair and in front of its MFMA block
 #endif
 #ifdef A5_STAMPS
 __device__ long* g_a5_stamps;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       };
       constexpr int NF = (A5_ABL & 1) ? 1 : KF;
       Ops a = rd(0), b = a;
-#pragma unroll 1
+#pragma unroll A5_UNROLL_1A
       for (int f = 0; f < NF; f += 2) {
         if (f + 1 < NF) b = rd(f + 1);
         go(f, a);

@@ -9,19 +9,15 @@ while read -r v; do
   echo "$i: $v" >> $O/variants.txt
   i=$((i+1))
 done <<'VARS'
-
--DA5_SB_1B=0
--DA5_UNROLL_1B=2
--DA5_SB_1B=0 -DA5_UNROLL_1B=2
--DA5_SB_1B=0 -DA5_UNROLL_1B=3
--DA5_SB_1B=0 -DA5_UNROLL_1B=6
--DA5_UNROLL_P2=1
--DA5_UNROLL_P2=3
--DA5_UNROLL_P2=6
--DA5_UNROLL_1A=2
--DA5_XSUM_SHFL
+-DA5_UNROLL_1A=1
+-DA5_UNROLL_1A=7
+-DA5_UNROLL_1A=7 -DA5_UNROLL_1B=6 -DA5_SB_1B=0
+-DA5_UNROLL_1A=7 -DA5_UNROLL_P2=6
+-DA5_UNROLL_1A=7 -DA5_UNROLL_1B=6 -DA5_SB_1B=0 -DA5_UNROLL_P2=6
+-DA5_UNROLL_1A=7 -DA5_UNROLL_1B=3 -DA5_SB_1B=0 -DA5_UNROLL_P2=6
+-DA5_UNROLL_1A=4 -DA5_UNROLL_P2=3
 VARS
 wait
 cat $O/variants.txt
-for j in $(seq 0 $((i-1))); do echo "variant $j" >> $O/sweep.txt; timeout 60 /tmp/a5v_$j.out 2048 196 >> $O/sweep.txt 2>&1; timeout 60 /tmp/a5v_$j.out 2048 64 >> $O/sweep.txt 2>&1; done
+for j in $(seq 0 $((i-1))); do echo "variant $j" >> $O/sweep.txt; timeout 60 /tmp/a5v_$j.out 2048 196 | grep -v "^  " >> $O/sweep.txt 2>&1; timeout 60 /tmp/a5v_$j.out 2048 64 | grep -v "^  " >> $O/sweep.txt 2>&1; done
 cat $O/sweep.txt
