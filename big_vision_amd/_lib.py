@@ -30,6 +30,7 @@ PROTOTYPES = {
     "bv_gemm_tune": [c_int, c_int, c_int],
     "bv_gemm_pre_issue": [c_int],
     "bv_gemm_roll": [c_int],
+    "bv_gemm_group_n": [c_int],
     "bv_gemm_reserve_cus": [c_int],
     "bv_gemm256_calls": [c_int],
     "bv_set_workspace": [P, c_long],

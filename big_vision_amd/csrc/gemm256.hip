@@ -56,6 +56,7 @@ struct G256Params {
   int aux_rows;
   int tiles_n;
   int ntiles;          // tiles_m * tiles_n
+  int group_n;         // k-major tile order: column tiles are walked in groups of this many (tile_mn below)
   int splits;          // split-K factor (work items = ntiles * splits)
   int ktiles_per_split;
   int epi;
@@ -109,6 +110,22 @@ __device__ __forceinline__ void st16(void* ptr, u32x4 v, bool nt) {
 __device__ __forceinline__ u32x4 ld16(const void* ptr, bool nt) {
   if (nt) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
   return *reinterpret_cast<const u32x4*>(ptr);
+}
+
+// Tile index -> (row tile, column tile) of the k-major kernels.  The ids an XCD's workgroups hold at one time are
+// consecutive, so their order decides what that XCD's 4 MiB L2 has to keep: with the column tile fastest over ALL
+// tiles_n columns (N = 3072: 12 weight panels = 4.7 MB) the weight panels fall out between two rounds and every
+// tile re-fetches its 393 KB panel from the fabric.  In groups of `g` column tiles (id order: column inside the
+// group, then row tile, then group) the XCD works on g weight panels that stay resident while the activation row
+// panels stream through, each shared by g workgroups.  g >= tiles_n is the plain order.
+__device__ __forceinline__ void tile_mn(int tile, int tiles_n, int ntiles, int g, int& tm, int& tn) {
+  if (g <= 0 || g >= tiles_n) { tm = tile / tiles_n; tn = tile - tm * tiles_n; return; }
+  const int tiles_m = ntiles / tiles_n;
+  const int per = tiles_m * g;
+  const int grp = tile / per, rem = tile - grp * per;
+  const int w = min(g, tiles_n - grp * g);    // the last group may be narrower
+  tm = rem / w;
+  tn = grp * g + (rem - tm * w);
 }
 
 // PROBE != 0 variants exist only for tools/probes/gemm256_probe.hip (bottleneck
@@ -193,7 +210,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     const int w = cs + idx + c.j * bpx;
     c.split = w / p.ntiles;
     c.tile = w - c.split * p.ntiles;
-    const int tm = c.tile / p.tiles_n, tn = c.tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_mn(c.tile, p.tiles_n, p.ntiles, KM ? p.group_n : 0, tm, tn);
     c.m0 = tm * 256; c.n0 = tn * 256;
     const int kt0 = c.split * p.ktiles_per_split;
     c.nk = min(p.ktiles_per_split, nk_all - kt0);
@@ -817,7 +835,8 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
   auto load_item = [&](Cursor& c) {
     c.tile = cs + idx + c.j * bpx;
     c.split = 0;
-    const int tm = c.tile / p.tiles_n, tn = c.tile - tm * p.tiles_n;
+    int tm, tn;
+    tile_mn(c.tile, p.tiles_n, p.ntiles, p.group_n, tm, tn);
     c.m0 = tm * 256; c.n0 = tn * 256;
     c.nk = nk_all;
     c.offA = (long)c.m0 * p.lda;
@@ -1248,7 +1267,7 @@ extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
 // Tuning knobs of the k-major kernel (tools/gemm_step_shapes.py A/Bs them):
 //   nt: bit 0 streaming stores, bit 1 streaming aux loads;  skew_mode / skew_pct: start skew of
 //   the workgroups as a percentage of one tile period (0 = off).  Negative = leave unchanged.
-static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1;
+static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1, g_group_n = 0;
 // Which epilogues run on the rolling-epilogue kernel (bit mask): 1 = +residual (default: the only one
 // it measured faster on, 2-5 %), 2 = none/bias (bf16), 4 = GELU.
 // CUs left free by the persistent grid (0 = all 256).  A workgroup of this kernel fills a CU (160 KiB of
@@ -1262,6 +1281,11 @@ extern "C" long bv_gemm256_calls(int which) { return which >= 0 && which < 3 ? g
 extern "C" int bv_gemm_reserve_cus(int n) {
   const int old = g_reserve;
   if (n >= 0) g_reserve = n > 128 ? 128 : n;
+  return old;
+}
+extern "C" int bv_gemm_group_n(int g) {   // column tiles per group of the k-major tile order (0 = all: plain order)
+  const int old = g_group_n;
+  if (g >= 0) g_group_n = g;
   return old;
 }
 extern "C" int bv_gemm_roll(int mask) {
@@ -1391,6 +1415,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
     p.skew_mode = g_skew_mode;
   }
   p.nt = g_nt;
+  p.group_n = km ? g_group_n : 0;
   p.pre_issue = g_pre;
   p.dbg = nullptr;
   const int cus = 256 - g_reserve;

@@ -119,6 +119,11 @@ int bv_gemm_pre_issue(int enable);
  * (alpha = 1), 2 = NONE (bf16 out), 4 = GELU; default 1 (the only one measured faster).
  * mask < 0 only queries; returns the old value. */
 int bv_gemm_roll(int mask);
+/* Tile order of the k-major 256x256 kernels: column tiles are walked in groups of g (inside a group: column tile
+ * fastest, then row tile), so the g weight panels an XCD works on stay in its L2 while the activation row panels
+ * stream through.  0 or >= N/256: the plain order (column tile fastest over the whole row).  Results do not
+ * depend on it.  g < 0 only queries; returns the old value. */
+int bv_gemm_group_n(int g);
 /* CUs the persistent 256x256 GEMM grid leaves free (0 = none; returns the old value, n < 0 only queries).
  * Its workgroups fill a CU, so kernels that must run BESIDE it (RCCL collectives overlapping the
  * backward) need CUs of their own; the data-parallel trainer reserves one per RCCL channel. */
