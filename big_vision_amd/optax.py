@@ -298,18 +298,33 @@ class Optimizer:
     assert AF_LEAF.itemsize == 88, AF_LEAF.itemsize
     own = [lf for lf in self.af_leaves if lf["own"]]   # the leaves this rank updates (all of them when replicated)
     self.af_nown = len(own)
+    # bv_adafactor_step launches a 2-D grid (extent of the LARGEST leaf of the table) x (leaves), and a workgroup beyond
+    # its own leaf's extent returns at once: with one table for the whole model the 300 biases / LayerNorm scales would
+    # each pay for the embedding table's 32 000 rows (~10 M empty workgroups per step at B/16 + text).  The table is
+    # therefore sorted by extent and cut into SIZE CLASSES (a new class where the row count or the element count
+    # drops below a quarter of the class's largest; unfactored leaves apart, they skip the three statistics launches);
+    # one bv_adafactor_step call per class, sized for that class.  The update does not depend on the order.
+    def extents(lf):
+      B = lf["B"]
+      return (B * lf["R"], B * lf["C"], B, B * lf["R"] * lf["C"])
+    own.sort(key=lambda lf: (not lf["factored"], -extents(lf)[3], -extents(lf)[0]))
     tab = np.zeros(max(1, len(own)), AF_LEAF)
-    mx = dict(rows=0, cols=0, b=0, total=0)
+    self.af_classes = []     # (first row of the table, rows, {rows, cols, b, total} grid extents)
     for i, lf in enumerate(own):
       off, B1, B2, R, C, sB1, sB2, sR, sC = (int(x) for x in lf["view"])
       tab[i] = (off, sB1, sB2, sR, sC, lf["soff"], B1, B2, R, C, int(lf["factored"]), lf["sched"], int(sR < sC), 0,
                 lf["lr_eff"], lf["wd"])
-      B = B1 * B2
+      rows, cols, b, total = extents(lf)
+      cur = self.af_classes[-1] if self.af_classes else None
+      if (cur is None or cur["factored"] != lf["factored"] or total * 4 < cur["total"]
+          or (lf["factored"] and rows * 4 < cur["rows"])):
+        cur = dict(first=i, n=0, factored=lf["factored"], rows=0, cols=0, b=0, total=0)
+        self.af_classes.append(cur)
+      cur["n"] += 1
       if lf["factored"]:
-        mx["rows"], mx["cols"], mx["b"] = max(mx["rows"], B * R), max(mx["cols"], B * C), max(mx["b"], B)
-      mx["total"] = max(mx["total"], B * R * C)
-    self.af_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
-    self.af_max = mx
+        cur["rows"], cur["cols"], cur["b"] = max(cur["rows"], rows), max(cur["cols"], cols), max(cur["b"], b)
+      cur["total"] = max(cur["total"], total)
+    self.af_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev).view(-1, AF_LEAF.itemsize)
     self.mu = torch.zeros(st.trainable_count, device=dev, dtype=mom_dtype) if self.af["momentum"] > 0 else None
     self.nu = None
     self.count = 0
@@ -333,11 +348,10 @@ class Optimizer:
     if self.sharded:
       self.comm.all_reduce_scalars_(self.gsq)
     self.stats.zero_()
-    mx = self.af_max
-    if self.af_nown:
-      ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table, self.af_nown, mx["rows"],
-                          mx["cols"], mx["b"], mx["total"], self.af_state, self.gsq, self.clip_norm, decay, af["eps"],
-                          af["momentum"], sched, self.stats)
+    for c in self.af_classes:     # one call per size class of the leaf table (four launches each, three for unfactored)
+      ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table[c["first"]:c["first"] + c["n"]], c["n"],
+                          c["rows"], c["cols"], c["b"], c["total"], self.af_state, self.gsq, self.clip_norm, decay,
+                          af["eps"], af["momentum"], sched, self.stats)
     if self.sharded:
       comm, n_tr = self.comm, st.trainable_count
       comm.all_reduce_scalars_(self.stats)

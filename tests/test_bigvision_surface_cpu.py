@@ -5,6 +5,7 @@ names of BASELINE.json (trainers.proj.image_text.contrastive, configs.proj.image
 must resolve to the accelerated implementation; names outside the hot path must fail loudly.
 CPU only: kernels are replaced by a recorder (dry run), so this checks plumbing, not numbers."""
 import collections
+import numpy as np
 import importlib
 
 import pytest
@@ -194,4 +195,17 @@ def test_fsdp_placement_builds_the_sharded_optimizer(dry):
   assert opt2.af_nown == len(opt2.af_leaves) and all(lf["own"] for lf in opt2.af_leaves)
   dry.clear()
   state2, meas2 = trainer.make_update_fn(model, c2)(state2, None, {"image": image, "labels": text})
-  assert dry["bv_adafactor_step"] == 1 and opt2.count == 1
+  # one bv_adafactor_step call per SIZE CLASS of the leaf table (a single table made every bias pay for
+  # the largest leaf's grid); the classes partition the table and no leaf sits in a class sized > 4x its own extent
+  assert dry["bv_adafactor_step"] == len(opt2.af_classes) >= 2 and opt2.count == 1
+  assert [c["first"] for c in opt2.af_classes] == [sum(d["n"] for d in opt2.af_classes[:i]) for i in range(len(opt2.af_classes))]
+  assert sum(c["n"] for c in opt2.af_classes) == opt2.af_nown
+  by_off = {int(lf["view"][0]): lf for lf in opt2.af_leaves}
+  rows = opt2.af_table.cpu().numpy().view(np.uint8).reshape(opt2.af_nown, 88)
+  for c in opt2.af_classes:
+    for r in rows[c["first"]:c["first"] + c["n"]]:
+      lf = by_off[int(r[:8].view(np.int64)[0])]
+      tot = lf["B"] * lf["R"] * lf["C"]
+      assert lf["factored"] == c["factored"] and tot <= c["total"] < 4 * tot + 4, (lf["leaf"], tot, c)
+      if lf["factored"]:
+        assert lf["B"] * lf["R"] <= c["rows"] <= 4 * lf["B"] * lf["R"], (lf["leaf"], c)
