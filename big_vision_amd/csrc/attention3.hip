@@ -194,17 +194,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
     }
     mfma_drain(oa[0], oa[1], oa[2], oa[3]);
     A3_STAMP(5 + it_ * 5);
-    if (qrow < L) {
-      bf16* orow = o + ((long)i * L + qrow) * H * DH + h * DH;
+    bf16* orow = o + ((long)i * L + qrow) * H * DH + h * DH;
+    if constexpr (KF == 17 && !TAIL) {
+      // (the masked 17-fragment instantiation sits at its 128-VGPR line: with the lane swaps of store_ot_rows hipcc
+      //  spills 3-9 registers inside the loop; it keeps the 8-byte pieces)
+      if (qrow < L) {
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        uint2 w;
-        w.x = pack_bf2(oa[d][0] * inv, oa[d][1] * inv);
-        w.y = pack_bf2(oa[d][2] * inv, oa[d][3] * inv);
-        *reinterpret_cast<uint2*>(orow + d * 16 + lg * 4) = w;
+        for (int d = 0; d < 4; ++d) {
+          uint2 w;
+          w.x = pack_bf2(oa[d][0] * inv, oa[d][1] * inv);
+          w.y = pack_bf2(oa[d][2] * inv, oa[d][3] * inv);
+          *reinterpret_cast<uint2*>(orow + d * 16 + lg * 4) = w;
+        }
       }
-      if (lg == 0) lse[((long)i * H + h) * L + qrow] = lsev;
+    } else {
+      store_ot_rows(orow, oa, inv, lg, qrow < L);   // 16-byte pieces: 16 rows x 64 B per store instruction
     }
+    if (qrow < L && lg == 0) lse[((long)i * H + h) * L + qrow] = lsev;
     A3_STAMP(6 + it_ * 5);
   }
 }

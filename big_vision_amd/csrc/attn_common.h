@@ -89,6 +89,25 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma16k16(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
+// Store of a TRANSPOSED 64 x 16 result (oa[d][r] = element (column d * 16 + 4 * lg + r) of row `lr`, the layout the
+// O^T / dQ^T accumulators have) as bf16 into 16 rows of 64 contiguous values, `row` = this lane's row pointer.
+// Straight from the accumulators a lane owns four 8-byte pieces of its row, and a wave store instruction writes 16
+// rows x 32 bytes: twice the instructions and half-empty write requests.  One v_permlane16_swap per dword first
+// pairs up the neighbouring pieces of two lane groups (a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1,
+// a.row3, b.row3}; inline asm, see attention5.hip on the builtin), so a lane stores two 16-byte pieces and an
+// instruction covers 16 rows x 64 bytes.  ALL 64 lanes must call it (the swaps); `valid` masks the stores.
+__device__ __forceinline__ void store_ot_rows(bf16* row, const f32x4 (&oa)[4], float mul, int lg, bool valid) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int dp = 0; dp < 4; dp += 2) {    // one pair of 16-column blocks at a time: four packed registers live
+    unsigned int a0 = pack_bf2(oa[dp][0] * mul, oa[dp][1] * mul), a1 = pack_bf2(oa[dp][2] * mul, oa[dp][3] * mul);
+    unsigned int b0 = pack_bf2(oa[dp + 1][0] * mul, oa[dp + 1][1] * mul), b1 = pack_bf2(oa[dp + 1][2] * mul, oa[dp + 1][3] * mul);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+    if (valid) *reinterpret_cast<u32x4_*>(row + (dp + (lg & 1)) * 16 + (lg >> 1) * 8) = u32x4_{a0, a1, b0, b1};
+  }
+}
+
 __device__ __forceinline__ float xmax4(float v) {   // max over the 4 lane groups (same lr)
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
