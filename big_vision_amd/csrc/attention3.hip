@@ -34,6 +34,14 @@
 #include <type_traits>
 #include "attn_common.h"
 #include "bvhip_internal.h"
+// scheduling fences of the forward loops at 3 workgroups per CU (168 VGPRs): one behind every A3_SB_S-th score
+// fragment / every A3_SB_PV-th pair of P V fragments bounds how many LDS operand reads hipcc hoists (0 = none)
+#ifndef A3_SB_S
+#define A3_SB_S 4
+#endif
+#ifndef A3_SB_PV
+#define A3_SB_PV 2
+#endif
 #ifndef A3_PROBE
 #define A3_PROBE 0   // != 0 only in tools/probes/attn3_probe.hip (ablations of the forward kernel)
 #endif
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       a = mfma16(k1, q1, a);
       s[f] = a;
       // bound load hoisting (register pressure): 2 fragments' operands in flight at 128 VGPRs, 4 at 168
-      if (KF > 13 || (WPS >= 4 ? (f & 1) : (f & 3) == 3)) __builtin_amdgcn_sched_barrier(0);
+      if (KF > 13 || (WPS >= 4 ? (f & 1) : (A3_SB_S > 0 && f % A3_SB_S == A3_SB_S - 1))) __builtin_amdgcn_sched_barrier(0);
     }
     // the NEXT fragment of this wave goes straight into the registers the scores no longer need
     // (rows >= L load nothing); its latency hides behind the softmax and the P V products
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
         const bf16x8 vf = t64_trpair(Vt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
         oa[d] = mfma16(vf, pf, oa[d]);
       }
-      if (WPS >= 4 || (fp & 1)) __builtin_amdgcn_sched_barrier(0);
+      if (WPS >= 4 || (A3_SB_PV > 0 && fp % A3_SB_PV == A3_SB_PV - 1)) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (KF & 1) {
       const s16x4 pf = pack4(s[KF - 1]);
