@@ -337,16 +337,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq_kernel(const bf16* 
           if (lr == 0) red[wave * 64 + d * 16 + lg * 4 + r] += t * scale;
         }
     }
-    if (qrow < L) {
-      bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        uint2 w;
-        w.x = pack_bf2(dq[d][0] * scale, dq[d][1] * scale);
-        w.y = pack_bf2(dq[d][2] * scale, dq[d][3] * scale);
-        *reinterpret_cast<uint2*>(row + d * 16 + lg * 4) = w;
-      }
-    }
+    store_ot_rows(dqkv + ((long)i * L + qrow) * ld + h * DH, dq, scale, lg, qrow < L);   // 16-byte pieces (attn_common.h)
     q0 = nq0; q1 = nq1; g0 = ng0; g1 = ng1; lse2 = nlse;
   }
   if (dbias) {   // per-(sample, head) column sums of dQ -> dbias[i][0][h][:]; the host sums over samples
@@ -506,16 +497,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq1_kernel(const bf16*
           if (lr == 0) red[wave * 64 + d * 16 + lg * 4 + r] += t * scale;
         }
     }
-    if (qrow < L) {
-      bf16* row = dqkv + ((long)i * L + qrow) * ld + h * DH;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        uint2 w;
-        w.x = pack_bf2(dq[d][0] * scale, dq[d][1] * scale);
-        w.y = pack_bf2(dq[d][2] * scale, dq[d][3] * scale);
-        *reinterpret_cast<uint2*>(row + d * 16 + lg * 4) = w;
-      }
-    }
+    store_ot_rows(dqkv + ((long)i * L + qrow) * ld + h * DH, dq, scale, lg, qrow < L);   // 16-byte pieces (attn_common.h)
   }
   if (dbias) {
     __syncthreads();
@@ -634,19 +616,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dkv_kernel(const bf16*
     // columns are garbage and are replaced by zeros (rows < L must still be written: the dX GEMM
     // reads every row of dqkv)
     const bool live = krow < Lk;
-    if (krow < L) {
+    {
       bf16* rowk = dqkv + ((long)i * L + krow) * ld + (long)H * DH + h * DH;
-      bf16* rowv = rowk + (long)H * DH;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        uint2 a, b;
-        a.x = live ? pack_bf2(dk[d][0] * scale, dk[d][1] * scale) : 0u;
-        a.y = live ? pack_bf2(dk[d][2] * scale, dk[d][3] * scale) : 0u;
-        *reinterpret_cast<uint2*>(rowk + d * 16 + lg * 4) = a;
-        b.x = live ? pack_bf2(dv[d][0], dv[d][1]) : 0u;
-        b.y = live ? pack_bf2(dv[d][2], dv[d][3]) : 0u;
-        *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
-      }
+      store_ot_rows(rowk, dk, scale, lg, krow < L, live);
+      store_ot_rows(rowk + (long)H * DH, dv, 1.0f, lg, krow < L, live);
     }
     if (dbias) {
       // column sums over this fragment's live keys (fp32, before the bf16 rounding), wave-private LDS row
@@ -810,19 +783,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* _
       // key rows >= Lk (masked or padded): k = v = 0 there, so S = 0 and P = exp2(-lse) != 0 - their columns are
       // garbage and are replaced by zeros (rows < L must still be written: the dX GEMM reads every row of dqkv)
       const bool live = krow < Lk;
-      if (krow < L) {
+      {
         bf16* rowk = dqkv + ((long)i * L + krow) * ld + (long)H * DH + h * DH;
-        bf16* rowv = rowk + (long)H * DH;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          uint2 a, b;
-          a.x = live ? pack_bf2(dk[e][d][0] * scale, dk[e][d][1] * scale) : 0u;
-          a.y = live ? pack_bf2(dk[e][d][2] * scale, dk[e][d][3] * scale) : 0u;
-          *reinterpret_cast<uint2*>(rowk + d * 16 + lg * 4) = a;
-          b.x = live ? pack_bf2(dv[e][d][0], dv[e][d][1]) : 0u;
-          b.y = live ? pack_bf2(dv[e][d][2], dv[e][d][3]) : 0u;
-          *reinterpret_cast<uint2*>(rowv + d * 16 + lg * 4) = b;
-        }
+        store_ot_rows(rowk, dk[e], scale, lg, krow < L, live);
+        store_ot_rows(rowk + (long)H * DH, dv[e], 1.0f, lg, krow < L, live);
       }
       if (dbias) {
 #pragma unroll

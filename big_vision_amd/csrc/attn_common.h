@@ -96,12 +96,15 @@ __device__ __forceinline__ f32x4 mfma16k16(s16x4 a, s16x4 b, f32x4 c) {
 // pairs up the neighbouring pieces of two lane groups (a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1,
 // a.row3, b.row3}; inline asm, see attention5.hip on the builtin), so a lane stores two 16-byte pieces and an
 // instruction covers 16 rows x 64 bytes.  ALL 64 lanes must call it (the swaps); `valid` masks the stores.
-__device__ __forceinline__ void store_ot_rows(bf16* row, const f32x4 (&oa)[4], float mul, int lg, bool valid) {
+// `live` = false writes zeros instead of the row (a per-ROW flag: the lanes that swap share their row).
+__device__ __forceinline__ void store_ot_rows(bf16* row, const f32x4 (&oa)[4], float mul, int lg, bool valid,
+                                              bool live = true) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int dp = 0; dp < 4; dp += 2) {    // one pair of 16-column blocks at a time: four packed registers live
     unsigned int a0 = pack_bf2(oa[dp][0] * mul, oa[dp][1] * mul), a1 = pack_bf2(oa[dp][2] * mul, oa[dp][3] * mul);
     unsigned int b0 = pack_bf2(oa[dp + 1][0] * mul, oa[dp + 1][1] * mul), b1 = pack_bf2(oa[dp + 1][2] * mul, oa[dp + 1][3] * mul);
+    if (!live) a0 = a1 = b0 = b1 = 0u;
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
     if (valid) *reinterpret_cast<u32x4_*>(row + (dp + (lg & 1)) * 16 + (lg >> 1) * 8) = u32x4_{a0, a1, b0, b1};
