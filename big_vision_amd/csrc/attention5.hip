@@ -64,6 +64,16 @@ __device__ long* g_a5_stamps;
 #else
 #define A5_STAMP(k)
 #endif
+#ifdef A5_WSTAMPS   // per-wave stamps of ONE workgroup (probe): [wave][8]
+__device__ long* g_a5_wstamps;
+#define A5_WSTAMP(k)                                                                     \
+  do {                                                                                   \
+    if (lane == 0 && blockIdx.x == 100 && pair == blockIdx.x + 2 * stride)               \
+      g_a5_wstamps[wave * 8 + (k)] = __builtin_amdgcn_s_memtime();                       \
+  } while (0)
+#else
+#define A5_WSTAMP(k)
+#endif
 
 int g_a5_bias_dpp = 0;   // 1: bias gradients by DPP column sums also where the identities apply (A/B, bv_attn_tune bit 256)
 
@@ -85,6 +95,11 @@ __device__ __forceinline__ int a5_opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// The same for the lane id, with its RANGE handed back to the compiler: behind the opaque copy hipcc no longer knows
+// that lr < 16 and lg < 4, cannot prove that a fragment's row offset (f * 16) leaves the swizzle bits of a row alone,
+// and re-derives every LDS address of every fragment with VALU instructions (7 of the 24 per tile of phase 1a, 230
+// per pair in phase 2) instead of folding f into the instruction's immediate offset.
+__device__ __forceinline__ int a5_lane(int lane) { return a5_opaque(lane) & 63; }
 
 // Sum over the four 16-lane rows of a wave (every lane gets the total): two lane-swap VALU operations instead of two
 // ds_bpermute round trips through the LDS crossbar.  Inline asm: the builtins of ROCm 7.2 drop the second result
@@ -130,7 +145,7 @@ struct A5 {
   static constexpr int OFF_G = R * 128;
   static constexpr int OFF_DS = 2 * R * 128;
   static constexpr int OFF_LSE = OFF_DS + KF * TS;
-  static constexpr int OFF_DEL = OFF_LSE + R * 4;
+  static constexpr int OFF_DEL = OFF_LSE + R * 8;   // lse: one (-lse2, -lse2) PAIR per query (an operand of v_pk_fma_f32)
   static constexpr int OFF_RED = OFF_DEL + R * 4;
   static constexpr int RED = KF * 192 * 4 > KF * R * 4 ? KF * 192 * 4 : KF * R * 4;   // column sums | delta partials [KF][R]
   static constexpr int OFF_CSO = OFF_RED + RED;
@@ -144,21 +159,24 @@ struct A5 {
 // acc[d]) -> bf16 -> a wave-private 2 KiB LDS image -> whole 128-byte rows -> global, 16 bytes per lane.  The scattered
 // form (sixteen 8-byte stores per lane, 32 bytes per row and instruction) is store-ISSUE bound: ~10 k cycles per
 // (sample, head) pair, a quarter of the first version of this kernel (profiles/r04_attn5_probe.txt).
-__device__ __forceinline__ void a5_store_rows(char* S, const f32x4 (&acc)[4], float mul, bf16* base, long ld, int row0,
-                                              int L, int lane, bool enable) {
-  const int lr = lane & 15, lg = lane >> 4;
+struct A5Rows {
+  char* w[4];       // where the lane puts its 8-byte piece of column block d
+  const char* r[2]; // the two 16-byte row pieces it reads back
+  uint32_t g[2];    // their byte offsets inside the (sample, head) block of dqkv
+  bool ok[2];       // row < L
+};
+__device__ __forceinline__ void a5_store_rows(const A5Rows& a, const f32x4 (&acc)[4], float mul, char* base) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     uint2 w;
     w.x = pack_bf2(acc[d][0] * mul, acc[d][1] * mul);
     w.y = pack_bf2(acc[d][2] * mul, acc[d][3] * mul);
-    *reinterpret_cast<uint2*>(S + lr * 128 + (((d * 2 + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8) = w;
+    *reinterpret_cast<uint2*>(a.w[d]) = w;
   }
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const int row = it * 8 + (lane >> 3), ch = lane & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(S + row * 128 + ((ch ^ (row & 7)) << 4));
-    if (enable && row0 + row < L) *reinterpret_cast<uint4*>(base + (long)(row0 + row) * ld + ch * 8) = v;
+    const uint4 v = *reinterpret_cast<const uint4*>(a.r[it]);
+    if (a.ok[it]) *reinterpret_cast<uint4*>(base + a.g[it]) = v;
   }
 }
 
@@ -252,7 +270,10 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
 #pragma unroll
       for (int j = 0; j < (R + NTL - 1) / NTL; ++j) {
         const int q = ll + j * NTL;
-        if (q < R) lse_s[q] = pl[j] * LOG2E;   // base-2 units
+        if (q < R) {   // minus lse in base-2 units, twice: phase 1a reads the pair with one ds_read_b64
+          const float v = -pl[j] * LOG2E;
+          *reinterpret_cast<float2*>(lse_s + 2 * q) = make_float2(v, v);
+        }
       }
     };
     // column sums of the dO tile held in pg: every piece of a lane is the same 8-column chunk (NTL % 8 == 0), so a
@@ -282,7 +303,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
     // read cst behind B6, the partial sums are overwritten behind B5.
     auto put_cst = [&]() __attribute__((always_inline)) {
       if (wave == KF) {
-        const int d = a5_opaque(lane), ch = d >> 3, e = d & 7;
+        const int d = a5_lane(lane), ch = d >> 3, e = d & 7;
         float t = 0.f;
 #pragma unroll
         for (int m = 0; m < NTL / 8; ++m) t += cso[(ch + 8 * m) * 8 + e];
@@ -311,7 +332,10 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       __syncthreads();   // B2
       __syncthreads();   // B3
       __syncthreads();   // B4: the dO tile and lse are free
+      A5_WSTAMP(3);
+      A5_WSTAMP(4);
       __syncthreads();   // B5
+      A5_WSTAMP(5);
       A5_STAMP(5);
       if (nxt < npairs) {   // under phase 2 of the compute waves
         A5_PUT_TILE(Gt, pg);
@@ -319,7 +343,9 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         if constexpr (BM >= 2) put_cso();   // partial column sums of the NEXT pair's dO
       }
       A5_STAMP(6);
+      A5_WSTAMP(6);
       __syncthreads();   // B6: the K tile (= Q tile) is free
+      A5_WSTAMP(7);
       A5_STAMP(9);
       if (nxt < npairs) A5_PUT_TILE(Qt, pq);
       A5_STAMP(10);
@@ -332,14 +358,14 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
   auto load_k = [&](int pair) __attribute__((always_inline)) {
     const int i = pair / H, h = pair % H;
     const bf16* kb_ = qkv + (long)i * L * ld + (long)H * DH + h * DH;
-    const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+    const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
     const int kr = wave * 16 + lr;
     k0 = gfrag(kb_, ld, kr, L, lg * 8); k1 = gfrag(kb_, ld, kr, L, 32 + lg * 8);
   };
   auto load_v = [&](int pair) __attribute__((always_inline)) {
     const int i = pair / H, h = pair % H;
     const bf16* vb_ = qkv + (long)i * L * ld + 2L * H * DH + h * DH;
-    const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+    const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
     const int kr = wave * 16 + lr;
     v0 = gfrag(vb_, ld, kr, L, lg * 8); v1 = gfrag(vb_, ld, kr, L, 32 + lg * 8);
   };
@@ -360,13 +386,24 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
     // LDS as bf16 - block (f, wave) of tile f, [q = lr][4 keys of lane group lg] - where phase 1b fetches it back
     // TRANSPOSED (ds_read_b64_tr_b16: P[q = 4 lg + r][key = lr]) instead of computing S and the exponentials again.
     {
-      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
-      struct Ops { bf16x8 q0, q1, g0, g1; float nl; };
+      const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
+      // Lane bases, each an OPAQUE register: every per-fragment address below is `base + compile-time constant`, i.e.
+      // the offset field of the LDS instruction.  (Written as t64_row(Qt, f * 16 + lr, lg) hipcc merged f * 16 into
+      // the row before the swizzle and re-derived the address of every fragment with VALU instructions: 7 of the 24
+      // per tile, on the SIMD whose issue time bounds the kernel.)  f * 16 leaves the swizzle bits of a row alone.
+      const int sw = t64_swz(lr);
+      const char* qa0 = smem + a5_opaque(lr * 128 + ((lg ^ sw) << 4));         // Q row lr, chunk lg (dO: + OFF_G)
+      const char* qa1 = smem + a5_opaque(lr * 128 + (((4 + lg) ^ sw) << 4));   // chunk 4 + lg
+      const char* la = smem + a5_opaque(C::OFF_LSE + lr * 8);                  // (-lse, -lse) of query lr
+      char* pwr = smem + a5_opaque(C::OFF_DS + lg * PL + (wave * 16 + lr) * 8);   // this wave's block of tile f: + f * TS
+      struct Ops { bf16x8 q0, q1, g0, g1; f32x2 nl; };
       auto rd = [&](int f) __attribute__((always_inline)) {
         Ops o;
-        o.q0 = t64_row(Qt, f * 16 + lr, lg); o.q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
-        o.g0 = t64_row(Gt, f * 16 + lr, lg); o.g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
-        o.nl = -lse_s[f * 16 + lr];
+        o.q0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qa0 + f * 2048));
+        o.q1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qa1 + f * 2048));
+        o.g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qa0 + C::OFF_G + f * 2048));
+        o.g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qa1 + C::OFF_G + f * 2048));
+        o.nl = *reinterpret_cast<const f32x2*>(la + f * 128);
         return o;
       };
       // Padded keys (rows >= L of the last fragment; k = v = 0) are masked for free: their S^T accumulators START at
@@ -375,32 +412,55 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       const int lim = L - wave * 16 - lg * 4;   // key 4 lg + r of this wave's fragment exists for r < lim
       const f32x4 st0 = f32x4{0 < lim ? 0.f : -1e30f, 1 < lim ? 0.f : -1e30f, 2 < lim ? 0.f : -1e30f,
                               3 < lim ? 0.f : -1e30f};
+      const f32x2 c2 = f32x2{c, c};
+      // one tile: returns this lane's partial of delta (its four keys of query lr); packed fp32 around the exponentials
       auto go = [&](int f, const Ops& o) __attribute__((always_inline)) {
         f32x4 st = st0, dp = f32x4{0.f, 0.f, 0.f, 0.f};
         st = mfma16(k0, o.q0, st);
         st = mfma16(k1, o.q1, st);
         dp = mfma16(v0, o.g0, dp);
         dp = mfma16(v1, o.g1, dp);
-        f32x4 e;
-        float x = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, o.nl));
-          x = __builtin_fmaf(e[r], dp[r], x);
-        }
-        *reinterpret_cast<s16x4*>(dSt + f * TS + lg * PL + (wave * 16 + lr) * 8) = pack4(e);
-        x = a5_xsum4(x);
-        if (lg == 0) dpart[wave * R + f * 16 + lr] = x;
+        const f32x2 a01 = __builtin_elementwise_fma(f32x2{st[0], st[1]}, c2, o.nl);
+        const f32x2 a23 = __builtin_elementwise_fma(f32x2{st[2], st[3]}, c2, o.nl);
+        const f32x4 e = f32x4{__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1]),
+                              __builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
+        f32x2 x2 = f32x2{e[0], e[1]} * f32x2{dp[0], dp[1]};
+        x2 = __builtin_elementwise_fma(f32x2{e[2], e[3]}, f32x2{dp[2], dp[3]}, x2);
+        *reinterpret_cast<s16x4*>(pwr + f * TS) = pack4(e);
+        return x2[0] + x2[1];
+      };
+      // Partials of FOUR tiles are summed over the four 16-lane rows together: two v_permlane32_swap, one
+      // v_permlane16_swap and three adds leave the total of tile f0 + {0, 2, 1, 3}[lg] in lane row lg (a' = {a.lo32,
+      // b.lo32}, b' = {a.hi32, b.hi32}; a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}),
+      // every lane writes one partial: 1.5 VALU operations per tile instead of 6 and no masked write.
+      float* dw4 = reinterpret_cast<float*>(smem + a5_opaque(C::OFF_RED + (wave * R + ((((lg & 1) << 1) | (lg >> 1)) * 16) + lr) * 4));
+      float* dw1 = reinterpret_cast<float*>(smem + a5_opaque(C::OFF_RED + (wave * R + lr) * 4));
+      auto red4 = [&](int f0, float xa, float xb, float xc, float xd) __attribute__((always_inline)) {
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xa), "+v"(xb));
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xc), "+v"(xd));
+        float t1 = xa + xb, t2 = xc + xd;
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t1), "+v"(t2));
+        dw4[f0 * 16] = t1 + t2;
       };
       constexpr int NF = (A5_ABL & 1) ? 1 : KF;
+      float xs[4] = {0.f, 0.f, 0.f, 0.f};
+      auto done = [&](int f, float x) __attribute__((always_inline)) {
+        if (f < (NF & ~3)) {
+          xs[f & 3] = x;
+          if ((f & 3) == 3) red4(f - 3, xs[0], xs[1], xs[2], xs[3]);
+        } else {   // the one to three tiles behind the last group of four
+          x = a5_xsum4(x);
+          if (lg == 0) dw1[f * 16] = x;
+        }
+      };
       Ops a = rd(0), b = a;
 #pragma unroll A5_UNROLL_1A
       for (int f = 0; f < NF; f += 2) {
         if (f + 1 < NF) b = rd(f + 1);
-        go(f, a);
+        done(f, go(f, a));
         if (f + 1 < NF) {
           if (f + 2 < NF) a = rd(f + 2);
-          go(f + 1, b);
+          done(f + 1, go(f + 1, b));
         }
       }
     }
@@ -408,7 +468,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
     __syncthreads();   // B2
     A5_STAMP(2);
     {   // fixed-order sum of the KF partials of every query row (four lanes per row, quad reduction): deterministic
-      const int tq = wave * 64 + a5_opaque(lane), row = tq >> 2, part = tq & 3;
+      const int tq = wave * 64 + a5_lane(lane), row = tq >> 2, part = tq & 3;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < (KF + 3) / 4; ++w)
@@ -418,6 +478,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       if (part == 0) del_s[row] = -t;   // minus delta: phase 1b starts its dP accumulators from it
     }
     __syncthreads();   // B3: delta complete; the partials are dead, the dS^T tiles may be written
+    A5_WSTAMP(0);
     A5_STAMP(3);
 
     // ---- phase 1b: dV^T, dK^T of this wave's key fragment; dS^T of every (query fragment, key fragment) -> LDS
@@ -432,23 +493,46 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
     // instead of four VALU adds per fragment and a cross-lane sum at the end)
     f32x4 csacc = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
+      // Lane bases (opaque registers, see phase 1a): every address of the loop is base + compile-time constant.
+      const int sw = t64_swz(lr);
+      const char* ga0 = smem + a5_opaque(C::OFF_G + lr * 128 + ((lg ^ sw) << 4));         // dO row lr, chunk lg
+      const char* ga1 = smem + a5_opaque(C::OFF_G + lr * 128 + (((4 + lg) ^ sw) << 4));   // chunk 4 + lg
+      const char* da = smem + a5_opaque(C::OFF_DEL + lg * 16);                            // -delta of rows 4 lg .. + 3
+      const char* ptr_ = smem + a5_opaque(C::OFF_DS + (lr & 3) * PL + (wave * 16 + 4 * lg + (lr >> 2)) * 8);   // a5_tr of this wave's P block
+      char* pwr = smem + a5_opaque(C::OFF_DS + lg * PL + (wave * 16 + lr) * 8);           // dS^T block (over the P block)
+      // transposed operand reads of the Q / dO tiles (t64_tr): the chunk position is (2 d + b) ^ swizzle - the four d
+      // blocks sit at a lane-dependent permutation of {0, 32, 64, 96} bytes, so each gets its own base register
+      const int trow = 4 * lg + (lr >> 2), tsw = t64_swz(trow);
+      const char* tq[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        tq[d] = smem + a5_opaque(trow * 128 + (((d * 2 + ((lr >> 1) & 1)) ^ tsw) << 4) + ((lr & 1) << 3));
+      auto trd = [&](const char* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+      };
+      auto trd2 = [&](const char* p) __attribute__((always_inline)) {   // rows 4 lg .. of two consecutive fragments
+        const s16x4 a = trd(p), b = trd(p + 2048);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
       // P and dS of query fragment f against the wave's key fragment: pw = bf16 P[q = 4 lg + r][key = lr] (from phase
       // 1a, transposed read), ds[r] = dS of the same elements.  dP - delta comes out of the MFMA: the accumulator starts
       // at -delta of its rows.
       auto pds = [&](int f, s16x4& pw, f32x4& ds) __attribute__((always_inline)) {
-        const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
-        const float4 d4 = *reinterpret_cast<const float4*>(del_s + f * 16 + lg * 4);
-        pw = a5_tr<PL>(dSt + f * TS, wave * 16 + 4 * lg, lr);
+        const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ga0 + f * 2048));
+        const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ga1 + f * 2048));
+        const float4 d4 = *reinterpret_cast<const float4*>(da + f * 64);
+        pw = trd(ptr_ + f * TS);
         f32x4 dp = f32x4{d4.x, d4.y, d4.z, d4.w};   // -delta of the fragment's rows
         dp = mfma16(g0, v0, dp);   // dP[q][key] - delta[q],  dP = sum_d dO[q][d] V[key][d]
         dp = mfma16(g1, v1, dp);
         const uint2 w = __builtin_bit_cast(uint2, pw);
-        ds[0] = bflo(w.x) * dp[0]; ds[1] = bfhi(w.x) * dp[1];
-        ds[2] = bflo(w.y) * dp[2]; ds[3] = bfhi(w.y) * dp[3];
+        const f32x2 s01 = f32x2{bflo(w.x), bfhi(w.x)} * f32x2{dp[0], dp[1]};
+        const f32x2 s23 = f32x2{bflo(w.y), bfhi(w.y)} * f32x2{dp[2], dp[3]};
+        ds = f32x4{s01[0], s01[1], s23[0], s23[1]};
         // dS^T[key][q = f * 16 + 4 lg .. + 3]: plane lg of tile f, 8 bytes per key - the bytes this wave's P block of
         // the tile occupied (read above; LDS operations of one wave complete in order)
-        *reinterpret_cast<s16x4*>(dSt + f * TS + lg * PL + (wave * 16 + lr) * 8) = pack4(ds);
+        *reinterpret_cast<s16x4*>(pwr + f * TS) = pack4(ds);
       };
 #pragma unroll A5_UNROLL_1B
       for (int ip = 0; ip < ((A5_ABL & 2) ? 1 : KF / 2); ++ip) {
@@ -466,8 +550,8 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         if (A5_SB_1B) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          const bf16x8 gt = t64_trpair(Gt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
-          const bf16x8 qt = t64_trpair(Qt, (2 * ip) * 16 + 4 * lg, (2 * ip + 1) * 16 + 4 * lg, d, lr);
+          const bf16x8 gt = trd2(tq[d] + C::OFF_G + (2 * ip) * 2048);
+          const bf16x8 qt = trd2(tq[d] + (2 * ip) * 2048);
           dv[d] = mfma16(gt, pf, dv[d]);    // D[d = 4 lg + r][key = lr]
           dk[d] = mfma16(qt, dsf, dk[d]);
         }
@@ -480,8 +564,8 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         if constexpr (BM == 2) csacc = mfma16k16(s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80}, dsf, csacc);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          dv[d] = mfma16k16(t64_tr(Gt, (KF - 1) * 16 + 4 * lg, d, lr), pf, dv[d]);
-          dk[d] = mfma16k16(t64_tr(Qt, (KF - 1) * 16 + 4 * lg, d, lr), dsf, dk[d]);
+          dv[d] = mfma16k16(trd(tq[d] + C::OFF_G + (KF - 1) * 2048), pf, dv[d]);
+          dk[d] = mfma16k16(trd(tq[d] + (KF - 1) * 2048), dsf, dk[d]);
         }
       }
       if constexpr (BM == 2) {
@@ -494,16 +578,22 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
           *reinterpret_cast<bf16*>(dSt + (KF - 1) * TS + 3 * PL + (wave * 16 + lr) * 8 + 6) = (bf16)cs;
       }
     }
+    A5_WSTAMP(1);
     a5_drain(dk[0], dk[1], dk[2], dk[3]);
     a5_drain(dv[0], dv[1], dv[2], dv[3]);
-    if (nxt < npairs) load_v(nxt);   // V is dead: the next pair's rows are in flight from here
+    // V is dead: the next pair's rows are in flight from here.  (With global loads in flight B4 and B5 release 1.7 k /
+    // 2.8 k cycles after their last arrival instead of ~0.4 k - per-wave stamps, profiles/r04_attn5_probe.txt - but every
+    // later position of the two requests measured SLOWER end to end: +2..8 %, profiles/NOTES_r04.md.)
+    if (nxt < npairs) load_v(nxt);
     A5_STAMP(4);
+    A5_WSTAMP(2);
     __syncthreads();   // B4: every dS^T tile complete; nobody reads the Q / dO tiles any more
+    A5_WSTAMP(3);
     A5_STAMP(5);
 
     // ---- K fragments -> the Q tile (T64 image, the A operand of phase 2)
     {
-      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
       const int row = wave * 16 + lr;
       *reinterpret_cast<uint4*>(Qt + row * 128 + ((lg ^ t64_swz(row)) << 4)) = __builtin_bit_cast(uint4, k0);
       *reinterpret_cast<uint4*>(Qt + row * 128 + (((4 + lg) ^ t64_swz(row)) << 4)) = __builtin_bit_cast(uint4, k1);
@@ -524,28 +614,43 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       }
     }
     A5_STAMP(6);
+    A5_WSTAMP(4);
     __syncthreads();   // B5: K tile complete
+    A5_WSTAMP(5);
     A5_STAMP(7);
 
     // ---- phase 2: dQ^T[d][q] of query fragment `wave` = sum_key K^T[d][key] dS^T[key][q]
     {
-      const int ln = a5_opaque(lane), lr = ln & 15, lg = ln >> 4;
+      const int ln = a5_lane(lane), lr = ln & 15, lg = ln >> 4;
       char* T = dSt + wave * TS;
+      // lane bases (opaque registers, see phase 1a): the dS^T planes of this wave's tile and the four d blocks of the K
+      // tile (transposed reads, lane-dependent chunk permutation as in phase 1b)
+      const char* sa = smem + a5_opaque(C::OFF_DS + wave * TS + (lr & 3) * PL + (4 * lg + (lr >> 2)) * 8);
+      const int trow = 4 * lg + (lr >> 2), tsw = t64_swz(trow);
+      const char* tk[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        tk[d] = smem + a5_opaque(trow * 128 + (((d * 2 + ((lr >> 1) & 1)) ^ tsw) << 4) + ((lr & 1) << 3));
+      auto trd = [&](const char* p) __attribute__((always_inline)) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+      };
+      auto trd2 = [&](const char* p, int step) __attribute__((always_inline)) {   // the same rows of two consecutive fragments
+        const s16x4 a = trd(p), b = trd(p + step);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
       f32x4 dq[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll A5_UNROLL_P2
       for (int fp = 0; fp < ((A5_ABL & 4) ? 1 : KF / 2); ++fp) {
-        const int ra = (2 * fp) * 16 + 4 * lg, rb = ra + 16;
-        const bf16x8 dsf = a5_trpair<PL>(T, ra, rb, lr);
+        const bf16x8 dsf = trd2(sa + fp * 256, 128);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma16(t64_trpair(Qt, ra, rb, d, lr), dsf, dq[d]);
+        for (int d = 0; d < 4; ++d) dq[d] = mfma16(trd2(tk[d] + fp * 4096, 2048), dsf, dq[d]);
       }
       if constexpr (KF & 1) {
-        const int ra = (KF - 1) * 16 + 4 * lg;
-        const s16x4 dsf = a5_tr<PL>(T, ra, lr);
+        const s16x4 dsf = trd(sa + (KF - 1) * 128);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma16k16(t64_tr(Qt, ra, d, lr), dsf, dq[d]);
+        for (int d = 0; d < 4; ++d) dq[d] = mfma16k16(trd(tk[d] + (KF - 1) * 2048), dsf, dq[d]);
       }
       a5_drain(dq[0], dq[1], dq[2], dq[3]);
       if constexpr (BM == 1 || BM == 3) {
@@ -567,20 +672,34 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
             for (int r = 0; r < 4; ++r) red[d * 16 + lg * 4 + r] = dq[d][r] * scale;
         }
       }
-      // ---- the wave's dQ rows, then its dK / dV rows, through its own (now dead) dS^T tile as whole rows
+      // ---- the wave's dQ rows, then its dK / dV rows, through its own (now dead) dS^T tile as whole rows (a5_store_rows;
+      // the lane's LDS positions and its offset inside the (sample, head) block are the same for all three)
       const bool st = !(A5_ABL & 16);
-      bf16* out = dqkv + (long)i * L * ld + h * DH;
-      a5_store_rows(T, dq, scale, out, ld, wave * 16, L, a5_opaque(lane), st);
-      a5_store_rows(T, dk, scale, out + (long)H * DH, ld, wave * 16, L, a5_opaque(lane), st);
-      a5_store_rows(T, dv, 1.0f, out + 2L * H * DH, ld, wave * 16, L, a5_opaque(lane), st);
+      char* outb = reinterpret_cast<char*>(dqkv + (long)i * L * ld + h * DH);   // wave-uniform
+      A5Rows rw;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        rw.w[d] = T + a5_opaque(lr * 128 + (((d * 2 + (lg >> 1)) ^ (lr & 7)) << 4) + (lg & 1) * 8);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (ln >> 3), ch = ln & 7;
+        rw.r[it] = T + a5_opaque(row * 128 + ((ch ^ (row & 7)) << 4));
+        rw.ok[it] = st && wave * 16 + row < L;
+        rw.g[it] = (uint32_t)a5_opaque((wave * 16 + row) * (int)(ld * 2) + ch * 16);
+      }
+      a5_store_rows(rw, dq, scale, outb);
+      a5_store_rows(rw, dk, scale, outb + (long)H * DH * 2);
+      a5_store_rows(rw, dv, 1.0f, outb + 4L * H * DH);
     }
     A5_STAMP(8);
+    A5_WSTAMP(6);
     __syncthreads();   // B6: the K tile, the dS^T tiles and `red` are free / complete
+    A5_WSTAMP(7);
     A5_STAMP(9);
     if constexpr (BM != 0) {
       // per-(sample, head) column sums -> dbias[i][which][h][:]; the host sums over samples
       if (wave < 3) {
-        const int which = wave, d = a5_opaque(lane), tid = wave * 64 + d;
+        const int which = wave, d = a5_lane(lane), tid = wave * 64 + d;
         float t = 0.f;
         if constexpr (BM == 1) {
 #pragma unroll

@@ -38,6 +38,10 @@ int main(int argc, char** argv) {
   long* st; (void)hipMalloc(&st, 4 * 3 * 16 * 8); (void)hipMemset(st, 0, 4 * 3 * 16 * 8);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a5_stamps), &st, sizeof(st));
 #endif
+#ifdef A5_WSTAMPS
+  long* wst; (void)hipMalloc(&wst, 16 * 8 * 8); (void)hipMemset(wst, 0, 16 * 8 * 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a5_wstamps), &wst, sizeof(wst));
+#endif
   for (int rep = 0; rep < 4; ++rep) {   // 1, 0, 1, 0: the first measurement of a process also warms the clocks up
     const int withb = (rep & 1) ^ 1;
     for (int i = 0; i < 3; ++i) bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, withb ? dbias : nullptr, n, L, H, nullptr);
@@ -64,6 +68,21 @@ int main(int argc, char** argv) {
         }
       }
     (void)hipMemset(st, 0, 4 * 3 * 16 * 8);
+#endif
+#ifdef A5_WSTAMPS
+    {
+      long w[16 * 8];
+      (void)hipMemcpy(w, wst, sizeof(w), hipMemcpyDeviceToHost);
+      long t0 = 0;
+      for (int v = 0; v < 16; ++v) if (w[v * 8 + 0] && (!t0 || w[v * 8 + 0] < t0)) t0 = w[v * 8 + 0];
+      printf("  workgroup 100, cycles since the first wave left B3: end 1b | at B4 | left B4 | at B5 | left B5 | at B6 | left B6\n");
+      for (int v = 0; v < 16; ++v) {
+        printf("   wave %2d:", v);
+        for (int k = 1; k < 8; ++k) printf(" %7ld", w[v * 8 + k] ? w[v * 8 + k] - t0 : -1L);
+        printf("\n");
+      }
+      (void)hipMemset(wst, 0, 16 * 8 * 8);
+    }
 #endif
   }
   return 0;
