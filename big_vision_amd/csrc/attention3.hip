@@ -36,6 +36,9 @@
 #include "bvhip_internal.h"
 // scheduling fences of the forward loops at 3 workgroups per CU (168 VGPRs): one behind every A3_SB_S-th score
 // fragment / every A3_SB_PV-th pair of P V fragments bounds how many LDS operand reads hipcc hoists (0 = none)
+#ifndef A3_PIPE
+#define A3_PIPE 1   // 1: software-pipelined S / P V loops of the 3-workgroups-per-CU forward (0: the plain loops, A/B)
+#endif
 #ifndef A3_SB_S
 #define A3_SB_S 4
 #endif
@@ -103,10 +106,55 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
   if (L > 0) return;
 #endif
   int it_ = 0;
+  // (software pipeline of the S loop, below: the first pair of key fragments of an iteration is requested at the end of
+  //  the previous iteration's S loop, the first V operands of the P V loop in front of the softmax)
+  // groups of two key fragments, the last one of three when KF is odd: KF / 2 groups, an EVEN number for every
+  // instantiation that runs this path (6, 14, 18), so the last group of an iteration works from register set 1 and
+  // set 0 is free for the next iteration's first group
+  constexpr int NG = KF / 2;
+  static_assert(!(A3_PIPE && WPS == 3) || (NG % 2 == 0 && NG >= 2), "attn3_fwd: the K prefetch ping-pong needs an even group count");
+  bf16x8 kk[2][3][2];
+  auto ldk = [&](int f, bf16x8 (&k)[2]) __attribute__((always_inline)) {
+    k[0] = t64_row(Kt, f * 16 + lr, lg);
+    k[1] = t64_row(Kt, f * 16 + lr, 4 + lg);
+  };
+  auto ldg = [&](int g, bf16x8 (&k)[3][2]) __attribute__((always_inline)) {   // group g: fragments 2 g, 2 g + 1 (, KF - 1)
+    ldk(2 * g, k[0]);
+    ldk(2 * g + 1, k[1]);
+    if ((KF & 1) && g == NG - 1) ldk(KF - 1, k[2]);
+  };
+  if constexpr (A3_PIPE && WPS == 3) ldg(0, kk[0]);
 
   for (; qf * 16 < L; qf += NW, ++it_) {
     A3_STAMP(2 + it_ * 5);
     f32x4 s[KF];
+    bf16x8 vv[2][4];
+    auto ldv = [&](int fp, bf16x8 (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) v[d] = t64_trpair(Vt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
+    };
+    if constexpr (A3_PIPE && WPS == 3) {
+      // software pipeline over PAIRS of key fragments: the K rows of the next pair are requested from the LDS before the
+      // MFMAs of the current pair are issued (two register sets, ping-pong; 3 workgroups per CU leave 168 VGPRs).  In
+      // the plain loop below every group of MFMAs waits for its own operands' LDS round trip with only the two other
+      // waves of the SIMD to cover it.
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int c_ = g & 1;
+        if (g + 1 < NG) {
+          ldg(g + 1, kk[c_ ^ 1]);
+        } else {               // last group (set 1): the NEXT iteration's first group into set 0, and this
+          ldg(0, kk[0]);       // iteration's first V operands
+          ldv(0, vv[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[2 * g] = mfma16(kk[c_][0][1], q1, mfma16(kk[c_][0][0], q0, z));
+        s[2 * g + 1] = mfma16(kk[c_][1][1], q1, mfma16(kk[c_][1][0], q0, z));
+        if ((KF & 1) && g == NG - 1) s[KF - 1] = mfma16(kk[c_][2][1], q1, mfma16(kk[c_][2][0], q0, z));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int f = 0; f < KF; ++f) {
       const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg);
@@ -117,6 +165,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
       s[f] = a;
       // bound load hoisting (register pressure): 2 fragments' operands in flight at 128 VGPRs, 4 at 168
       if (KF > 13 || (WPS >= 4 ? (f & 1) : (A3_SB_S > 0 && f % A3_SB_S == A3_SB_S - 1))) __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // the NEXT fragment of this wave goes straight into the registers the scores no longer need
     // (rows >= L load nothing); its latency hides behind the softmax and the P V products
@@ -185,6 +234,20 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
     A3_STAMP(4 + it_ * 5);
 #pragma unroll
     for (int d = 0; d < 4; ++d) oa[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (A3_PIPE && WPS == 3) {
+      // the same for the P V products: the transposed V operands of the next pair of key fragments are in flight
+      // while the current pair's four MFMAs issue
+#pragma unroll
+      for (int fp = 0; fp < KF / 2; ++fp) {
+        const int c_ = fp & 1;
+        if (fp + 1 < KF / 2) ldv(fp + 1, vv[c_ ^ 1]);
+        const bf16x8 pf = pack8(s[2 * fp], s[2 * fp + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) oa[d] = mfma16(vv[c_][d], pf, oa[d]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int fp = 0; fp < KF / 2; ++fp) {
       const bf16x8 pf = pack8(s[2 * fp], s[2 * fp + 1]);
@@ -194,6 +257,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
         oa[d] = mfma16(vf, pf, oa[d]);
       }
       if (WPS >= 4 || (A3_SB_PV > 0 && fp % A3_SB_PV == A3_SB_PV - 1)) __builtin_amdgcn_sched_barrier(0);
+    }
     }
     if constexpr (KF & 1) {
       const s16x4 pf = pack4(s[KF - 1]);

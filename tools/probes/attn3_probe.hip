@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   long* st; (void)hipMalloc(&st, 8 * 32 * 8); (void)hipMemset(st, 0, 8 * 32 * 8);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_a3_stamps), &st, sizeof(st));
 #endif
-  for (int cfg : {0, 8}) {
+  for (int cfg : {0, 8, 0, 8}) {   // twice: the first measurement of a process runs on the ramping clock
     bv_attn_tune(cfg);
     for (int i = 0; i < 3; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
