@@ -552,10 +552,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     // 64 contiguous bytes.  EPI is a compile-time constant and the auxiliary loads of 4 row
     // fragments are issued together before their first use (one memory round trip per
     // batch: the whole CU is in its epilogue at the same time, nothing else hides it).
-    int nc[4];
+    int nc[4], ncl[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      nc[j] = n0 + wc * 64 + (OUTF32 ? j * 16 + lg * 4 : (j >> 1) * 32 + lg * 8 + (j & 1) * 4);
+    for (int j = 0; j < 4; ++j) {
+      ncl[j] = OUTF32 ? j * 16 + lg * 4 : (j >> 1) * 32 + lg * 8 + (j & 1) * 4;   // inside the wave's 64 columns
+      nc[j] = n0 + wc * 64 + ncl[j];
+    }
+    // Addresses: a wave-uniform 64-bit base per row fragment (scalar registers, scalar arithmetic) + one 32-bit lane
+    // offset per column piece, the `saddr + voffset` form of the global instructions.  (Built per element as
+    // (long)m * ldc + n the epilogue spent a third of its VALU instructions - quarter-rate 64-bit multiplies among
+    // them - on addresses: 70 of 200 per tile and lane in the plain bf16 epilogue.)
+    constexpr int ESZ = OUTF32 ? 4 : 2;
+    const long crow = (long)(m0 + wr * 128) * p.ldc + n0 + wc * 64;     // wave-uniform: first element of the wave's block
+    char* const Cb = reinterpret_cast<char*>(p.C) + crow * ESZ;
+    char* const C2b = reinterpret_cast<char*>(p.C2) + crow * 2;
+    const long cstep = 16L * p.ldc;                                     // elements between row fragments
+    uint32_t vc[4];                                                     // lane offsets (bytes) of its four column pieces
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vc[j] = (uint32_t)(lr * (PROBE == 7 ? 256 : (int)p.ldc) + ncl[j]) * ESZ;
     // Everything below works on PAIRS of adjacent columns (f32x2: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32,
     // two fp32 lanes per VALU instruction): pair q of a row fragment = columns nc[q >> 1] + 2 (q & 1) + {0, 1}.
     f32x2 bv[8], cs[8];
@@ -580,22 +594,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     for (int ib = 0; ib < 8; ib += IB) {
       float4 ax[IB][4];
       uint4 hx[IB][2];
-      if constexpr ((EPI == BV_EPI_RESIDUAL && OUTF32) || EPI == BV_EPI_POS) {
+      if constexpr (EPI == BV_EPI_POS) {   // rows wrap around the table (m % aux_rows): per-element addresses
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
           const int m = mrow0 + (ib + ii) * 16;
-          const long arow = (EPI == BV_EPI_POS) ? (long)(m % p.aux_rows) : (long)m;
-          const float* x = reinterpret_cast<const float*>(p.aux) + arow * p.ldaux;
+          const float* x = reinterpret_cast<const float*>(p.aux) + (long)(m % p.aux_rows) * p.ldaux;
 #pragma unroll
           for (int j = 0; j < 4; ++j) ax[ii][j] = __builtin_bit_cast(float4, ld16(x + nc[j], ntl));
         }
-      } else if constexpr (GBWD || RESBF) {
+      } else if constexpr (EPI == BV_EPI_RESIDUAL && OUTF32) {
+        const char* Ab = reinterpret_cast<const char*>(p.aux) + ((long)(m0 + wr * 128) * p.ldaux + n0 + wc * 64) * 4;
 #pragma unroll
         for (int ii = 0; ii < IB; ++ii) {
-          const int m = mrow0 + (ib + ii) * 16;
-          const bf16* h = reinterpret_cast<const bf16*>(p.aux) + (long)m * p.ldaux;
-          hx[ii][0] = __builtin_bit_cast(uint4, ld16(h + nc[0], ntl));
-          hx[ii][1] = __builtin_bit_cast(uint4, ld16(h + nc[2], ntl));
+          const char* x = Ab + (long)(ib + ii) * 16 * p.ldaux * 4;   // wave-uniform
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            ax[ii][j] = __builtin_bit_cast(float4, ld16(x + (uint32_t)(lr * (int)p.ldaux + ncl[j]) * 4u, ntl));
+        }
+      } else if constexpr (GBWD || RESBF) {
+        const char* Ab = reinterpret_cast<const char*>(p.aux) + ((long)(m0 + wr * 128) * p.ldaux + n0 + wc * 64) * 2;
+        const uint32_t va0 = (uint32_t)(lr * (int)p.ldaux + ncl[0]) * 2u, va1 = (uint32_t)(lr * (int)p.ldaux + ncl[2]) * 2u;
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          const char* h = Ab + (long)(ib + ii) * 16 * p.ldaux * 2;   // wave-uniform
+          hx[ii][0] = __builtin_bit_cast(uint4, ld16(h + va0, ntl));
+          hx[ii][1] = __builtin_bit_cast(uint4, ld16(h + va1, ntl));
         }
       }
 #pragma unroll
@@ -619,15 +642,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
               v[j * 2 + 1] += f32x2{ax[ii][j].z, ax[ii][j].w};
             }
           }
-          float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc;
+          char* c = Cb + (long)i * cstep * 4;   // wave-uniform
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            st16(c + nc[j], __builtin_bit_cast(u32x4, make_float4(v[j * 2].x, v[j * 2].y, v[j * 2 + 1].x, v[j * 2 + 1].y)), nts);
+            st16(c + vc[j], __builtin_bit_cast(u32x4, make_float4(v[j * 2].x, v[j * 2].y, v[j * 2 + 1].x, v[j * 2 + 1].y)), nts);
         } else {
-          bf16* c = reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc;
-          bf16* c2 = reinterpret_cast<bf16*>(p.C2) + (long)m * p.ldc;
-          if (PROBE == 7)   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back)
-            c = reinterpret_cast<bf16*>(p.C) + ((long)bid * 128 + ((m - m0) & 127)) * 256 - n0;
+          char* c = Cb + (long)i * cstep * 2;     // wave-uniform
+          char* c2 = C2b + (long)i * cstep * 2;
+          if (PROBE == 7)   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back; vc: pitch 256)
+            c = reinterpret_cast<char*>(p.C) + ((long)bid * 128 + ((wr * 128 + i * 16) & 127)) * 512 + wc * 128;
           if (PROBE == 5) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(v[q]));
@@ -670,9 +693,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
                 if constexpr (EPI == BV_EPI_GELU) gw[e] = bf2_pack(gelu_tanh_pk(bf2_unpack(cw[e])));
               }
             }
-            st16(c + nc[hh * 2], u32x4{cw[0], cw[1], cw[2], cw[3]}, nts);
+            st16(c + vc[hh * 2], u32x4{cw[0], cw[1], cw[2], cw[3]}, nts);
             if constexpr (EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_GD || EPI == BV_EPI_GELU_BWD_EMIT)
-              st16(c2 + nc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
+              st16(c2 + vc[hh * 2], u32x4{gw[0], gw[1], gw[2], gw[3]}, nts);
           }
         }
       }
