@@ -279,6 +279,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     glds16(s + gB, d + 8192);
   };
 
+  // PROBE 16 (tools/probes/gemm_vf_probe.hip; bit-identical to PROBE 0, timing): both operand streams go through
+  // VGPRs - global_load_dwordx4 into staging registers where the DMA instruction would be issued, ds_write_b128 into
+  // the same LDS positions two phases later - instead of through global_load_lds (whose issue costs a wave ~60 cycles
+  // per instruction).  Two instructions per phase in a fixed order, so every wait is vmcnt(4) in the steady state.
+  u32x4 vstA[2][2], vstB[2][2];          // [half][piece]
+  uint32_t vdA[2] = {0, 0}, vdB[2] = {0, 0};   // LDS byte offsets of the staged halves (wave-uniform)
+  bool vpA[2] = {false, false}, vpB[2] = {false, false};   // a staged half waits for its ds_write
+  auto vloadA = [&](const Cursor& c, int slot, int h) __attribute__((always_inline)) {
+    const bf16* s0 = srcA + c.offA + (long)c.t * stepA + (h ? hA : 0);
+    const bf16* s1 = s0 + gA;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vstA[h][0]) : "v"(s0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vstA[h][1]) : "v"(s1) : "memory");
+    vdA[h] = (slot * 2 + h) * HALF + wave_off;
+    vpA[h] = true;
+  };
+  auto vloadB = [&](const Cursor& c, int slot, int h) __attribute__((always_inline)) {
+    const bf16* s0 = srcB + c.offB + (long)c.t * stepB + (h ? hB : 0);
+    const bf16* s1 = s0 + gB;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vstB[h][0]) : "v"(s0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vstB[h][1]) : "v"(s1) : "memory");
+    vdB[h] = (slot * 2 + h) * HALF + wave_off;
+    vpB[h] = true;
+  };
+  // steady: the two phases since the staged half was requested issued their two loads each (4 younger requests)
+  auto vstoreA = [&](int h, bool steady) __attribute__((always_inline)) {
+    if (!vpA[h]) return;
+    if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    char* d = ldsA + vdA[h] + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = vstA[h][0];
+    *reinterpret_cast<u32x4*>(d + 8192) = vstA[h][1];
+    asm volatile("" ::: "memory");
+    vpA[h] = false;
+  };
+  auto vstoreB = [&](int h, bool steady) __attribute__((always_inline)) {
+    if (!vpB[h]) return;
+    if (steady) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    char* d = ldsB + vdB[h] + lane * 16;
+    *reinterpret_cast<u32x4*>(d) = vstB[h][0];
+    *reinterpret_cast<u32x4*>(d + 8192) = vstB[h][1];
+    asm volatile("" ::: "memory");
+    vpB[h] = false;
+  };
+
   // ---- per-lane LDS read addresses (relative to the stage base)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   uint32_t ra0, ra1, rb0, rb1;   // A/B fragment base for k-step 0 / 1 (KM) or ka/kb rows (!KM)
@@ -474,6 +517,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   // leaves the stores outstanding (vmcnt(4 + NSTORE)) instead of draining them.
   constexpr int NSTORE = KM ? ((OUTF32 || EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_BWD_EMIT || EPI == BV_EPI_GELU_GD) ? 32 : 16) : 32;
   bool pre = false;
+  bool vf_prev = false;   // PROBE 16: the previous K-tile requested its B halves
   for (int jt = 0; jt < nmy; ++jt) {
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
     const int nkc = cur.nk;
@@ -485,6 +529,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
       const bool doA = moreA && !pre, doB = moreB && !pre;
       const bool first = t == 0;
+      if constexpr (PROBE == 16) {
+        // VGPR-fed streams: A(k+1) requested in phases 0 / 1 and written in phases 2 / 3, B(k+2) requested in phases
+        // 2 / 3 and written in phases 0 / 1 of the next K-tile.  The phase-3 write is read right behind the next
+        // barrier by the wave group that runs one barrier ahead: it is waited for in front of BV_MID.
+        const bool st_now = doA && doB, st_prev = vf_prev && doA;
+        readA(sa, 0);
+        readB(sb, 0);
+        if (doA) vloadA(ca, (gk + 1) & 1, 0);
+        vstoreB(0, st_prev);
+        BV_MID();
+        BV_MFMA_QUAD(0, 0);
+        BV_END();
+        readB(sb, 1);
+        if (doA) vloadA(ca, (gk + 1) & 1, 1);
+        vstoreB(1, st_prev);
+        BV_MID();
+        BV_MFMA_QUAD(0, 2);
+        BV_END();
+        readA(sa, 1);
+        if (doB) vloadB(cb, bs2, 0);
+        vstoreA(0, st_now);
+        BV_MID();
+        BV_MFMA_QUAD(4, 2);
+        BV_END();
+        if (doB) vloadB(cb, bs2, 1);
+        vstoreA(1, st_now);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        BV_MID();
+        BV_MFMA_QUAD(4, 0);
+        BV_END();
+        vf_prev = doB;
+      } else {
       // -------- phase 0: quadrant (0,0)
       readA(sa, 0);
       readB(sb, 0);
@@ -519,6 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       BV_MID();
       BV_MFMA_QUAD(4, 0);
       BV_END();
+      }
       if (moreA) advance(ca);
       if (moreB) advance(cb);
       bs = bs1;
