@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 `gloo` processes drive big_vision_amd.dp.Comm
+"""N>1 path on CPU: 2, 4 and 8 `gloo` processes drive big_vision_amd.dp.Comm
 (the RCCL layer on GPUs) through the sharded sigmoid-loss exchange of
 trainers/proj/image_text/siglip.py ("convention A"):
 
@@ -95,7 +95,7 @@ def _worker(rank, world, port, n, E, out):
   assert torch.equal(buf2, base * sum(r + 1 for r in range(world)))
   # ---- sharded optimizer ("fsdp" placement): reduce_scatter of the flat gradient buffer into per-rank slices,
   # all_gather of the updated slices; the buffer length is not a multiple of the slice length
-  nflat, S = 1003, 512
+  nflat, S = 1003, 1024 // world          # world * S >= nflat; the last slice is cut short by the end of the buffer
   ranks_sum = sum(r + 1 for r in range(world))
   part = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
   mine = comm.reduce_scatter_flat(part, S)
@@ -112,7 +112,7 @@ def _worker(rank, world, port, n, E, out):
   part = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
   buf = torch.cat([part, torch.full((7,), -5.0, dtype=torch.float64)])   # 7 frozen elements behind the trainable prefix
   ssync = dp.GradShardSync(comm, buf, [min(nflat, r * S) for r in range(world + 1)])
-  ssync.launch(400, 700)          # straddles the slice boundary at 512: two owners
+  ssync.launch(400, 700)          # straddles the slice boundary at 512 (world 2: two owners; world 8: slices 3, 4, 5)
   ssync.launch(0, 100)
   ssync.finish()
   assert torch.equal(buf[lo:hi], tot[lo:hi]), "GradShardSync: the own slice must hold the global sum"
@@ -121,11 +121,17 @@ def _worker(rank, world, port, n, E, out):
   params[lo:hi] = buf[lo:hi] + 1.0
   comm.broadcast_slices_(params, S)
   assert torch.equal(params, tot[:nflat] + 1.0), "broadcast_slices_: every rank must end with every slice"
-  # uneven, tensor-aligned ownership (Adafactor under fsdp): ranges [0, 300), [300, 1003)
-  ub = [0, 300, nflat] if world == 2 else [min(nflat, r * S) for r in range(world + 1)]
+  # uneven, tensor-aligned ownership (Adafactor under fsdp): world 2 -> [0, 355), [355, 1003); world 8 -> eight
+  # ranges of growing length; from 4 ranks on one rank owns NOTHING (a model with fewer large tensors than ranks)
+  ub = [int(round(nflat * (r / world) ** 1.5)) for r in range(world + 1)]
+  if world >= 4:
+    ub[2] = ub[1]
+  assert ub[0] == 0 and ub[-1] == nflat and all(a <= b for a, b in zip(ub, ub[1:]))
   buf = torch.arange(nflat, dtype=torch.float64) * (rank + 1)
   us = dp.GradShardSync(comm, buf, ub)
-  us.launch(250, 350)
+  us.launch(ub[1] - 50, ub[1] + 50)     # across the first owner boundary (and the empty range behind it)
+  if world > 2:
+    us.launch(ub[-2] - 10, nflat)       # across the last one
   us.finish()
   assert torch.equal(buf[ub[rank]:ub[rank + 1]], tot[ub[rank]:ub[rank + 1]])
   pr = torch.full((nflat,), -1.0, dtype=torch.float64)
@@ -137,8 +143,11 @@ def _worker(rank, world, port, n, E, out):
   dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_sigmoid_loss_equals_global(world):
+  """world 4 / 8: row offsets r * n for r >= 2, slices that straddle several owners, 8-way tensor-aligned (uneven,
+  one empty) ownership - the shapes of the headline's 8-GPU job (reference
+  _deprecated_contrastive.py:67-77,117-141,343-344)."""
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
   port = _free_port()
@@ -146,10 +155,10 @@ def test_sharded_sigmoid_loss_equals_global(world):
   for p in procs:
     p.start()
   for p in procs:
-    p.join(180)
+    p.join(240)
     assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
   res = dict(out.get(timeout=5) for _ in range(world))
-  assert len(res) == world and abs(res[0] - res[1]) < 1e-15
+  assert len(res) == world and all(abs(res[0] - res[r]) < 1e-15 for r in range(world))
 
 
 def test_single_process_comm_is_identity():

@@ -1,9 +1,10 @@
-"""The N > 1 trainer path on ONE GPU: two rank processes share cuda:0 and talk over `gloo`
+"""The N > 1 trainer path on ONE GPU: two (and, for two cases, FOUR) rank processes share cuda:0 and talk over `gloo`
 (RCCL refuses two ranks on one device; the collectives' semantics are the same).  Each rank runs
 the product `update_fn` on its half of the batch - all_gather of ztxt, sharded sigmoid loss with
 the positive diagonal at rank*n, reduce_scatter of dztxt, overlapped gradient all-reduce
 (dp.GradSync on a side stream) - and the result must match the single-process step on the
-whole batch (trainers/proj/image_text/siglip.py:271-323 under a 2-device mesh)."""
+whole batch (trainers/proj/image_text/siglip.py:271-323 under a 2-device mesh).  The 4-rank cases execute the row
+offsets rank * n for rank >= 2 and 4-way slice / tensor ownership of the sharded optimizer."""
 import math
 import os
 import socket
@@ -106,9 +107,12 @@ FSDP = dict(sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)
 FSDP_AF = dict(FSDP, optax_name="big_vision.scale_by_adafactor")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(overlap_grad_sync=False), dict(microbatch=2), dict(loss_fn="softmax"),
-                                dict(loss_fn="sigmoid"), FSDP, FSDP_AF])
-def test_two_ranks_match_single_process(dev, kw):
+@pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(overlap_grad_sync=False)), (2, dict(microbatch=2)),
+                                      (2, dict(loss_fn="softmax")), (2, dict(loss_fn="sigmoid")), (2, FSDP), (2, FSDP_AF),
+                                      (4, dict()), (4, FSDP)],
+                         ids=["w2-plain", "w2-no_overlap", "w2-microbatch", "w2-softmax", "w2-sigmoid", "w2-fsdp",
+                              "w2-fsdp_adafactor", "w4-plain", "w4-fsdp"])
+def test_two_ranks_match_single_process(dev, world, kw):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
   import bv_oracle as O
@@ -120,33 +124,36 @@ def test_two_ranks_match_single_process(dev, kw):
   ctx = mp.get_context("spawn")
   out = ctx.Queue()
   port = _free_port()
-  procs = [ctx.Process(target=_worker, args=(r, 2, port, out, kw)) for r in range(2)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, out, kw)) for r in range(world)]
   for p in procs:
     p.start()
   res = {}
-  for _ in range(2):
+  for _ in range(world):
     r = out.get(timeout=300)
     res[r[0]] = r[1:]
   for p in procs:
     p.join(60)
     assert p.exitcode == 0, f"rank process failed (exit {p.exitcode})"
   loss2, gn2, g2, p2, params2 = res[0]
-  assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(loss1), "ranks disagree on the global loss"
+  for r in range(1, world):
+    assert abs(res[0][0] - res[r][0]) <= 1e-6 * abs(loss1), "ranks disagree on the global loss"
+    assert res[0][3] == res[r][3], "replicated parameters diverged between the ranks after the update"
   assert abs(loss2 - loss1) <= 1e-4 * abs(loss1), (loss1, loss2)
   assert abs(gn2 - gn1) <= 2e-2 * gn1, (gn1, gn2)
-  assert res[0][3] == res[1][3], "replicated parameters diverged between the ranks after the update"
   if "sharding_strategy" in kw:
     # three sharded steps (reduce-to-owner overlapped with the backward, Adam on the own slice, in-place exchange,
     # partial shadow refresh): every parameter bit and every bf16 shadow bit agrees between the ranks
-    b0, b1 = res[0][3]["__bits__"], res[1][3]["__bits__"]
-    assert b0 is not None and b0[0] == b1[0], "fp32 parameters differ between the ranks after 3 sharded steps"
-    assert b0[1] == b1[1], "bf16 shadows differ between the ranks after 3 sharded steps"
-    assert abs(b0[2] - b1[2]) <= 1e-6 * abs(b0[2]) and b0[2] < loss1, (b0[2], loss1)
+    b0 = res[0][3]["__bits__"]
+    for r in range(1, world):
+      b1 = res[r][3]["__bits__"]
+      assert b0 is not None and b0[0] == b1[0], "fp32 parameters differ between the ranks after 3 sharded steps"
+      assert b0[1] == b1[1], "bf16 shadows differ between the ranks after 3 sharded steps"
+      assert abs(b0[2] - b1[2]) <= 1e-6 * abs(b0[2]) and b0[2] < loss1, (b0[2], loss1)
     # "fsdp" placement: each rank's gradient buffer holds its PARTIAL sums (the optimizer reduce-scatters them),
     # each rank updated its own slice of the flat buffer and all-gathered the rest: the parameters after the
     # step must be the single-process step's.  Adam's first update is lr * g / (|g| + eps): a gradient that is
     # ~0 up to summation order may flip its sign, one update = lr = 1e-3.
-    assert abs(res[0][1] - res[1][1]) <= 1e-9 * gn1, "ranks disagree on the global gradient norm"
+    assert all(abs(res[0][1] - res[r][1]) <= 1e-9 * gn1 for r in range(1, world)), "ranks disagree on the global gradient norm"
     gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
     adafactor = "adafactor" in kw.get("optax_name", "")
     for k, v in p1.items():
