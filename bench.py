@@ -573,9 +573,12 @@ def main():
                         "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                         "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
-                        # whole step: algorithmic matmul FLOPs of the workload / wall time / peak
+                        # whole step, PER GPU: algorithmic matmul FLOPs of the workload (forward + backward of the
+                        # kept contexts; the recompute FLOPs of re-run micro-batches are NOT counted) / wall time /
+                        # (world x one GPU's peak)
                         "step_frac": (MATMUL_GFLOP_PER_PAIR * 1e9 * args.global_batch * args.steps / dt / 1e12
-                                      / BF16_DENSE_PEAK_TFLOPS),
+                                      / (BF16_DENSE_PEAK_TFLOPS * world)),
+                        "step_frac_is": "per GPU (job FLOP/s / (n_gpus x 2.5 PF))",
                         "algorithmic_bytes_per_launch": nbytes / max(1, launches),
                         "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
                         "share_of_step_time": ms / (1e3 * dt)}

@@ -570,7 +570,9 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       }
       if constexpr (BM == 2) {
         // cs of key lr (all four lane groups) -> the padded query column R - 1 of the dS^T image: element 3 of
-        // plane 3 of the last tile.  This wave wrote that word itself (zeros: query R - 1 does not exist), LDS
+        // plane 3 of the last tile.  cs is rounded to bf16 HERE (advisor r4: documented, include/bvhip.h at
+        // bv_attn_bwd): it is the same 2^-9 rounding every dS element of this image carries into dQ, so the q-bias
+        // gradient (column R - 1 of dQ^T) has the dQ rows' precision; the k-bias gradient is exactly 0 by identity.  This wave wrote that word itself (zeros: query R - 1 does not exist), LDS
         // operations of one wave complete in order.
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(csacc));   // MFMA result -> VALU read behind control flow
         const float cs = csacc[0];

@@ -206,11 +206,17 @@ class GradShardSync(GradSync):
   zero-padded 813 MB copy after the whole backward).  After finish() the own range of `flat` holds the global
   sum; the rest of the buffer holds partial sums nobody reads."""
 
-  def __init__(self, comm: Comm, flat: torch.Tensor, bounds, bucket_bytes: int = 256 << 20):
+  def __init__(self, comm: Comm, flat: torch.Tensor, bounds, bucket_bytes: int = 256 << 20, on_finish=None):
     bounds = [int(b) for b in bounds]
     assert len(bounds) == comm.size + 1 and bounds[0] == 0 and all(a <= b for a, b in zip(bounds, bounds[1:]))
     super().__init__(comm, flat[:bounds[-1]], bucket_bytes)
     self.bounds = bounds
+    self.on_finish = on_finish     # optax.Optimizer stamps itself: the sharded step checks that the owners' sums exist
+
+  def finish(self):
+    super().finish()
+    if self.on_finish is not None:
+      self.on_finish()
 
   def _collective(self, lo: int, hi: int):
     import bisect

@@ -123,9 +123,12 @@ class BertExec:
     suffix, so the non-pad tokens must be a prefix (what tokenize-then-pad produces).  EVERY batch is checked
     (advisor r3: a later batch with an inner pad id or an all-pad row must not slip through), without stalling
     the launch queue: the verdict of batch k is computed on the device, copied to pinned host memory
-    asynchronously and read when batch k + 1 arrives (by then the copy has long completed); `check_pending()`
-    reads the last one (the trainers call it through `model.check` / at the end of a run).  lens is clamped to
-    >= 1 so that even the one unchecked step cannot run an attention row over zero keys."""
+    asynchronously and read by `check_pending()` - which the callers that own a step run BEFORE anything is
+    committed: the SigLIP / contrastive trainers right before `opt.step()` (TwoTowersExec.check_inputs: by then the
+    copy of this step's first kernels has long completed, and a refused batch leaves the weights untouched),
+    `two_towers.Model.apply` and `Model.apply` of this module before they return (the evaluators' predict_fn) - and,
+    as a backstop, when the next batch arrives.  lens is clamped to >= 1 so that a forward that is later refused
+    never runs an attention row over zero keys."""
     self.check_pending()
     valid = ids != 0
     lens = valid.sum(dim=1).to(torch.int32)
@@ -281,7 +284,9 @@ class _Model:
                           lambda: ParamStore(self.entries("", text.shape[1]), dev))
       prefix = ""
     store.refresh_shadow()
-    x, out, _ = self.executor(store, prefix, text.shape[1]).fwd(text, save=False, collect=collect)
+    ex = self.executor(store, prefix, text.shape[1])
+    x, out, _ = ex.fwd(text, save=False, collect=collect)
+    ex.check_pending()        # the verdict on THIS batch's input_mask, before its outputs are handed out
     return x, out
 
 

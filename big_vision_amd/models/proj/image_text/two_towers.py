@@ -55,6 +55,15 @@ class TwoTowersExec:
       out["b"] = self.b.f32
     return zimg, ztxt, out, (ctx if save else None)
 
+  def check_inputs(self):
+    """Raises what the towers' deferred input validation found for the batch(es) handed to fwd() since the last call
+    (the BERT tower validates input_mask on the device and reads the verdict late, bert.BertExec._lengths).  The
+    trainers call it before `opt.step()`, `Model.apply` before it returns: a refused batch is never committed."""
+    for tw in (self.txt, self.img):
+      chk = getattr(tw, "check_pending", None)
+      if chk is not None:
+        chk()
+
   def _block_ranges(self, tower, enc):
     """{block index: [lo, hi) of its gradients in the flat buffer} for `tower` ('img/' | 'txt/')."""
     key = (tower, enc)
@@ -193,6 +202,7 @@ class Model:
     ishape = None if image is None else (tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape))
     ex = self.executor(store, prefix, ishape, None if text is None else tuple(text.shape))
     zimg, ztxt, out, _ = ex.fwd(image, text, save=False, collect=collect)
+    ex.check_inputs()
     return zimg, ztxt, out
 
 

@@ -86,8 +86,9 @@ class Optimizer:
     """comm / shard: placement of the optimizer.  shard=False (config.sharding_strategy "replicate"): every rank
     holds the whole state and applies the whole update to gradients the trainer has all-reduced.  shard=True
     ("fsdp", sharding.py): rank r owns the 1/N slice [lo, hi) of the flat trainable buffer - its Adam moments
-    exist only there; `step()` reduce-scatters the UNREDUCED gradients, updates its slice and all-gathers the
-    parameters (the reference's FSDP rule shards parameters and optimizer state, sharding.py:104-139; see
+    exist only there; `store.grad` holds this rank's PARTIAL sums, the trainer sums every range onto its owner with
+    the object `grad_sync()` returns (overlapped with the backward; `step()` does it itself if nobody did), then
+    `step()` updates its slice and exchanges the parameters (the reference's FSDP rule shards parameters and optimizer state, sharding.py:104-139; see
     big_vision_amd/sharding.py for how the per-tensor axis rule maps onto flat slices)."""
     self.store = store
     self.comm, self.sharded = comm, bool(shard)
@@ -341,6 +342,7 @@ class Optimizer:
     sched = [fn(k) for fn in self.schedule_fns]
     t = float(k - af["decay_offset"]) + 1.0
     decay = min(af["beta2_cap"], 1.0 - t ** (-af["decay_rate"]))     # optax.py:196-199
+    self._owner_sums_ready()
     self.gsq.zero_()
     lo, hi = (self.lo, self.hi) if self.sharded else (0, st.trainable_count)
     if hi > lo:
@@ -448,13 +450,28 @@ class Optimizer:
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
 
-  def grad_sync(self, overlap=True):
+  def grad_sync(self):
     """The gradient reduction object a trainer drives during the backward of a sharded step (dp.GradShardSync:
-    every final range is summed onto the rank that owns it); None on one rank."""
+    every final range is summed onto the rank that owns it); None on one rank.  Its finish() stamps this optimizer
+    (`_reduced_for` = the step count the reduced gradients belong to): the sharded step() checks the stamp."""
     from big_vision_amd import dp
     if not self.sharded or self.comm is None or not self.comm.active:
       return None
-    return dp.GradShardSync(self.comm, self.store.grad, self.bounds)
+    return dp.GradShardSync(self.comm, self.store.grad, self.bounds, on_finish=self._mark_reduced)
+
+  def _mark_reduced(self):
+    self._reduced_for = self.count
+
+  def _owner_sums_ready(self):
+    """Contract of step() under shard=True (advisor r4): `store.grad` holds this rank's PARTIAL sums and every range
+    must have been summed onto its owner - normally by the trainer's grad_sync() object during the backward.  A
+    caller that never drove one (its finish() leaves the stamp) gets the whole trainable range reduced here, after
+    the backward, instead of an update from partial gradients that nothing would flag."""
+    if not (self.sharded and self.comm is not None and self.comm.active):
+      return
+    if getattr(self, "_reduced_for", None) != self.count:
+      self.grad_sync().finish()
+    self._reduced_for = None      # the stamp is good for ONE step
 
   def _sharded_adam_step(self):
     """"fsdp" placement.  The trainer has summed every gradient range onto its OWNER during the backward
@@ -471,6 +488,7 @@ class Optimizer:
     n_own = hi - lo
     k = self.count
     sched = [fn(k) for fn in self.schedule_fns]
+    self._owner_sums_ready()
     self.gsq.zero_()
     if n_own:
       ops.sqnorm_(st.grad[lo:hi], self.gsq)
@@ -662,8 +680,15 @@ class Optimizer:
       self._assign_moment(self.mu, flat, pre + "2/1/")
 
   def state_dict(self):
+    """The raw state buffers.  Under the "fsdp" placement this is a COLLECTIVE like state_tree() (every rank must
+    call it): each rank holds the moments / statistics of what it owns only, so the owners' parts are exchanged
+    first and every rank returns the WHOLE state (advisor r4: a rank-0 state_dict used to lose (N-1)/N of it);
+    what load_state_dict of a replicated or sharded optimizer takes back."""
     if self.name in ADAFACTOR_NAMES:
+      self._gather_af_state()
       return {"mu": self.mu, "af_state": self.af_state, "count": self.count}
+    if self.sharded and self.comm is not None and self.comm.active:
+      return {"mu": self._full_moment(self.mu), "nu": self._full_moment(self.nu), "count": self.count}
     return {"mu": self.mu, "nu": self.nu, "count": self.count}
 
   def load_state_dict(self, d):
@@ -672,7 +697,14 @@ class Optimizer:
         self.mu.copy_(d["mu"].to(self.mu.dtype))
       self.af_state.copy_(d["af_state"]); self.count = int(d["count"])
       return
-    self.mu.copy_(d["mu"].to(self.mu.dtype)); self.nu.copy_(d["nu"]); self.count = int(d["count"])
+    mu, nu = d["mu"], d["nu"]
+    if self.sharded and mu.numel() != self.mu.numel():     # whole moments (state_dict of any placement) -> own slice
+      n_own = self.hi - self.lo
+      self.mu.zero_(); self.nu.zero_()
+      self.mu[:n_own].copy_(mu[self.lo:self.hi].to(self.mu.dtype)); self.nu[:n_own].copy_(nu[self.lo:self.hi])
+    else:
+      self.mu.copy_(mu.to(self.mu.dtype)); self.nu.copy_(nu)
+    self.count = int(d["count"])
 
 
 def make(config, store: ParamStore, *, sched_kw, comm=None, shard=False):

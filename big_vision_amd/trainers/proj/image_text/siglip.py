@@ -237,6 +237,9 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     measurements = {"training_loss": loss[0]}
     if measure is not None:
       measurements.update(measure(lx[0] if lx else {}, norms, t_param))
+    # deferred input validation of the towers (BERT input_mask): raise BEFORE the update is applied - the weights of a
+    # refused batch stay untouched (advisor r4: the last batch of a run was never validated)
+    ex.check_inputs()
     measurements.update(opt.step())
     return {"params": params, "opt": opt}, measurements
 

@@ -243,9 +243,14 @@ def save_params_npz(fname, tree):
 def save_train_state(fname, train_state):
   """Writes {"params": ..., "opt": ...} as a flat .npz with the reference's '/'-joined key naming
   (`params/<leaf>`, `opt/<chain index>/...`, utils.py:616-641 + trainers/.../siglip.py:263-268): what
-  `load_params("file.npz")` / `load_train_state` read back."""
+  `load_params("file.npz")` / `load_train_state` read back.
+
+  Under the "fsdp" placement on N > 1 ranks `opt.state_tree()` is a COLLECTIVE (the owners' moments / statistics are
+  gathered first): EVERY rank must call this function - a call on rank 0 only deadlocks - and the ranks that should not
+  write pass `fname=None` (advisor r4)."""
   tree = {"params": train_state["params"], "opt": train_state["opt"].state_tree()}
-  save_params_npz(fname, tree)
+  if fname is not None:
+    save_params_npz(fname, tree)
 
 
 def load_train_state(fname, train_state):

@@ -198,7 +198,14 @@ int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void*
  * [n][H][L] (rowsum(dO*O), computed here).  dbias_rows (optional, fp32 [n][3][H][64]) receives
  * the per-sample column sums of dqkv, reduced inside the kernels from the fp32 results; summed
  * over n (bv_colsum) they are the gradient of the query/key/value projection biases
- * (vit.py:93-98) - no separate pass over dqkv. */
+ * (vit.py:93-98) - no separate pass over dqkv.  Precision of dbias_rows on the one-launch path (unmasked
+ * L <= 64 and 193..208, attention5.hip): value bias = fp32 column sums of the dO tile (exact identity: rows
+ * of P sum to 1); key bias = 0 - the exact value (sum_j dS_ij = 0 for every query: a key bias shifts a whole
+ * score row), where autodiff of the reference leaves rounding noise of ~1e-9 relative; query bias =
+ * scale * sum_j cs_j K_j with the per-key sums cs_j = sum_i dS_ij taken by the matrix pipe in fp32 and ROUNDED
+ * TO bf16 (2^-9 relative per key) when L % 16 != 0 - the same rounding every dS element gets before it enters
+ * dQ, so the bias gradient carries the dQ rows' error, not more (tests bound both at 2e-2 of the tensor norm;
+ * measured ~3e-3).  The two-launch path (masked / other L) sums the fp32 results by DPP. */
 int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                 void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
 

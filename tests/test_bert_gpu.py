@@ -40,6 +40,41 @@ def test_bert_tower_forward_matches_oracle(dev):
     bert.Model(TINY, num_classes=64).apply({"params": params}, torch.tensor([[5, 0, 6, 0]]).to(dev))
 
 
+def test_bad_input_mask_of_the_last_batch_is_refused_before_the_update(dev):
+  """Advisor r4: the mask verdict of batch k used to be read when batch k + 1 arrived - the LAST batch of a run (or a
+  bad second batch) was trained on.  Now the trainer reads it before `opt.step()`: the bad batch raises in its own
+  step and leaves every weight bit untouched; `apply` (the evaluators' predict_fn) raises before it returns."""
+  import bv_oracle as O
+  from big_vision_amd import dp
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  image_cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok", head_zeroinit=False)
+  model = two_towers.Model(image=image_cfg, text=dict(config=dict(TINY, num_hidden_layers=1), head_zeroinit=False),
+                           text_model="proj.flaxformer.bert", out_dim=(None, 128), temperature_init=10.0, bias_init=-2.71)
+  config = _cfg()
+  image, text = O.synthetic_batch(5, 4, 32, 12, 60)
+  text = text.clamp(min=1)                      # no pad id at all: a valid (full-length) mask
+  image, text = image.to(dev), text.to(dev)
+  state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, comm=dp.Comm(), total_steps=10)
+  fn = siglip.make_update_fn(model, config, comm=dp.Comm())
+  state, _ = fn(state, None, {"image": image, "labels": text})            # first batch: fine
+  torch.cuda.synchronize()
+  before = state["params"].store.master.detach().clone()
+  bad = text.clone(); bad[1, 3] = 0                                         # an inner pad id in the SECOND (= last) batch
+  with pytest.raises(NotImplementedError, match="prefix"):
+    fn(state, None, {"image": image, "labels": bad})
+  torch.cuda.synchronize()
+  assert torch.equal(state["params"].store.master, before), "a refused batch must not move the weights"
+  allpad = text.clone(); allpad[2] = 0
+  with pytest.raises(ValueError, match="without any token"):
+    fn(state, None, {"image": image, "labels": allpad})
+  with pytest.raises(NotImplementedError, match="prefix"):                  # eval path: raised by the call that saw the batch
+    siglip.make_predict_fn(model)(state, {"labels": bad})
+  state, _ = fn(state, None, {"image": image, "labels": text})            # and a good batch afterwards trains again
+  torch.cuda.synchronize()
+  assert not torch.equal(state["params"].store.master, before)
+
+
 def test_lit_step_with_bert_text_tower_tiny(dev):
   """LiT on a toy width: frozen `tok`-pooled ViT + trainable BERT (2 post-LN blocks), ragged padding."""
   image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="tok", head_zeroinit=False)

@@ -168,3 +168,72 @@ def test_two_ranks_match_single_process(dev, world, kw):
   gnorm = math.sqrt(sum((v ** 2).sum().item() for v in g1.values()))
   for k, v in g1.items():
     assert (v - torch.from_numpy(g2[k])).norm().item() <= 2e-2 * max(v.norm().item(), 1e-2 * gnorm), k
+
+
+def _contract_worker(rank, world, port, out):
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+  from big_vision_amd import dp
+  torch.cuda.set_device(0)
+  comm = dp.init_from_env(backend="gloo")
+  out.put((rank,) + _bare_sharded_step(comm, rank, world))
+  comm.barrier()
+  torch.distributed.destroy_process_group()
+
+
+def _bare_sharded_step(comm, rank, world):
+  """A caller that is NOT one of the trainers: builds Optimizer(shard=True), writes its partial gradients and calls
+  step() - never touching grad_sync().  Returns (bits of the updated masters, whole-state digest of state_dict())."""
+  import hashlib
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  model = two_towers.Model(image=IMAGE_CFG, text=TEXT_CFG, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+  config = _config(schedule=dict(decay_type="cosine", warmup_steps=0),
+                   **(dict(sharding_strategy=FSDP["sharding_strategy"]) if world > 1 else {}))
+  state, _ = siglip.make_train_state(model, config, (8, 64, 64, 3), (8, 16), rng=0, comm=comm, total_steps=10)
+  opt, store = state["opt"], state["params"].store
+  assert bool(getattr(opt, "sharded", False)) == (world > 1)
+  g = torch.Generator(device="cpu").manual_seed(7)
+  full = torch.randn(store.trainable_count, generator=g) * 1e-2
+  # rank r contributes (r + 1) / sum of the global gradient: the partial sums add up to `full` (not bit-exactly)
+  share = (rank + 1) / sum(r + 1 for r in range(world))
+  store.grad[:store.trainable_count].copy_((full * share).to(store.grad.device))
+  opt.step()                                   # no grad_sync(): the step must reduce onto the owners itself
+  store.grad[:store.trainable_count].copy_((full * share).to(store.grad.device))
+  opt.step()                                   # and again (the stamp of the first step must not leak into the second)
+  torch.cuda.synchronize()
+  sd = opt.state_dict()                        # whole moments on every rank (a collective under fsdp)
+  assert sd["mu"].numel() == store.trainable_count and sd["nu"].numel() == store.trainable_count
+  dig = hashlib.sha256(sd["mu"].float().cpu().numpy().tobytes() + sd["nu"].float().cpu().numpy().tobytes()).hexdigest()
+  return store.master.detach().cpu().numpy(), dig, float(sd["mu"].float().abs().sum().item())
+
+
+def test_sharded_step_without_a_driven_grad_sync_still_sums_onto_the_owners(dev):
+  """Advisor r4: Optimizer(shard=True).step() used to assume that the trainer had driven grad_sync() to completion
+  and otherwise updated from this rank's partial gradients.  Now finish() stamps the optimizer and a step without
+  the stamp reduces [0, n_tr) itself.  Also: state_dict() of a sharded optimizer returns the WHOLE moments on every
+  rank (it used to return the own slice and stale zeros elsewhere)."""
+  import numpy as np
+  import torch.multiprocessing as mp
+  from big_vision_amd import dp
+  ref_master, _, ref_mu = _bare_sharded_step(dp.Comm(), 0, 1)
+  ctx = mp.get_context("spawn")
+  out = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_contract_worker, args=(r, 2, port, out)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = {}
+  for _ in range(2):
+    r = out.get(timeout=300)
+    res[r[0]] = r[1:]
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  assert np.array_equal(res[0][0], res[1][0]), "ranks hold different parameters after two bare sharded steps"
+  assert res[0][1] == res[1][1], "state_dict() must return the same WHOLE moments on every rank"
+  # two Adam steps of lr <= 1e-3 from partial sums that differ from `full` in the last bits
+  # (a ~0 gradient may flip the sign of its first updates: 2 lr per step)
+  assert np.abs(res[0][0] - ref_master).max() <= 4.2e-3
+  assert (np.abs(res[0][0] - ref_master) > 1e-6).mean() <= 0.05, "the update was not computed from the summed gradient"
+  assert abs(res[0][2] - ref_mu) <= 1e-3 * ref_mu
