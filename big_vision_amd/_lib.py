@@ -22,34 +22,25 @@ P = c_void_p
 # name -> argtypes (return type is always int, except bv_last_error)
 PROTOTYPES = {
     "bv_version": [],
+    # the caller's context (options, split-K workspace, launch counters): the library keeps no global state
+    "bv_ctx_create": [], "bv_ctx_destroy": [P], "bv_ctx_set": [P, c_int, c_long], "bv_ctx_get": [P, c_int],
+    "bv_ctx_set_workspace": [P, P, c_long],
     "bv_gemm_bf16": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
-                     c_int, P, P, c_long, c_int, P, c_float, c_int, P],
+                     c_int, P, P, c_long, c_int, P, c_float, c_int, P, P],
     "bv_gemm_bf16_colsum": [c_int, c_int, P, c_long, P, c_long, P, c_long, c_int, c_int, c_int, c_int,
-                            c_int, P, P, c_long, c_int, P, c_float, c_int, P, P],
-    "bv_gemm_fast_path": [c_int],
-    "bv_gemm_tune": [c_int, c_int, c_int],
-    "bv_gemm_pre_issue": [c_int],
-    "bv_gemm_roll": [c_int],
-    "bv_gemm_group_n": [c_int],
-    "bv_gemm_reserve_cus": [c_int],
-    "bv_gemm256_calls": [c_int],
-    "bv_set_workspace": [P, c_long],
-    "bv_set_stream_workspace": [P, P, c_long],
+                            c_int, P, P, c_long, c_int, P, c_float, c_int, P, P, P],
     "bv_gemm_workspace_bytes": [c_int, c_int, c_int],
     "bv_sgemm_strided": [P, c_long, c_long, P, c_long, c_long, P, c_long, c_int, c_int, c_int,
-                         c_float, c_float, P, P],
-    "bv_sgemm_path": [c_int],
+                         c_float, c_float, P, P, P],
     "bv_layernorm_fwd": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_fwd_bf16x": [P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, c_float, P],
     "bv_layernorm_bwd": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
     "bv_layernorm_bwd_y": [P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P, P, P],
     "bv_layernorm_bwd_bf16x": [P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_long, c_long, P],
-    "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P],
-    "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
-    "bv_attn_fwd_masked": [P, P, P, P, c_int, c_int, c_int, P],
-    "bv_attn_bwd_masked": [P, P, P, P, P, P, P, c_int, c_int, c_int, P],
-    "bv_attn_impl": [c_int],
-    "bv_attn_tune": [c_int],
+    "bv_attn_fwd": [P, P, P, c_int, c_int, c_int, P, P],
+    "bv_attn_bwd": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P],
+    "bv_attn_fwd_masked": [P, P, P, P, c_int, c_int, c_int, P, P],
+    "bv_attn_bwd_masked": [P, P, P, P, P, P, P, c_int, c_int, c_int, P, P],
     "bv_map_attn_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_bwd": [P, P, P, P, P, P, c_int, c_int, c_int, P],
     "bv_map_attn_fwd_masked": [P, P, P, P, P, c_int, c_int, c_int, P],
@@ -101,7 +92,14 @@ PROTOTYPES.update({
     "bv_comm_all_reduce_bucket": [P, P, c_long, c_long, c_int, P],
 })
 
-RESTYPES = {"bv_gemm_workspace_bytes": c_long, "bv_gemm256_calls": c_long}   # everything else returns an int status
+# everything else returns an int status
+RESTYPES = {"bv_gemm_workspace_bytes": c_long, "bv_ctx_create": P, "bv_ctx_destroy": None, "bv_ctx_set": c_long,
+            "bv_ctx_get": c_long}
+
+# bv_ctx options / statistics (include/bvhip.h)
+OPTS = {"fast_path": 0, "gemm_nt": 1, "gemm_skew_mode": 2, "gemm_skew_pct": 3, "gemm_pre_issue": 4, "gemm_roll": 5,
+        "gemm_group_n": 6, "gemm_reserve_cus": 7, "attn_cfg": 8, "sgemm_mfma": 9,
+        "gemm256_calls": 100, "gemm256_multi": 101, "gemm256_fused": 102}
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)
 

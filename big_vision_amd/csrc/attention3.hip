@@ -878,8 +878,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* _
   }
 }
 
-int g_a3_one_sweep = 1;   // 0: always the two-sweep dQ kernel (A/B, bv_attn_tune bit 16)
-int g_a4_dkv = 0;          // 32-key-block dK/dV kernel: 0 off, 1 = 4 waves x 2 workgroups per CU, 2 = 7 waves x 1 (bv_attn_tune bits 32 / 64)
+// A/B switches of a launch, decoded from the caller's BV_OPT_ATTN_CFG (include/bvhip.h)
+struct A3Cfg {
+  bool fwd8;        // bit 8:   forward of the L <= 208 kernels as 8 waves x 2 workgroups
+  bool one_sweep;   // !bit 16: one-sweep dQ kernel (default); bit 16 = always the two-sweep kernel
+  int dkv32;        // bits 32 / 64: 32-key-block dK/dV kernel, 1 = 4 waves x 2 workgroups per CU, 2 = 7 waves x 1
+  bool a5_off;      // bit 128: keep the two-launch backward also where the one-launch kernel (attention5.hip) applies
+  bool a5_bias_dpp; // bit 256: attention5.hip reduces the bias gradients with DPP column sums instead of the identities
+};
+A3Cfg a3cfg(const bv_ctx* ctx) {
+  const long c = bv_opt(ctx, BV_OPT_ATTN_CFG);
+  return A3Cfg{(c & 15) == 8, !(c & 16), (c & 64) ? 2 : (c & 32) ? 1 : 0, (c & 128) != 0, (c & 256) != 0};
+}
 
 template <typename K>
 void set_lds(K kernel, size_t bytes) {
@@ -905,7 +915,9 @@ int launch_fwd3(const void* qkv, void* o, float* lse, const int* kv_len, int n, 
 // NW / WPS: the dQ kernel, NW2 / WPS2: the dK,dV kernel (waves per workgroup / per SIMD)
 template <int KF, int NW, int WPS, int WPS2, int NW2 = NW>
 int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                float* dbias, const int* kv_len, int n, int L, int H, hipStream_t s) {
+                float* dbias, const int* kv_len, int n, int L, int H, hipStream_t s, const A3Cfg& cfg) {
+  const bool g_a3_one_sweep = cfg.one_sweep;
+  const int g_a4_dkv = cfg.dkv32;
   const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
   if (o && g_a3_one_sweep) {
     if (!kv_len && L > (KF - 1) * 16) {
@@ -952,32 +964,18 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
 // Entry points used by bv_attn_fwd / bv_attn_bwd (attention.hip).  Key fragments = ceil(L/16) for
 // the common sequence lengths (64 text tokens; 196/197 at 224 px; 256/257; 441 at 336 px; 576 at
 // 384 px), the next instantiated size otherwise.
-static int g_a3cfg = 0;
-static int g_a5_off = 0;   // 1: keep the two-launch backward also where the one-launch kernel (attention5.hip) applies
-extern int g_a5_bias_dpp;  // attention5.hip
 // attention5.hip: the backward in one launch (unmasked, L <= 64 or 193..208); -100 = shape not covered
 int bv_attn5_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
-                 int L, int H, void* stream);
-// A/B switches: 8 = forward of the L <= 208 kernels with 8 waves x 2 workgroups; +16 = two-sweep dQ kernel;
-// +32 / +64 = 32-key dK/dV kernels; +128 = two-launch backward instead of attention5.hip; +256 = attention5.hip
-// reduces the bias gradients with DPP column sums instead of the identities
-extern "C" int bv_attn_tune(int cfg) {
-  const int old = g_a3cfg | (g_a3_one_sweep ? 0 : 16) | (g_a4_dkv == 1 ? 32 : g_a4_dkv == 2 ? 64 : 0) | (g_a5_off ? 128 : 0) |
-                  (g_a5_bias_dpp ? 256 : 0);
-  if (cfg >= 0) {
-    g_a3cfg = cfg & 15; g_a3_one_sweep = !(cfg & 16); g_a4_dkv = (cfg & 64) ? 2 : (cfg & 32) ? 1 : 0;
-    g_a5_off = (cfg & 128) != 0;
-    g_a5_bias_dpp = (cfg & 256) != 0;
-  }
-  return old;
-}
+                 int L, int H, void* stream, bool bias_dpp);
 
-int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream) {
+int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H, void* stream,
+                 const bv_ctx* ctx) {
   hipStream_t s = (hipStream_t)stream;
+  const A3Cfg cfg = a3cfg(ctx);
   if (L <= 64) return launch_fwd3<4, 4, 4>(qkv, o, lse, kv_len, n, L, H, s);
   // 13 key fragments: 4 waves per workgroup and 3 workgroups per CU (the third one computes while
   // another stages its K/V: 605-650 us instead of 670-730 at n = 2048); 8 waves x 2 under bv_attn_tune(8)
-  if (L <= 208 && g_a3cfg == 8) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 208 && cfg.fwd8) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 208) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 448) return launch_fwd3<28, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
@@ -985,15 +983,16 @@ int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n,
 }
 
 int bv_attn3_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                 float* dbias, const int* kv_len, int n, int L, int H, void* stream) {
+                 float* dbias, const int* kv_len, int n, int L, int H, void* stream, const bv_ctx* ctx) {
   hipStream_t s = (hipStream_t)stream;
-  if (!kv_len && !g_a5_off) {
-    const int rc = bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, dbias, n, L, H, stream);
+  const A3Cfg cfg = a3cfg(ctx);
+  if (!kv_len && !cfg.a5_off) {
+    const int rc = bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, dbias, n, L, H, stream, cfg.a5_bias_dpp);
     if (rc != -100) return rc;
   }
-  if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
-  return launch_bwd3<36, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s);
+  if (L <= 64) return launch_bwd3<4, 4, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s, cfg);
+  if (L <= 208) return launch_bwd3<13, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s, cfg);
+  if (L <= 272) return launch_bwd3<17, 8, 4, 4>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s, cfg);
+  if (L <= 448) return launch_bwd3<28, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s, cfg);
+  return launch_bwd3<36, 8, 2, 2>(qkv, o, d_o, lse, delta, dqkv, dbias, kv_len, n, L, H, s, cfg);
 }

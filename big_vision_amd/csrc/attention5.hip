@@ -75,8 +75,6 @@ __device__ long* g_a5_wstamps;
 #define A5_WSTAMP(k)
 #endif
 
-int g_a5_bias_dpp = 0;   // 1: bias gradients by DPP column sums also where the identities apply (A/B, bv_attn_tune bit 256)
-
 namespace {
 using namespace bvattn;
 // register arrays of 16-byte pieces: a first-class vector type (arrays of HIP's uint4 STRUCT were left in scratch memory)
@@ -724,7 +722,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
 
 template <int KF, int LW>
 int launch_bwd5(const void* qkv, const void* d_o, const float* lse, void* dqkv, float* dbias, int n, int L, int H,
-                hipStream_t s) {
+                hipStream_t s, bool bias_dpp) {
   using C = A5<KF, LW>;
   static int cus = 0;
   if (!cus) {
@@ -745,7 +743,7 @@ int launch_bwd5(const void* qkv, const void* d_o, const float* lse, void* dqkv, 
                        dbias, L, H, npairs, 0.125f);
   };
   if (!dbias) go(attn5_bwd_kernel<KF, LW, 0>);
-  else if (g_a5_bias_dpp) go(attn5_bwd_kernel<KF, LW, 1>);
+  else if (bias_dpp) go(attn5_bwd_kernel<KF, LW, 1>);   // A/B (BV_OPT_ATTN_CFG bit 256): DPP column sums where the identities apply
   else if (L & 15) go(attn5_bwd_kernel<KF, LW, 2>);
   else go(attn5_bwd_kernel<KF, LW, 3>);
   return bv_check_launch("bv_attn_bwd(one launch)");
@@ -756,10 +754,10 @@ int launch_bwd5(const void* qkv, const void* d_o, const float* lse, void* dqkv, 
 // Entry used by bv_attn3_bwd (attention3.hip) for unmasked sequences of at most 208 tokens; returns -100 when the
 // shape is not covered (the caller keeps the two-launch path).
 int bv_attn5_bwd(const void* qkv, const void* d_o, const float* lse, float* delta, void* dqkv, float* dbias, int n,
-                 int L, int H, void* stream) {
+                 int L, int H, void* stream, bool bias_dpp) {
   hipStream_t s = (hipStream_t)stream;
   (void)delta;   // scratch of the two-launch path; the exact delta never leaves the LDS here
-  if (L <= 64) return launch_bwd5<4, 1>(qkv, d_o, lse, dqkv, dbias, n, L, H, s);
-  if (L > 192 && L <= 208) return launch_bwd5<13, 3>(qkv, d_o, lse, dqkv, dbias, n, L, H, s);
+  if (L <= 64) return launch_bwd5<4, 1>(qkv, d_o, lse, dqkv, dbias, n, L, H, s, bias_dpp);
+  if (L > 192 && L <= 208) return launch_bwd5<13, 3>(qkv, d_o, lse, dqkv, dbias, n, L, H, s, bias_dpp);
   return -100;
 }

@@ -1358,88 +1358,6 @@ __global__ __launch_bounds__(256) void gemm256_reduce_kernel(const float* __rest
 
 }  // namespace
 
-static int g_skew = 1;
-extern "C" int bv_gemm_skew(int enable) {   // diagnostics: A/B the start skew
-  const int old = g_skew;
-  if (enable >= 0) g_skew = enable;
-  return old;
-}
-// Tuning knobs of the k-major kernel (tools/gemm_step_shapes.py A/Bs them):
-//   nt: bit 0 streaming stores, bit 1 streaming aux loads;  skew_mode / skew_pct: start skew of
-//   the workgroups as a percentage of one tile period (0 = off).  Negative = leave unchanged.
-static int g_nt = 0, g_skew_mode = 1, g_skew_pct = 0, g_pre = 0, g_roll = 1, g_group_n = 0;
-// Which epilogues run on the rolling-epilogue kernel (bit mask): 1 = +residual (default: the only one
-// it measured faster on, 2-5 %), 2 = none/bias (bf16), 4 = GELU.
-// CUs left free by the persistent grid (0 = all 256).  A workgroup of this kernel fills a CU (160 KiB of
-// LDS, 8 waves x ~230 VGPRs), so a collective's workgroups cannot share one: while RCCL kernels are
-// resident, 256 persistent workgroups do not all fit and the ones that wait start a whole launch late.
-// The data-parallel trainer reserves as many CUs as RCCL has channels for the backward, where the
-// per-block gradient all-reduces run beside the GEMMs (dp.py).
-static int g_reserve = 0;
-static long g_calls[3] = {0, 0, 0};   // bv_gemm256_calls: all / multi-tile walks / multi-tile walks with a fused epilogue
-extern "C" long bv_gemm256_calls(int which) { return which >= 0 && which < 3 ? g_calls[which] : -1; }
-extern "C" int bv_gemm_reserve_cus(int n) {
-  const int old = g_reserve;
-  if (n >= 0) g_reserve = n > 128 ? 128 : n;
-  return old;
-}
-extern "C" int bv_gemm_group_n(int g) {   // column tiles per group of the k-major tile order (0 = all: plain order)
-  const int old = g_group_n;
-  if (g >= 0) g_group_n = g;
-  return old;
-}
-extern "C" int bv_gemm_roll(int mask) {
-  const int old = g_roll;
-  if (mask >= 0) g_roll = mask;
-  return old;
-}
-extern "C" int bv_gemm_pre_issue(int enable) {   // diagnostics: A/B the pre-epilogue load issue
-  const int old = g_pre;
-  if (enable >= 0) g_pre = enable;
-  return old;
-}
-extern "C" int bv_gemm_tune(int nt, int skew_mode, int skew_pct) {
-  if (nt >= 0) g_nt = nt;
-  if (skew_mode >= 0) g_skew_mode = skew_mode;
-  if (skew_pct >= 0) g_skew_pct = skew_pct;
-  return BV_OK;
-}
-// Split-K workspaces: a default one (bv_set_workspace) and up to 16 bound to specific streams
-// (bv_set_stream_workspace), so weight-gradient GEMMs enqueued on different streams never share
-// a slab.  Looked up per launch under a mutex; the kernels only ever see the pointer.
-#include <mutex>
-namespace {
-struct WsSlot { void* stream; void* ptr; long bytes; };
-std::mutex g_ws_mu;
-WsSlot g_ws_default = {nullptr, nullptr, 0};
-WsSlot g_ws_stream[16] = {};
-int g_ws_nstream = 0;
-WsSlot ws_for(void* stream) {
-  std::lock_guard<std::mutex> lk(g_ws_mu);
-  for (int i = 0; i < g_ws_nstream; ++i)
-    if (g_ws_stream[i].stream == stream && g_ws_stream[i].ptr) return g_ws_stream[i];
-  return g_ws_default;
-}
-}  // namespace
-extern "C" int bv_set_workspace(void* ptr, long bytes) {
-  std::lock_guard<std::mutex> lk(g_ws_mu);
-  g_ws_default = {nullptr, ptr, ptr ? bytes : 0};
-  return BV_OK;
-}
-extern "C" int bv_set_stream_workspace(void* stream, void* ptr, long bytes) {
-  std::lock_guard<std::mutex> lk(g_ws_mu);
-  for (int i = 0; i < g_ws_nstream; ++i)
-    if (g_ws_stream[i].stream == stream) {
-      g_ws_stream[i] = {stream, ptr, ptr ? bytes : 0};
-      return BV_OK;
-    }
-  if (g_ws_nstream == 16) {
-    bv_set_error("bv_set_stream_workspace: more than 16 streams");
-    return BV_ERR_UNSUPPORTED;
-  }
-  g_ws_stream[g_ws_nstream++] = {stream, ptr, ptr ? bytes : 0};
-  return BV_OK;
-}
 // Bytes of split-K scratch a dW GEMM (a_kmajor = b_kmajor = 0, EPI_ATOMIC) of this shape uses
 // with the automatic split choice; 0 = the shape takes no workspace.
 extern "C" long bv_gemm_workspace_bytes(int M, int N, int K) {
@@ -1459,7 +1377,11 @@ extern "C" long bv_gemm_workspace_bytes(int M, int N, int K) {
 int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                   float alpha, int split_k, float* colsum, void* stream) {
+                   float alpha, int split_k, float* colsum, void* stream, const bv_ctx* ctx_) {
+  // every option, the split-K workspace and the launch counters come from the caller's context (NULL: defaults)
+  const bv_ctx* ctx = bv_ctx_or_default(ctx_);
+  const int g_reserve = (int)ctx->opt[BV_OPT_GEMM_RESERVE_CUS], g_roll = (int)ctx->opt[BV_OPT_GEMM_ROLL];
+  const int g_skew_pct = (int)ctx->opt[BV_OPT_GEMM_SKEW_PCT], g_skew_mode = (int)ctx->opt[BV_OPT_GEMM_SKEW_MODE];
   if (a_kmajor != b_kmajor) return 0;
   if ((M & 255) || (N & 255) || (K & 63)) return 0;
   const bool km = a_kmajor != 0;
@@ -1500,31 +1422,30 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   p.ktiles_per_split = (nk + splits - 1) / splits;
   splits = (nk + p.ktiles_per_split - 1) / p.ktiles_per_split;
   const long slab_bytes = (long)p.ntiles * splits * 65536 * 4;
-  const WsSlot ws = epilogue == BV_EPI_ATOMIC ? ws_for(stream) : WsSlot{nullptr, nullptr, 0};
-  const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && ws.ptr && slab_bytes <= ws.bytes &&
+  void* const ws_ptr = epilogue == BV_EPI_ATOMIC ? ctx->ws : nullptr;
+  const bool use_slab = epilogue == BV_EPI_ATOMIC && splits > 1 && ws_ptr && slab_bytes <= ctx->ws_bytes &&
                         (ldc & 3) == 0;
-  if (use_slab) p.slab = (float*)ws.ptr;
+  if (use_slab) p.slab = (float*)ws_ptr;
   p.splits = splits;
   const int nwork = p.ntiles * splits;
-  // start skew (see kernel): one tile period (~3600 cycles per K-tile + epilogue) when every
-  // workgroup has >= 8 tiles, so the skewed tail costs < 1/8 of the launch.
-  p.skew_cycles = (km && g_skew > 1 && nwork >= 8 * 256) ? nk * 3600 + 3000 : 0;
+  // start skew (see kernel): a percentage of one tile period (~3600 cycles per K-tile + epilogue)
+  p.skew_cycles = 0;
   p.skew_mode = 0;
   if (km && g_skew_pct > 0 && nwork > 256) {
     p.skew_cycles = (int)((long)(nk * 3600 + 12000) * g_skew_pct / 100);
     p.skew_mode = g_skew_mode;
   }
-  p.nt = g_nt;
-  p.group_n = km ? g_group_n : 0;
-  p.pre_issue = g_pre;
+  p.nt = (int)ctx->opt[BV_OPT_GEMM_NT];
+  p.group_n = km ? (int)ctx->opt[BV_OPT_GEMM_GROUP_N] : 0;
+  p.pre_issue = (int)ctx->opt[BV_OPT_GEMM_PRE_ISSUE];
   p.dbg = nullptr;
   const int cus = 256 - g_reserve;
   dim3 grid(nwork < cus ? nwork : cus), block(512);   // persistent: one workgroup per CU
   hipStream_t s = (hipStream_t)stream;
-  ++g_calls[0];
+  ctx->calls[0].fetch_add(1, std::memory_order_relaxed);
   if (nwork > (int)grid.x) {
-    ++g_calls[1];
-    if ((epilogue != BV_EPI_NONE && epilogue != BV_EPI_ATOMIC) || colsum) ++g_calls[2];
+    ctx->calls[1].fetch_add(1, std::memory_order_relaxed);
+    if ((epilogue != BV_EPI_NONE && epilogue != BV_EPI_ATOMIC) || colsum) ctx->calls[2].fetch_add(1, std::memory_order_relaxed);
   }
   // rolling-epilogue kernel: k-major, at least two K-tiles per tile, the epilogues it implements
   const bool roll = km && nk >= 2 && !colsum &&
@@ -1551,7 +1472,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   else if (out_f32) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_NONE, false>), grid, block, 0, s, p);
   if (use_slab)
-    hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)ws.ptr,
+    hipLaunchKernelGGL(gemm256_reduce_kernel, dim3(p.ntiles * 64), dim3(256), 0, s, (const float*)ws_ptr,
                        (float*)C, ldc, p.ntiles, p.tiles_n, splits, alpha, 1);
   return 1;
 }

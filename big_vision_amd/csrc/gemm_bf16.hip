@@ -285,33 +285,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
 int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                    void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                   float alpha, int split_k, float* colsum, void* stream);
-static int g_fast_path = 1;
-int bv_fast_path_enabled() { return g_fast_path; }
-extern "C" int bv_gemm_fast_path(int enable) {
-  const int old = g_fast_path;
-  if (enable >= 0) g_fast_path = enable != 0;
-  return old;
-}
+                   float alpha, int split_k, float* colsum, void* stream, const bv_ctx* ctx);
 
 // See include/bvhip.h for the contract.
 extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
                                    long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
                                    int epilogue, const float* bias, const void* aux, long ldaux,
                                    int aux_rows, void* C2, float alpha, int split_k, float* colsum,
-                                   void* stream);
+                                   void* stream, const bv_ctx* ctx);
 extern "C" int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
                             long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
                             int epilogue, const float* bias, const void* aux, long ldaux,
-                            int aux_rows, void* C2, float alpha, int split_k, void* stream) {
+                            int aux_rows, void* C2, float alpha, int split_k, void* stream, const bv_ctx* ctx) {
   return bv_gemm_bf16_colsum(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K, epilogue, bias,
-                             aux, ldaux, aux_rows, C2, alpha, split_k, nullptr, stream);
+                             aux, ldaux, aux_rows, C2, alpha, split_k, nullptr, stream, ctx);
 }
 extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
                                    long ldb, void* C, long ldc, int out_f32, int M, int N, int K,
                                    int epilogue, const float* bias, const void* aux, long ldaux,
                                    int aux_rows, void* C2, float alpha, int split_k, float* colsum,
-                                   void* stream) {
+                                   void* stream, const bv_ctx* ctx) {
   BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_gemm_bf16: empty problem M=%d N=%d K=%d", M, N, K);
   BV_REQUIRE(N % 8 == 0, "bv_gemm_bf16: N=%d must be a multiple of 8", N);
   BV_REQUIRE(a_kmajor ? (K % 8 == 0 && lda % 8 == 0) : (M % 8 == 0 && lda % 8 == 0),
@@ -337,8 +330,9 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
     BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_MUL,
                "bv_gemm_bf16_colsum: column sums are fused into the GELU_BWD / MUL epilogues only (got %d)", epilogue);
 
-  if (g_fast_path && bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K,
-                                     epilogue, bias, aux, ldaux, aux_rows, C2, alpha, split_k, colsum, stream))
+  if (bv_opt(ctx, BV_OPT_FAST_PATH) &&
+      bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K, epilogue, bias, aux, ldaux, aux_rows,
+                     C2, alpha, split_k, colsum, stream, ctx))
     return bv_check_launch("bv_gemm_bf16(256x256)");
 
   GemmParams p;

@@ -522,16 +522,11 @@ extern "C" int bv_sigmoid_xent(const float* logits, const float* labels, double*
   return bv_check_launch("bv_sigmoid_xent");
 }
 
-static int g_sgemm_mfma = 1;   // 0: always the VALU kernel (A/B and bit-equality test, bv_sgemm_path)
-extern "C" int bv_sgemm_path(int mfma) {
-  const int old = g_sgemm_mfma;
-  if (mfma >= 0) g_sgemm_mfma = mfma != 0;
-  return old;
-}
 extern "C" int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                                 float* C, long ldc, int M, int N, int K, float alpha, float beta,
-                                const float* log_alpha, void* stream) {
+                                const float* log_alpha, void* stream, const bv_ctx* ctx) {
   BV_REQUIRE(M > 0 && N > 0 && K > 0, "bv_sgemm_strided: empty problem");
+  const bool g_sgemm_mfma = bv_opt(ctx, BV_OPT_SGEMM_MFMA) != 0;   // 0: always the VALU kernel (A/B and bit-equality test)
   // the fp32 matrix pipe for everything that fills at least one 64 x 64 tile (bit-identical results: both kernels
   // are k-ordered fmaf chains); 128 x 128 tiles once those alone give every CU two workgroups
   const long t128 = (long)((N + 127) / 128) * ((M + 127) / 128);

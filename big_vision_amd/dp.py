@@ -277,7 +277,7 @@ def warn_if_overlap_is_uncapped():
 
 
 # CUs the persistent 256x256 GEMM leaves to RCCL while gradient all-reduces overlap the backward
-# (bv_gemm_reserve_cus): its workgroups fill a CU, so a collective launched beside it would otherwise
+# (BV_OPT_GEMM_RESERVE_CUS of the compute stream's bv_ctx): its workgroups fill a CU, so a collective launched beside it would otherwise
 # wait for - or delay - a whole GEMM launch.  4 keeps the split-K choices of the B/16 shapes intact
 # (252 = 36 x 7 = 9 x 28 work items) and costs the k-major GEMMs 1.6 % of the chip during the backward.
 RESERVED_CUS = 4
@@ -292,11 +292,11 @@ class reserve_cus_for_collectives:
 
   def __enter__(self):
     if self.on:
-      from big_vision_amd import _lib
-      self.old = _lib.load().bv_gemm_reserve_cus(RESERVED_CUS)
+      from big_vision_amd import ops
+      self.ctx = ops.ctx()          # the context of the stream the backward's GEMMs are enqueued on
+      self.old = self.ctx.set("gemm_reserve_cus", RESERVED_CUS)
     return self
 
   def __exit__(self, *exc):
     if self.on:
-      from big_vision_amd import _lib
-      _lib.load().bv_gemm_reserve_cus(self.old)
+      self.ctx.set("gemm_reserve_cus", self.old)

@@ -37,16 +37,83 @@ def _rowmajor2d(t, name):
   return t.stride(0)
 
 
-_workspace = None
 WORKSPACE_BYTES = 64 << 20   # 256 split-K partial tiles of 256 KiB (one per CU)
 
 
-def _ensure_workspace(device):
-  """Registers the split-K scratch of the weight-gradient GEMMs (bv_set_workspace) once."""
-  global _workspace
-  if _workspace is None or _workspace.device != device:
-    _workspace = torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8)
-    _lib.call("bv_set_workspace", _workspace.data_ptr(), WORKSPACE_BYTES)
+class Context:
+  """The caller's `bv_ctx` (include/bvhip.h "Context"): kernel-variant options, the split-K workspace of the
+  weight-gradient GEMMs and the launch counters.  libbvhip keeps no process-global state; the Python host keeps
+  ONE context per (device, stream) it launches GEMMs on (`ctx()`), so two streams never share a split-K slab."""
+
+  def __init__(self):
+    self.ptr = _lib.load().bv_ctx_create()
+    if not self.ptr:
+      raise RuntimeError("bv_ctx_create failed")
+    self._ws = None
+    self.use_workspace = True   # False: weight-gradient GEMMs combine their split-K partials with fp32 atomics (A/B)
+
+  def __del__(self):
+    try:
+      if self.ptr:
+        _lib.load().bv_ctx_destroy(self.ptr)
+    except Exception:   # interpreter shutdown
+      pass
+
+  def set(self, name, value):
+    """Sets option `name` (_lib.OPTS), returns the previous value."""
+    old = _lib.load().bv_ctx_set(self.ptr, _lib.OPTS[name], int(value))
+    if old < 0:
+      raise RuntimeError(f"bv_ctx_set({name}): {_lib.load().bv_last_error().decode()}")
+    return old
+
+  def get(self, name):
+    return _lib.load().bv_ctx_get(self.ptr, _lib.OPTS[name])
+
+  def ensure_workspace(self, device):
+    if not self.use_workspace:
+      if self._ws is not None:
+        self._ws = None
+        _lib.call("bv_ctx_set_workspace", self.ptr, None, 0)
+      return
+    if self._ws is None or self._ws.device != device:
+      self._ws = torch.empty(WORKSPACE_BYTES, device=device, dtype=torch.uint8)
+      _lib.call("bv_ctx_set_workspace", self.ptr, self._ws.data_ptr(), WORKSPACE_BYTES)
+
+
+_contexts = {}
+
+
+def ctx() -> Context:
+  """The context of the current (device, stream)."""
+  key = (torch.cuda.current_device() if torch.cuda.is_available() else -1, _stream())
+  c = _contexts.get(key)
+  if c is None:
+    c = _contexts[key] = Context()
+  return c
+
+
+def ctx_set(name, value):
+  """A/B tools and tests: option `name` of the current stream's context; returns the previous value."""
+  return ctx().set(name, value)
+
+
+def ctx_get(name):
+  return ctx().get(name)
+
+
+class option:
+  """`with ops.option("gemm_roll", 0): ...` - an option of the current stream's context for the duration of a block."""
+
+  def __init__(self, name, value):
+    self.name, self.value = name, value
+
+  def __enter__(self):
+    self.c = ctx()
+    self.old = self.c.set(self.name, self.value)
+    return self
+
+  def __exit__(self, *exc):
+    self.c.set(self.name, self.old)
 
 
 # ------------------------------------------------------------------- GEMMs --
@@ -75,17 +142,18 @@ def gemm(a, b, *, a_kmajor=True, b_kmajor=False, out=None, out_dtype=BF16, M=Non
     ldaux = _rowmajor2d(aux, "gemm.aux")
   if bias is not None:
     _chk(bias, F32, "gemm.bias")
+  c = ctx()
   if epilogue == EPI_ATOMIC:
-    _ensure_workspace(a.device)
+    c.ensure_workspace(a.device)
   if colsum is not None:
     _chk(colsum, F32, "gemm.colsum")
     _lib.call("bv_gemm_bf16_colsum", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
               int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
-              float(alpha), split_k, _p(colsum), _stream())
+              float(alpha), split_k, _p(colsum), _stream(), c.ptr)
     return out
   _lib.call("bv_gemm_bf16", int(a_kmajor), int(b_kmajor), _p(a), lda, _p(b), ldb, _p(out), ldc,
             int(out.dtype == F32), M, N, K, epilogue, _p(bias), _p(aux), ldaux, aux_rows, _p(out2),
-            float(alpha), split_k, _stream())
+            float(alpha), split_k, _stream(), c.ptr)
   return out
 
 
@@ -93,7 +161,7 @@ def sgemm(a, sam, sak, b, sbk, sbn, out, M, N, K, alpha=1.0, beta=0.0, log_alpha
   """fp32 strided GEMM (bv_sgemm_strided); alpha is multiplied by exp(log_alpha[0]) (device)."""
   _chk(a, F32, "sgemm.a"); _chk(b, F32, "sgemm.b"); _chk(out, F32, "sgemm.out")
   _lib.call("bv_sgemm_strided", _p(a), sam, sak, _p(b), sbk, sbn, _p(out), out.stride(0), M, N, K,
-            float(alpha), float(beta), _p(log_alpha), _stream())
+            float(alpha), float(beta), _p(log_alpha), _stream(), ctx().ptr)
   return out
 
 
@@ -175,9 +243,9 @@ def attn_fwd(qkv, n, L, H, kv_len=None):
   if Dh != 64 or L > 576:
     _lib.call("bv_attn_fwd_dh", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, Dh, _stream())
   elif kv_len is not None:
-    _lib.call("bv_attn_fwd_masked", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, _stream())
+    _lib.call("bv_attn_fwd_masked", _p(qkv), _p(o), _p(lse), _p(kv_len), n, L, H, _stream(), ctx().ptr)
   else:
-    _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream())
+    _lib.call("bv_attn_fwd", _p(qkv), _p(o), _p(lse), n, L, H, _stream(), ctx().ptr)
   return o, lse
 
 
@@ -200,10 +268,10 @@ def attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=None, dbias=None, kv_len=None):
               n, L, H, Dh, _stream())
   elif kv_len is not None:
     _lib.call("bv_attn_bwd_masked", _p(qkv), _p(d_o), _p(lse), _p(kv_len), _p(delta), _p(dqkv), _p(rows),
-              n, L, H, _stream())
+              n, L, H, _stream(), ctx().ptr)
   else:
     _lib.call("bv_attn_bwd", _p(qkv), _p(o), _p(d_o), _p(lse), _p(delta), _p(dqkv), _p(rows), n, L, H,
-              _stream())
+              _stream(), ctx().ptr)
   if dbias is not None:
     colsum(rows, dbias)   # per-sample sums (written by the kernels) -> bias gradient
   return dqkv

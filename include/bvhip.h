@@ -14,9 +14,13 @@
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and
  *     returns immediately: 0 = ok, <0 = error (BV_ERR_*); the message is
  *     available from bv_last_error().  No call synchronises.
- *   - thread-safe per stream.  Process-global state: the last-error string, the split-K
- *     workspace registry (bv_set_workspace / bv_set_stream_workspace) and the diagnostic
- *     dispatch / tuning switches (bv_gemm_fast_path, bv_gemm_tune, bv_gemm_pre_issue).
+ *   - thread-safe per stream.  The library keeps NO process-global state besides the (thread-local)
+ *     last-error string (what else is static is immutable after its first use: the compute-unit count of
+ *     the device, the kernel attributes the HIP runtime caches, the RCCL entry points bv_comm_* binds): every option
+ *     that selects a kernel variant, the split-K workspace and the launch counters live in an opaque
+ *     `bv_ctx` the caller creates and passes to the entry points that consult it (GEMM, attention,
+ *     fp32 GEMM).  ctx = NULL means "all defaults, no workspace".  Two callers in one process that
+ *     hold their own contexts cannot change each other's kernels.
  */
 #ifndef BVHIP_H_
 #define BVHIP_H_
@@ -35,6 +39,62 @@ extern "C" {
 
 const char* bv_last_error(void);
 int bv_version(void);
+
+/* --------------------------------------------------------------- Context ----
+ * Options, split-K workspace and launch counters of ONE caller ("no global state").  A
+ * context is plain host memory: creating one allocates nothing on the device and enqueues nothing.
+ * Entry points take it as `const bv_ctx*` (they only read options; the counters are atomics); a context
+ * may be shared by threads as long as nobody calls bv_ctx_set / bv_ctx_set_workspace on it concurrently
+ * with a launch.  Its workspace serves ONE stream at a time: callers that enqueue weight-gradient GEMMs
+ * on several streams concurrently give each stream its own context. */
+typedef struct bv_ctx bv_ctx;
+bv_ctx* bv_ctx_create(void);
+void bv_ctx_destroy(bv_ctx* ctx);
+/* Options (diagnostics / A-B benchmarking; defaults in parentheses; results never depend on them
+ * beyond the summation order of a different kernel). */
+#define BV_OPT_FAST_PATH 0         /* (1) GEMMs with M, N multiples of 256, K of 64 and both operands in the same
+                                      layout run on the 256x256x64 direct-to-LDS kernel; 0: everything on the
+                                      general 128x128x64 kernel */
+#define BV_OPT_GEMM_NT 1           /* (0) bit 0 = streaming (nontemporal) stores of C / C2, bit 1 = streaming aux loads */
+#define BV_OPT_GEMM_SKEW_MODE 2    /* (1) start phase per XCD (0) / per workgroup (1), see SKEW_PCT */
+#define BV_OPT_GEMM_SKEW_PCT 3     /* (0) spread of the persistent workgroups' start, % of one tile period */
+#define BV_OPT_GEMM_PRE_ISSUE 4    /* (0) issue the next tile's K-tile 1 / 2 loads ahead of the epilogue's stores */
+#define BV_OPT_GEMM_ROLL 5         /* (1) which epilogues of k-major GEMMs with K >= 128 run on the rolling-epilogue
+                                      kernel (no separate epilogue phase; the residual is loaded straight into the
+                                      accumulators): bit mask 1 = RESIDUAL fp32 (alpha = 1), 2 = NONE (bf16 out),
+                                      4 = GELU, 8 = stores inside the MFMA segments; 1 is the only one measured faster */
+#define BV_OPT_GEMM_GROUP_N 6      /* (0) tile order of the k-major 256x256 kernels: column tiles are walked in groups
+                                      of g (column tile fastest inside a group, then row tile): the g weight panels an
+                                      XCD works on stay in its L2.  0 or >= N/256: plain order */
+#define BV_OPT_GEMM_RESERVE_CUS 7  /* (0) CUs the persistent 256x256 grid leaves free (<= 128).  Its workgroups fill
+                                      a CU, so kernels that must run BESIDE it (RCCL collectives overlapping the
+                                      backward) need CUs of their own; the data-parallel trainer reserves one per
+                                      RCCL channel for the duration of the overlapped backward */
+#define BV_OPT_ATTN_CFG 8          /* (0) attention A/B switches: 8 = forward of the L <= 208 kernels as 8 waves x 2
+                                      workgroups; +16 = two-sweep dQ kernel; +32 / +64 = 32-key dK/dV kernels;
+                                      +128 = two-launch backward where the one-launch kernel applies; +256 = the
+                                      one-launch kernel reduces the bias gradients by DPP column sums */
+#define BV_OPT_SGEMM_MFMA 9        /* (1) bv_sgemm_strided on the fp32 matrix pipe wherever a 64 x 64 tile is filled;
+                                      0 = always the VALU kernel (both are k-ordered fmaf chains: identical results) */
+#define BV_OPT_COUNT 10
+/* Read-only statistics of a context (bv_ctx_get): launches bv_gemm_bf16[_colsum] put on the 256x256 kernels
+ * through this context: all of them / those in which a persistent workgroup walks more than one tile / those of
+ * the latter with a fused epilogue (anything but NONE / ATOMIC) or fused column sums.  The parity suite asserts
+ * with them that a case really ran where it claims to. */
+#define BV_STAT_GEMM256_CALLS 100
+#define BV_STAT_GEMM256_MULTI 101
+#define BV_STAT_GEMM256_FUSED 102
+/* Sets an option and returns its previous value (>= 0); value < 0 only queries.  BV_ERR_INVALID_ARG for an
+ * unknown option or a NULL context. */
+long bv_ctx_set(bv_ctx* ctx, int opt, long value);
+long bv_ctx_get(const bv_ctx* ctx, int opt);
+/* Caller-provided scratch (device memory, >= 64 MiB recommended) for the split-K partial tiles of the
+ * weight-gradient GEMMs (EPI_ATOMIC) launched through this context: with a workspace the partials are written
+ * with plain coalesced stores and combined by a second small kernel (deterministic); without one (no context, or
+ * ptr = NULL) fp32 atomics are used.  bv_gemm_workspace_bytes(M, N, K) = bytes the dW GEMM C[M,N] = A[K,M]^T B[K,N]
+ * takes with the automatic split choice (0: the shape needs none) -- size the slab for the largest. */
+int bv_ctx_set_workspace(bv_ctx* ctx, void* ptr, long bytes);
+long bv_gemm_workspace_bytes(int M, int N, int K);
 
 /* ---------------------------------------------------------------- GEMM ----
  * C[M,N] = alpha * A(MxK) * B(KxN) (+ epilogue), bf16 inputs, fp32 MFMA
@@ -72,7 +132,7 @@ int bv_version(void);
 int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                 float alpha, int split_k /*0 = auto*/, void* stream);
+                 float alpha, int split_k /*0 = auto*/, void* stream, const bv_ctx* ctx);
 
 /* bv_gemm_bf16 with a fused column reduction: colsum[n] += sum_m C[m][n], taken from the fp32
  * results before the output rounding (fp32 atomics).  Supported with the GELU_BWD / MUL epilogues:
@@ -81,59 +141,7 @@ int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void
 int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                         void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                         const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
-                        float alpha, int split_k, float* colsum, void* stream);
-
-/* Caller-provided scratch (device memory, >= 64 MiB recommended) for split-K
- * partial tiles of the weight-gradient GEMMs (EPI_ATOMIC): with a workspace the
- * partials are written with plain coalesced stores and combined by a second
- * small kernel (deterministic); without one (ptr = NULL) fp32 atomics are used.
- * bv_set_workspace registers the DEFAULT workspace: every dW GEMM whose stream has no
- * workspace of its own uses it, so such calls must be ordered on ONE stream.  To run dW
- * GEMMs concurrently on several streams give each its own slab with
- * bv_set_stream_workspace(stream, ptr, bytes) (up to 16 streams; ptr = NULL unbinds).
- * bv_gemm_workspace_bytes(M, N, K) = bytes the dW GEMM C[M,N] = A[K,M]^T B[K,N] takes with
- * the automatic split choice (0: the shape needs none) -- size the slab for the largest. */
-int bv_set_workspace(void* ptr, long bytes);
-int bv_set_stream_workspace(void* stream, void* ptr, long bytes);
-long bv_gemm_workspace_bytes(int M, int N, int K);
-
-/* Dispatch control (diagnostics / A-B benchmarking).  With the switch on (default)
- * GEMMs with M,N multiples of 256, K a multiple of 64 and both operands in the
- * same layout run on the 256x256x64 direct-to-LDS kernel (everything else on the
- * general 128x128x64 kernel) and bv_attn_fwd/bwd use the LDS-resident kernels.
- * enable = 0/1 sets the switch, -1 only queries; returns the old value. */
-int bv_gemm_fast_path(int enable);
-
-/* Tuning knobs of the 256x256 k-major kernel (diagnostics / A-B benchmarking; negative =
- * leave unchanged): nt bit 0 = streaming (nontemporal) stores of C/C2, bit 1 = streaming
- * loads of aux; skew_mode 0/1 = start phase per XCD / per workgroup, skew_pct = spread of
- * the workgroups' start as a percentage of one tile period (0 = off). */
-int bv_gemm_tune(int nt, int skew_mode, int skew_pct);
-/* 1 (default): the persistent 256x256 kernel issues the next tile's K-tile 1/2 loads ahead of
- * the epilogue's stores (same in-order VMEM queue) and leaves the stores outstanding at the
- * next tile's first counted wait.  enable = 0/1 sets, -1 queries; returns the old value. */
-int bv_gemm_pre_issue(int enable);
-/* Which epilogues of k-major GEMMs with K >= 128 run on the rolling-epilogue kernel (no separate
- * epilogue phase: the epilogue of each accumulator quadrant is folded into the load segments of
- * the K loop; the residual is loaded straight into the accumulators).  Bit mask: 1 = RESIDUAL
- * (alpha = 1), 2 = NONE (bf16 out), 4 = GELU; default 1 (the only one measured faster).
- * mask < 0 only queries; returns the old value. */
-int bv_gemm_roll(int mask);
-/* Tile order of the k-major 256x256 kernels: column tiles are walked in groups of g (inside a group: column tile
- * fastest, then row tile), so the g weight panels an XCD works on stay in its L2 while the activation row panels
- * stream through.  0 or >= N/256: the plain order (column tile fastest over the whole row).  Results do not
- * depend on it.  g < 0 only queries; returns the old value. */
-int bv_gemm_group_n(int g);
-/* CUs the persistent 256x256 GEMM grid leaves free (0 = none; returns the old value, n < 0 only queries).
- * Its workgroups fill a CU, so kernels that must run BESIDE it (RCCL collectives overlapping the
- * backward) need CUs of their own; the data-parallel trainer reserves one per RCCL channel. */
-int bv_gemm_reserve_cus(int n);
-/* Diagnostics for the parity suite: launches bv_gemm_bf16[_colsum] has put on the 256x256 kernels since the
- * library was loaded.  which = 0: all of them; 1: only launches in which a persistent workgroup walks more than
- * one tile (work items > workgroups); 2: those of (1) with a fused epilogue (anything but BV_EPI_NONE /
- * BV_EPI_ATOMIC) or fused column sums.  Tests assert that a case really ran where it claims to
- * (tests/test_siglip_step_gpu.py::test_b16_depth2_n64_image_tower_on_gemm256). */
-long bv_gemm256_calls(int which);
+                        float alpha, int split_k, float* colsum, void* stream, const bv_ctx* ctx);
 
 /* fp32 GEMM with arbitrary element strides (small, numerically sensitive
  * products: the B x B logits of the sigmoid loss and its gradients,
@@ -142,12 +150,7 @@ long bv_gemm256_calls(int which);
 int bv_sgemm_strided(const float* A, long sam, long sak, const float* B, long sbk, long sbn,
                      float* C, long ldc, int M, int N, int K, float alpha, float beta,
                      const float* log_alpha /*device, optional: alpha *= exp(*log_alpha)*/,
-                     void* stream);
-/* A/B switch of bv_sgemm_strided: 1 (default) = the fp32 matrix-pipe kernel (v_mfma_f32_32x32x2_f32) wherever a
- * 64 x 64 tile is filled, 0 = always the VALU kernel.  Both are k-ordered fmaf chains: identical results.  mfma < 0
- * only queries; returns the old value. */
-int bv_sgemm_path(int mfma);
-
+                     void* stream, const bv_ctx* ctx);
 /* ------------------------------------------------------------ LayerNorm ----
  * flax nn.LayerNorm(): eps=1e-6, fp32 statistics (models/vit.py:92,103,160,181).
  * Input row r is read at x + (r*row_stride + row_offset)*D (row_stride>=1 lets
@@ -193,7 +196,7 @@ int bv_layernorm_bwd_bf16x(const void* dy, int dy_is_f32, const void* x_bf16, co
  * dropout.  qkv is the packed projection output [n*L][3][H][64] bf16 (row
  * stride 3*H*64); o is [n*L][H][64] bf16; lse is [n][H][L] fp32 (row
  * log-sum-exp, saved for the backward).  Dh must be 64; L <= 576. */
-int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream);
+int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void* stream, const bv_ctx* ctx);
 /* dqkv (same layout as qkv) from do ([n*L][H][64] bf16); delta is fp32 scratch
  * [n][H][L] (rowsum(dO*O), computed here).  dbias_rows (optional, fp32 [n][3][H][64]) receives
  * the per-sample column sums of dqkv, reduced inside the kernels from the fp32 results; summed
@@ -207,7 +210,7 @@ int bv_attn_fwd(const void* qkv, void* o, float* lse, int n, int L, int H, void*
  * dQ, so the bias gradient carries the dQ rows' error, not more (tests bound both at 2e-2 of the tensor norm;
  * measured ~3e-3).  The two-launch path (masked / other L) sums the fp32 results by DPP. */
 int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
+                void* dqkv, float* dbias_rows, int n, int L, int H, void* stream, const bv_ctx* ctx);
 
 /* The same with a key-padding length per sample: keys >= kv_len[i] (1 <= kv_len[i] <= L, int32
  * device array, NULL = no mask) get zero probability and zero dK / dV rows; all L query rows are
@@ -216,18 +219,9 @@ int bv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* ls
  * at the end of the sequence).  The backward computes delta = rowsum(P o dP) itself (fp32) and
  * does not read o. */
 int bv_attn_fwd_masked(const void* qkv, void* o, float* lse, const int* kv_len, int n, int L, int H,
-                       void* stream);
+                       void* stream, const bv_ctx* ctx);
 int bv_attn_bwd_masked(const void* qkv, const void* d_o, const float* lse, const int* kv_len, float* delta,
-                       void* dqkv, float* dbias_rows, int n, int L, int H, void* stream);
-/* Diagnostics / A-B benchmarking: which LDS-resident implementation bv_attn_fwd/bwd use on the
- * fast path - 3 = attention3.hip (default: one query fragment per wave, 16 waves per CU,
- * prefetched fragments, exact delta), 2 = attention2.hip.  impl < 0 only queries; returns the
- * old value. */
-int bv_attn_impl(int impl);
-/* A/B switches of attention3.hip (default 0): 8 = the forward of the 13-key-fragment shapes (L = 196 / 197)
- * with 8 waves x 2 workgroups per CU instead of 4 x 3; +16 = always the two-sweep dQ kernel.  cfg < 0 only
- * queries; returns the old value. */
-int bv_attn_tune(int cfg);
+                       void* dqkv, float* dbias_rows, int n, int L, int H, void* stream, const bv_ctx* ctx);
 
 /* Single-query attention of the MAP head (models/vit.py:176-178): q [n][H][64]
  * bf16, kv packed [n*L][2][H][64] bf16 -> o [n][H][64] bf16, probabilities p

@@ -15,7 +15,7 @@ HEADER = os.path.join(ROOT, "include", "bvhip.h")
 def _header_symbols():
   src = open(HEADER).read()
   src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-  return sorted(set(re.findall(r"^(?:int|long|const char\*)\s+(bv_\w+)\s*\(", src, re.M)))
+  return sorted(set(re.findall(r"^(?:int|long|void|bv_ctx\*|const char\*)\s+(bv_\w+)\s*\(", src, re.M)))
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +41,52 @@ def test_python_prototypes_cover_the_header(lib):
   from big_vision_amd import _lib
   assert sorted(list(_lib.PROTOTYPES) + ["bv_last_error"]) == _header_symbols()
   assert lib.bv_version() == 1
+
+
+def test_library_keeps_no_process_global_state(lib):
+  """SURVEY.md 8b / VERDICT r4 #6: options, split-K workspace and launch counters live in a caller-owned `bv_ctx`;
+  the header's state paragraph names the last-error string only, the old process-global setters are gone from the
+  ABI, the library's data segment holds no writable globals besides the thread-local error buffer and caches, and
+  two contexts do not see each other's options."""
+  import subprocess
+  src = open(HEADER).read()
+  para = src[src.index("thread-safe per stream"):src.index("#ifndef BVHIP_H_")]
+  assert "NO process-global state besides" in para and "last-error string" in para
+  for gone in ("bv_gemm_tune", "bv_gemm_roll", "bv_gemm_reserve_cus", "bv_gemm_group_n", "bv_gemm_pre_issue",
+               "bv_gemm_fast_path", "bv_attn_impl", "bv_attn_tune", "bv_sgemm_path", "bv_set_workspace",
+               "bv_set_stream_workspace", "bv_gemm256_calls"):
+    assert gone not in _header_symbols() and not hasattr(ctypes.CDLL(os.path.join(ROOT, "big_vision_amd", "libbvhip.so")), gone), gone
+  # source level: no mutable namespace-scope variable in csrc besides the thread-local error buffer and the
+  # one-time RCCL binding table (+ its mutex) of comm.cpp; function-local `static` caches hold device properties only
+  decl = re.compile(r"^(?:static |thread_local |extern )*(?:std::\w+(?:<[^>]*>)? |unsigned |int |long |bool |float |"
+                    r"double |char |void\* |\w+ )(g_\w+)\b[^()]*[;=]", re.M)
+  found = {}
+  csrc = os.path.join(ROOT, "big_vision_amd", "csrc")
+  for f in sorted(os.listdir(csrc)):
+    txt = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+    for m in decl.finditer(txt):
+      if "__device__" not in txt[max(0, m.start() - 20):m.start() + 12]:
+        found.setdefault(m.group(1), f)
+  assert set(found) <= {"g_err", "g_rccl", "g_mu"}, found
+  statics = []
+  for f in sorted(os.listdir(csrc)):
+    for ln in open(os.path.join(csrc, f)):
+      if re.match(r"\s+static (?!const|constexpr|_assert|inline)\w", ln) and "static_assert" not in ln:
+        statics.append((f, ln.strip()))
+  assert all("cus = 0" in l or "dflt" in l for _, l in statics), statics
+  a, b = lib.bv_ctx_create(), lib.bv_ctx_create()
+  try:
+    from big_vision_amd._lib import OPTS
+    assert lib.bv_ctx_get(a, OPTS["gemm_roll"]) == 1 and lib.bv_ctx_get(None, OPTS["gemm_roll"]) == 1
+    assert lib.bv_ctx_set(a, OPTS["gemm_roll"], 7) == 1 and lib.bv_ctx_get(a, OPTS["gemm_roll"]) == 7
+    assert lib.bv_ctx_get(b, OPTS["gemm_roll"]) == 1 and lib.bv_ctx_get(None, OPTS["gemm_roll"]) == 1
+    assert lib.bv_ctx_set(a, OPTS["gemm_reserve_cus"], 500) == 0 and lib.bv_ctx_get(a, OPTS["gemm_reserve_cus"]) == 128
+    assert lib.bv_ctx_set(None, OPTS["gemm_roll"], 0) < 0 and b"NULL context" in lib.bv_last_error()
+    assert lib.bv_ctx_set(a, 55, 0) < 0 and lib.bv_ctx_get(a, 55) < 0
+    assert lib.bv_ctx_get(a, OPTS["gemm256_calls"]) == 0
+    assert lib.bv_ctx_set_workspace(a, None, 0) == 0 and lib.bv_ctx_set_workspace(None, None, 0) != 0
+  finally:
+    lib.bv_ctx_destroy(a); lib.bv_ctx_destroy(b)
 
 
 def test_header_cites_reference_call_sites():

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "big_vision_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # file -> kernels that may use scratch (general fallbacks outside the default dispatch)
-ALLOWED_SCRATCH = {"attention.hip": ("attn_fwd_kernelILi28E", "attn_fwd_kernelILi36E")}
+ALLOWED_SCRATCH = {}
 
 
 def _resources(src, tmp_path):
@@ -37,7 +37,7 @@ def _resources(src, tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("src", ["gemm256.hip", "attention2.hip", "attention3.hip", "attention_dh.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
+@pytest.mark.parametrize("src", ["gemm256.hip", "attention3.hip", "attention_dh.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
                                  "elementwise.hip", "loss_optim.hip"])
 def test_no_spills_no_scratch(src, tmp_path):
   res = _resources(src, tmp_path)

@@ -26,19 +26,16 @@ def close(a, b, rtol, atol, name):
 
 @pytest.fixture()
 def fast(dev):
-  from big_vision_amd import _lib
-  _lib.load().bv_gemm_fast_path(1)      # returns the previous setting, not a status
+  from big_vision_amd import ops
+  ops.ctx_set("fast_path", 1)
   yield
-  _lib.load().bv_gemm_fast_path(1)
+  ops.ctx_set("fast_path", 1)
 
 
 def _general(fn):
-  from big_vision_amd import _lib
-  _lib.load().bv_gemm_fast_path(0)
-  try:
+  from big_vision_amd import ops
+  with ops.option("fast_path", 0):
     return fn()
-  finally:
-    _lib.load().bv_gemm_fast_path(1)
 
 
 NT_SHAPES = [(256, 256, 64), (256, 256, 128), (512, 768, 768), (1024, 2304, 768), (768, 768, 3072),
@@ -198,7 +195,7 @@ ROLL_SHAPES = [(256, 256, 128), (512, 256, 192), (1024, 768, 320), (66816, 768, 
 @pytest.mark.parametrize("M,N,K", ROLL_SHAPES)
 def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, N, K):
   """gemm256r_kernel (epilogue folded into the K loop, residual loaded into the accumulators) vs
-  gemm256_kernel through the same dispatcher (bv_gemm_roll mask): bit-identical for the bf16
+  gemm256_kernel through the same dispatcher (BV_OPT_GEMM_ROLL mask): bit-identical for the bf16
   epilogues (same accumulation order and epilogue arithmetic), fp32 rounding-order noise for
   +residual; run-to-run bit-equality as the race screen.  66816 x 768 x 128 = 783 tiles of two
   K-tiles: every workgroup rolls 3-4 tiles whose first K-tile is also the one before the last
@@ -219,13 +216,10 @@ def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, 
     y2 = ops.gemm(a, w, out_dtype=BF16, alpha=0.5, **kw)          # no bias, alpha != 1
     return y0, h, g, y1, y2
 
-  old = lib.bv_gemm_roll(0)
-  try:
+  with ops.option("gemm_roll", 0):
     ref = run_all()
-    lib.bv_gemm_roll(7)
+  with ops.option("gemm_roll", 7):
     new = [run_all() for _ in range(3)]
-  finally:
-    lib.bv_gemm_roll(old)
   for k, name in enumerate(("bias bf16", "gelu h", "gelu g", "residual f32", "alpha bf16")):
     for r in new[1:]:
       assert torch.equal(r[k], new[0][k]), f"{name}: run-to-run difference"
@@ -236,7 +230,7 @@ def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, 
 
 
 def test_reserved_cus_change_nothing_but_the_grid(dev, fast):
-  """bv_gemm_reserve_cus(4): the persistent grid leaves 4 CUs to RCCL during an overlapped backward
+  """BV_OPT_GEMM_RESERVE_CUS = 4: the persistent grid leaves 4 CUs to RCCL during an overlapped backward
   (dp.reserve_cus_for_collectives).  k-major results are bit-identical (a tile's arithmetic does not
   depend on which workgroup runs it); the split-K choice of the weight-gradient GEMM follows the CUs
   in use, so dW matches to accumulation order."""
@@ -248,14 +242,11 @@ def test_reserved_cus_change_nothing_but_the_grid(dev, fast):
   y0 = ops.gemm(a, w, a_kmajor=True, b_kmajor=True, out_dtype=BF16)
   g0 = torch.zeros((768, 2304), device=dev)
   ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=g0, epilogue=ops.EPI_ATOMIC)
-  old = lib.bv_gemm_reserve_cus(4)
-  try:
-    assert old == 0
+  with ops.option("gemm_reserve_cus", 4) as o:
+    assert o.old == 0
     y1 = ops.gemm(a, w, a_kmajor=True, b_kmajor=True, out_dtype=BF16)
     g1 = torch.zeros((768, 2304), device=dev)
     ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=g1, epilogue=ops.EPI_ATOMIC)
-  finally:
-    lib.bv_gemm_reserve_cus(old)
   assert torch.equal(y0, y1)
   close(g1, g0, 1e-5, 1e-3, "dW with 4 reserved CUs")
   close(g0, a.float().T @ dy.float(), 1e-4, 2e-2, "dW")
@@ -263,7 +254,7 @@ def test_reserved_cus_change_nothing_but_the_grid(dev, fast):
 
 @pytest.mark.parametrize("g", [2, 4, 5, 7])
 def test_grouped_tile_order_changes_no_bit(dev, fast, g):
-  """bv_gemm_group_n(g): the k-major tiles are walked in groups of g column tiles (an A/B knob for the L2 traffic of
+  """BV_OPT_GEMM_GROUP_N = g: the k-major tiles are walked in groups of g column tiles (an A/B knob for the L2 traffic of
   the wide GEMMs, profiles/NOTES_r04.md; default off).  Which workgroup computes a tile, and when, does not enter
   its arithmetic: the outputs of a multi-tile walk (12 x 49 and 9 x 49 tiles; groups that divide the column count
   and ragged last groups; plain kernel, two-output GELU on the full-epilogue kernel, fp32 +residual on the rolling
@@ -288,12 +279,9 @@ def test_grouped_tile_order_changes_no_bit(dev, fast, g):
     return y9, h, gl, x1
 
   ref = run()
-  old = lib.bv_gemm_group_n(g)
-  try:
-    assert old == 0
+  with ops.option("gemm_group_n", g) as o:
+    assert o.old == 0
     got = run()
-  finally:
-    lib.bv_gemm_group_n(old)
   for r, o, name in zip(ref, got, ("plain N=2304", "gelu h", "gelu g", "+residual fp32 N=768")):
     assert not torch.isnan(o.float()).any(), f"{name}: a tile was never written with groups of {g}"
     assert torch.equal(r, o), f"{name}: groups of {g} column tiles changed the result"
@@ -337,7 +325,8 @@ def test_fused_epilogues_multi_tile_vs_fp64(dev, fast, M, N, K, reserve):
   hh = rnd((M, N), dev, 35, dtype=BF16)       # a stored pre-activation (light contexts)
   L = 196
   pos = rnd((L, N), dev, 36)
-  old = lib.bv_gemm_reserve_cus(reserve)
+  ctx_ = ops.ctx()
+  old = ctx_.set("gemm_reserve_cus", reserve)
   try:
     # plain +bias (QKV / dX shapes), bf16 and fp32 outputs
     close(ops.gemm(x, w, bias=b, out_dtype=F32, **kw), pre, 1e-4, 2e-3, "bias f32")
@@ -393,4 +382,4 @@ def test_fused_epilogues_multi_tile_vs_fp64(dev, fast, M, N, K, reserve):
     close(cs, ref_mul.sum(0), 1e-3, 2e-3 * ref_mul.abs().sum(0).max().item(), "mul: column sums")
     assert _rel_l2(cs, ref_mul.sum(0)) < 5e-3, "mul: column sums rel-L2"
   finally:
-    lib.bv_gemm_reserve_cus(old)
+    ctx_.set("gemm_reserve_cus", old)

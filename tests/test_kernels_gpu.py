@@ -153,11 +153,8 @@ def test_sgemm_matrix_pipe_equals_the_valu_kernel(dev, n, B, E):
     ops.sgemm(G, 1, B, zi, E, 1, dzt, B, E, n, alpha=2.0, beta=1.0)
     return raw, dzi, dzt
   new = run()
-  old = lib.bv_sgemm_path(0)
-  try:
+  with ops.option("sgemm_mfma", 0):
     ref = run()
-  finally:
-    lib.bv_sgemm_path(old)
   for a, b, name in zip(new, ref, ("logits", "dzimg", "dztxt")):
     assert torch.equal(a, b), f"{name}: matrix-pipe kernel differs from the VALU kernel"
   assert_close(new[0], zi.double() @ zt.double().T, 1e-5, 1e-4, "logits vs fp64")
@@ -285,21 +282,12 @@ def _attn_ref(qkv, n, L, H):
   return o.reshape(n * L, H * 64), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("impl", [3, 2, 0])
 @pytest.mark.parametrize("n,L,H", [(3, 196, 2), (2, 64, 3), (2, 5, 1), (1, 197, 2), (1, 441, 1), (1, 576, 1),
                                    (2, 224, 1), (1, 33, 2), (2, 257, 1), (3, 208, 1), (2, 272, 2)])
-def test_attention(dev, n, L, H, impl):
-  """impl 3 / 2: LDS-resident kernels (attention3.hip, the default / attention2.hip); 0: the general
-  fallback kernels."""
-  from big_vision_amd import ops, _lib
-  lib = _lib.load()
-  lib.bv_gemm_fast_path(1 if impl else 0)
-  old = lib.bv_attn_impl(impl if impl else -1)
-  try:
-    _attention_case(dev, n, L, H)
-  finally:
-    lib.bv_gemm_fast_path(1)
-    lib.bv_attn_impl(old)
+def test_attention(dev, n, L, H):
+  """The Dh = 64 kernels behind bv_attn_fwd / bv_attn_bwd (attention3.hip, attention5.hip) vs fp64.  (Rounds 1-4 ran
+  the same cases on two superseded kernel sets as well; those left the library in round 5.)"""
+  _attention_case(dev, n, L, H)
 
 
 @pytest.mark.parametrize("n,L,H", [(4, 196, 2), (3, 64, 1), (2, 441, 1), (3, 256, 2)])
@@ -353,49 +341,19 @@ def test_attention_delta_is_exact_for_near_uniform_rows(dev):
   d_o = rnd((n * L, H * 64), dev, 11, dtype=BF16)
   o_ref.backward(d_o.double())
   g = qr.grad.view(n * L, 3, H * 64)
-  lib = _lib.load()
-  rel = {}
-  for impl in (3, 2):
-    old = lib.bv_attn_impl(impl)
-    try:
-      o, lse = ops.attn_fwd(qkv, n, L, H)
-      d = ops.attn_bwd(qkv, o, d_o, lse, n, L, H).double().view(n * L, 3, H * 64)
-    finally:
-      lib.bv_attn_impl(old)
-    rel[impl] = [((d[:, j] - g[:, j]).norm() / g[:, j].norm()).item() for j in range(3)]
-  print("rel-L2 of dq/dk/dv: attention3", rel[3], "attention2", rel[2])
-  # measured on MI355X: attention3 dq 0.079 / dk 0.0023 / dv 0.0023, attention2 dq 32 (!) / dk 0.036 / dv 0.0023
-  assert rel[3][0] <= 0.15 and rel[3][1] <= 1e-2 and rel[3][2] <= 1e-2, rel
-  assert rel[3][0] <= 0.1 * rel[2][0] and rel[3][1] <= 0.5 * rel[2][1], rel
-
-
-def _attention_case(dev, n, L, H):
-  from big_vision_amd import ops
-  qkv = rnd((n * L, 3 * H * 64), dev, 1, 1.5, dtype=BF16)
-  qr = qkv.double().requires_grad_(True)
-  o_ref, lse_ref = _attn_ref(qr, n, L, H)
   o, lse = ops.attn_fwd(qkv, n, L, H)
-  assert_close(lse, lse_ref, 1e-4, 1e-3, "lse")
-  assert_close(o, o_ref, 2e-2, 2e-2, "attn out")
-  d_o = rnd((n * L, H * 64), dev, 2, dtype=BF16)
-  o_ref.backward(d_o.double())
-  dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
-  g = qr.grad
-  err = (dqkv.double() - g).abs().max().item()
-  assert_close(dqkv, g, 3e-2, 3e-2 * g.abs().max().item(), f"dqkv (max err {err:.3e})")
-  # fused q/k/v bias gradient: column sums of dqkv, accumulated in place
-  db = torch.full((3 * H * 64,), 0.5, device=dev)
-  dqkv2 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
-  assert torch.equal(dqkv2, dqkv)
-  cs = g.sum(0)
-  assert_close(db, 0.5 + cs, 2e-2, 2e-2 * g.abs().sum(0).max().item(), "fused qkv bias grad")
-
+  d = ops.attn_bwd(qkv, o, d_o, lse, n, L, H).double().view(n * L, 3, H * 64)
+  rel = [((d[:, j] - g[:, j]).norm() / g[:, j].norm()).item() for j in range(3)]
+  print("rel-L2 of dq/dk/dv:", rel)
+  # measured on MI355X: dq 0.079 / dk 0.0023 / dv 0.0023; the rowsum(dO o O) shortcut with the bf16 O (the round-2
+  # kernels) gave dq 32 (!) / dk 0.036 on the same inputs
+  assert rel[0] <= 0.15 and rel[1] <= 1e-2 and rel[2] <= 1e-2, rel
 
 @pytest.mark.parametrize("n,L,H", [(48, 196, 12), (40, 197, 12), (160, 64, 12), (30, 208, 4), (300, 33, 3)])
 def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
   """attention5.hip (the backward in one launch: persistent workgroups, loader waves prefetching the next
   (sample, head) pair) on more pairs than workgroups, so every workgroup walks 2-3 pairs: vs fp64 on the same
-  bf16 inputs, vs the two-launch kernels of attention3.hip (bv_attn_tune(128)), run-to-run bit-equal (the delta
+  bf16 inputs, vs the two-launch kernels of attention3.hip (BV_OPT_ATTN_CFG bit 128), run-to-run bit-equal (the delta
   partials are summed in a fixed order), and the fused q/k/v bias gradients."""
   from big_vision_amd import ops, _lib
   lib = _lib.load()
@@ -410,13 +368,10 @@ def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
   d5 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
   d5b = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
   assert torch.equal(d5, d5b), "run-to-run / dbias-variant difference"
-  old = lib.bv_attn_tune(-1)
-  lib.bv_attn_tune(old | 128)
-  try:
+  old = ops.ctx_get("attn_cfg")
+  with ops.option("attn_cfg", old | 128):
     db3 = torch.zeros((3 * H * 64,), device=dev)
     d3 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db3)
-  finally:
-    lib.bv_attn_tune(old)
   gmax = g.abs().max().item()
   assert_close(d5, g, 3e-2, 3e-2 * gmax, "one-launch dqkv vs fp64")
   gv = g.view(n * L, 3, H * 64)
@@ -431,12 +386,9 @@ def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
   assert_close(db, db3, 2e-2, tol, "one-launch vs two-launch bias gradients")
   # the bias gradients came from the identities (attention5.hip BM = 2 for L % 16 != 0, BM = 3 otherwise): same
   # again by DPP column sums of dq / dk / dv (BM = 1)
-  lib.bv_attn_tune(old | 256)
-  try:
+  with ops.option("attn_cfg", old | 256):
     dbd = torch.zeros((3 * H * 64,), device=dev)
     d5d = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=dbd)
-  finally:
-    lib.bv_attn_tune(old)
   assert torch.equal(d5d, d5)
   assert_close(dbd, cs, 2e-2, tol, "one-launch bias gradients (column sums) vs fp64")
   for j, name in enumerate(("q", "k", "v")):

@@ -302,15 +302,15 @@ def test_b16_depth2_n64_image_tower_on_gemm256(dev, light):
   contexts (the bench's: LayerNorm outputs and gelu(h) re-emitted by the backward kernels, BV_EPI_GELU /
   BV_EPI_GELU_BWD_EMIT) and once with full contexts (BV_EPI_GELU_GD / BV_EPI_MUL), both as ONE micro-batch of
   64 so every fused epilogue walks its multi-tile persistent schedule, against the fp64 oracle."""
-  from big_vision_amd import _lib
+  from big_vision_amd import ops
   image_cfg = dict(variant="B/16", pool_type="map", depth=2)
   text_cfg = dict(variant="B", depth=2)
-  calls0 = _lib.load().bv_gemm256_calls(2)   # multi-tile walks with a fused epilogue so far
+  calls0 = ops.ctx_get("gemm256_fused")   # multi-tile walks with a fused epilogue through this stream's context so far
   _run_case(dev, image_cfg, text_cfg, E=768, n=64, res=224, seq=64, vocab=32_000,
             config=_cfg(microbatch=64, microbatch_keep="all", microbatch_light=light),
             case=f"siglip B/16 depth2 n=64 (image tower on gemm256), {'light' if light else 'full'} contexts")
   # forward + backward of 2 image blocks: fc1 GELU(_GD), out-proj / fc2 +residual, fc2 dX GELU'(MUL) + column sums
-  assert _lib.load().bv_gemm256_calls(2) >= calls0 + 8, "the image tower did not run on the 256x256 kernel"
+  assert ops.ctx_get("gemm256_fused") >= calls0 + 8, "the image tower did not run on the 256x256 kernel"
 
 
 @pytest.mark.parametrize("stream", ["float32", "bfloat16"])

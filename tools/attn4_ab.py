@@ -1,4 +1,4 @@
-"""A/B of the 32-key-block dK/dV kernel (attn4_bwd_dkv_kernel, bv_attn_tune bits 32 / 64) against the 16-key
+"""A/B of the 32-key-block dK/dV kernel (attn4_bwd_dkv_kernel, BV_OPT_ATTN_CFG bits 32 / 64) against the 16-key
 kernel of attention3.hip: bit-equality of dqkv and the bias-gradient rows, and time per backward. GPU only."""
 import os
 import sys
@@ -24,7 +24,7 @@ def timeit(fn, iters=10, warm=3):
 
 def main():
   lib = _lib.load()
-  base = lib.bv_attn_tune(-1)
+  base = ops.ctx_get("attn_cfg")
   for name, n, L, H in (("img n=2048 L=196", 2048, 196, 12), ("img n=512 L=196", 512, 196, 12), ("LiT n=512 L=197", 512, 197, 12),
                         ("L=256 n=256", 256, 256, 12), ("L/16@336 n=256 L=441", 256, 441, 16)):
     qkv = torch.randn(n * L, 3 * H * 64, device=dev).to(BF16)
@@ -32,7 +32,7 @@ def main():
     o, lse = ops.attn_fwd(qkv, n, L, H)
     res = {}
     for cfg in (0, 32, 64):
-      lib.bv_attn_tune(cfg)
+      ops.ctx_set("attn_cfg", cfg)
       dq = torch.zeros_like(qkv)
       db = torch.zeros(3 * H * 64, device=dev)
       ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=dq, dbias=db)
@@ -43,7 +43,7 @@ def main():
     ok64 = torch.equal(res[0][0], res[64][0]), (res[0][1] - res[64][1]).abs().max().item()
     print(f"{name:24s} bwd us: 16-key {res[0][2]:7.1f} | 32-key 4x2 {res[32][2]:7.1f} (dqkv equal {ok32[0]}, dbias maxdiff {ok32[1]:.2e})"
           f" | 32-key 7x1 {res[64][2]:7.1f} (dqkv equal {ok64[0]}, dbias maxdiff {ok64[1]:.2e})", flush=True)
-  lib.bv_attn_tune(base)
+  ops.ctx_set("attn_cfg", base)
 
 
 if __name__ == "__main__":

@@ -1,4 +1,4 @@
-"""A/B of the attention implementations (bv_attn_impl 2 / 3) at the training step's shapes. GPU only."""
+"""A/B of the attention backward paths (BV_OPT_ATTN_CFG bit 128: two launches / one launch) at the training step's shapes. GPU only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,15 +30,14 @@ def main():
     gbb = (3 * n * L * H * 64 * 2 * 2 + 2 * n * L * H * 64 * 2) / 1e9   # bwd (att3): qkv x2 passes, dO x2, dqkv write
     fl = 4 * n * H * L * L * 64 / 1e12
     row = [name]
-    for impl in (2, 3, 5):   # 5 = attention3 forward + the one-launch backward of attention5.hip (the default)
-      lib.bv_attn_impl(3 if impl == 5 else impl)
-      lib.bv_attn_tune(0 if impl == 5 else 128)
+    for impl in (3, 5):   # 3 = two-launch backward of attention3.hip, 5 = the one-launch backward of attention5.hip (the default)
+      ops.ctx_set("attn_cfg", 0 if impl == 5 else 128)
       o, lse = ops.attn_fwd(qkv, n, L, H)
       dq = torch.empty_like(qkv)
       tf = timeit(lambda: ops.attn_fwd(qkv, n, L, H))
       tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=dq, dbias=db))
       row.append(f"impl{impl}: fwd {tf:7.1f} us ({gb / tf * 1e3:5.2f} TB/s, {fl / tf * 1e6:5.0f} TF)  bwd {tb:7.1f} us ({gbb / tb * 1e3:5.2f} TB/s)")
-    lib.bv_attn_impl(3); lib.bv_attn_tune(0)
+    ops.ctx_set("attn_cfg", 0)
     print(" | ".join(row), flush=True)
 
 

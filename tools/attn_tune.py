@@ -1,4 +1,4 @@
-"""A/B of the bv_attn_tune switches at the image tower's shape. GPU only."""
+"""A/B of the BV_OPT_ATTN_CFG switches at the image tower's shape. GPU only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,12 +13,12 @@ def main():
     qkv = torch.randn(n * L, 3 * H * 64, device=dev).to(BF16)
     d_o = torch.randn(n * L, H * 64, device=dev).to(BF16)
     db = torch.zeros(3 * H * 64, device=dev)
-    lib.bv_attn_tune(16)
+    ops.ctx_set("attn_cfg", 16)
     o0, lse0 = ops.attn_fwd(qkv, n, L, H)
     dq0 = torch.empty_like(qkv)
     ops.attn_bwd(qkv, o0, d_o, lse0, n, L, H, dqkv=dq0, dbias=db)
     for cfg in cfgs:
-      lib.bv_attn_tune(cfg)
+      ops.ctx_set("attn_cfg", cfg)
       o, lse = ops.attn_fwd(qkv, n, L, H)
       dq = torch.empty_like(qkv)
       ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=dq, dbias=db)
@@ -28,7 +28,7 @@ def main():
       tb = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=dq, dbias=db))
       tn = timeit(lambda: ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dqkv=dq))
       print(f"{name} cfg {cfg}: fwd {tf:7.1f} us  bwd {tb:7.1f} us (without the bias sums {tn:7.1f})  bit-equal to the two-sweep default: {same} (dqkv rel-L2 {rel:.2e})", flush=True)
-    lib.bv_attn_tune(0)
+    ops.ctx_set("attn_cfg", 0)
 
 
 if __name__ == "__main__":

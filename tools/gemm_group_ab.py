@@ -1,4 +1,4 @@
-"""A/B of the k-major tile order (bv_gemm_group_n): per step shape and epilogue, us per launch for groups of
+"""A/B of the k-major tile order (BV_OPT_GEMM_GROUP_N): per step shape and epilogue, us per launch for groups of
 g column tiles, bit-compared with the plain order; `--step g [bench args]` runs bench.py's main with the knob set.  GPU only."""
 import os
 import sys
@@ -22,7 +22,7 @@ def timeit(fn, iters=6, warm=2):
 def main():
   lib = _lib.load()
   if len(sys.argv) > 2 and sys.argv[1] == "--step":
-    lib.bv_gemm_group_n(int(sys.argv[2]))
+    ops.ctx_set("gemm_group_n", int(sys.argv[2]))
     import bench
     sys.argv = ["bench.py"] + sys.argv[3:]
     return bench.main()
@@ -53,7 +53,7 @@ def main():
       run = lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out=out, out2=out2, **kw)
       cells, ref = [], None
       for g in groups:
-        lib.bv_gemm_group_n(g)
+        ops.ctx_set("gemm_group_n", g)
         us = timeit(run)
         got = (out.clone(), out2.clone() if out2 is not None else None)
         if ref is None:
@@ -62,7 +62,7 @@ def main():
         else:
           same = "=" if torch.equal(ref[0], got[0]) and (ref[1] is None or torch.equal(ref[1], got[1])) else "!"
         cells.append(f"{us:8.1f}{same}")
-      lib.bv_gemm_group_n(0)
+      ops.ctx_set("gemm_group_n", 0)
       flops = 2.0 * T * N * a.shape[1]
       print(f"T={T:6d} {name:32s} | " + " ".join(cells) + f" | plain {flops / float(cells[0].strip('=!')) / 1e6:6.0f} TFLOP/s", flush=True)
     del x, hM, res

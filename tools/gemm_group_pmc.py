@@ -1,4 +1,4 @@
-"""FETCH_SIZE of the wide k-major GEMMs per tile order (bv_gemm_group_n).  Run under
+"""FETCH_SIZE of the wide k-major GEMMs per tile order (BV_OPT_GEMM_GROUP_N).  Run under
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR -- python tools/gemm_group_pmc.py run
 then  python tools/gemm_group_pmc.py parse <counter_collection.csv>.  GPU only."""
 import csv
@@ -29,7 +29,7 @@ def run():
     o1, o2 = torch.empty(T, M, device=dev, dtype=BF16), torch.empty(T, M, device=dev, dtype=BF16)
     torch.cuda.synchronize()
     for g in GROUPS:
-      lib.bv_gemm_group_n(g)
+      ops.ctx_set("gemm_group_n", g)
       for _ in range(REPS):
         ops.gemm(x, wq, a_kmajor=True, b_kmajor=True, out=oq, bias=bq)
       for _ in range(REPS):
@@ -37,7 +37,7 @@ def run():
       for _ in range(REPS):
         ops.gemm(x, w1, a_kmajor=True, b_kmajor=True, out=o1, out2=o2, epilogue=ops.EPI_GELU_BWD_EMIT, aux=hM)
       torch.cuda.synchronize()
-    lib.bv_gemm_group_n(0)
+    ops.ctx_set("gemm_group_n", 0)
 
 
 def parse(path):

@@ -1,4 +1,4 @@
-"""A/B sweep of the k-major GEMM tuning knobs (bv_gemm_tune) over every (shape, epilogue)
+"""A/B sweep of the k-major GEMM tuning knobs (BV_OPT_GEMM_NT / _SKEW_MODE / _SKEW_PCT / _PRE_ISSUE of the context) over every (shape, epilogue)
 instance of the training step.  GPU only.  Prints one row per case, one column per variant;
 also checks that every variant's output is bit-identical to the baseline's."""
 import sys, os
@@ -50,7 +50,8 @@ def main():
       ref = None
       row = []
       for v in VARIANTS:
-        lib.bv_gemm_pre_issue(v[0]); lib.bv_gemm_tune(*v[1:])
+        for k_, v_ in zip(("gemm_pre_issue", "gemm_nt", "gemm_skew_mode", "gemm_skew_pct"), v):
+          ops.ctx_set(k_, v_)
         out.zero_()
         ms = timeit(lambda: ops.gemm(a, b, a_kmajor=True, b_kmajor=True, out=out, **kw))
         if ref is None:
@@ -59,7 +60,8 @@ def main():
           print("MISMATCH", name, v)
         row.append(ms)
         sums[(T, v)] = sums.get((T, v), 0.0) + ms
-      lib.bv_gemm_pre_issue(1); lib.bv_gemm_tune(0, 1, 0)
+      for k_, v_ in zip(("gemm_pre_issue", "gemm_nt", "gemm_skew_mode", "gemm_skew_pct"), (0, 0, 1, 0)):
+        ops.ctx_set(k_, v_)
       print(f"T={T:6d} {name:24s} N={N:4d} K={K:4d} " + " ".join(f"{m*1e3:7.1f}" for m in row) +
             f"   best {2*T*N*K/min(row)/1e9:7.1f} TF/s")
     print(f"T={T} sums: " + " ".join(f"{sums[(T, v)]*1e3:7.1f}" for v in VARIANTS))

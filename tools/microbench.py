@@ -38,27 +38,26 @@ def main():
     ms = timeit(lambda: ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=dw, epilogue=ops.EPI_ATOMIC))
     res[f"dw_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
   # 256x256 direct-to-LDS path (NT with pre-transposed weights) vs the general kernel
-  from big_vision_amd import _lib
   for name, K, N in (("qkv", D, 3 * D), ("out", D, D), ("fc1", D, M), ("fc2", M, D)):
     a = x if K == D else h
     wt = (torch.randn(N, K, device=dev) * 0.02).to(BF16)     # W^T [out][in]
     out = torch.empty(T, N, device=dev, dtype=BF16)
     for fast in (1, 0):
-      _lib.load().bv_gemm_fast_path(fast)
+      ops.ctx_set("fast_path", fast)
       ms = timeit(lambda: ops.gemm(a, wt, a_kmajor=True, b_kmajor=True, out=out))
       res[f"nt{'256' if fast else '128'}_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
     dy = x if N == D else (h if N == M else torch.randn(T, N, device=dev).to(BF16))
     dw = torch.zeros(K, N, device=dev)
     for fast in (1, 0):
-      _lib.load().bv_gemm_fast_path(fast)
+      ops.ctx_set("fast_path", fast)
       ms = timeit(lambda: ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=dw, epilogue=ops.EPI_ATOMIC))
       res[f"tn{'256' if fast else '128'}_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
-    _lib.load().bv_gemm_fast_path(1)
-    _lib.load().bv_set_workspace(None, 0)     # fp32-atomic split-K for comparison
+    ops.ctx_set("fast_path", 1)
+    ops.ctx().use_workspace = False     # fp32-atomic split-K for comparison
     ms = timeit(lambda: ops.gemm(a, dy, a_kmajor=False, b_kmajor=False, out=dw, epilogue=ops.EPI_ATOMIC))
     res[f"tn256atomic_{name}"] = (ms, 2 * T * N * K / ms / 1e9)
-    ops._workspace = None
-  _lib.load().bv_gemm_fast_path(1)
+    ops.ctx().use_workspace = True
+  ops.ctx_set("fast_path", 1)
   qkv = torch.randn(T, 3 * D, device=dev).to(BF16)
   ms = timeit(lambda: ops.attn_fwd(qkv, n, L, H))
   fl = 4 * n * H * L * L * 64

@@ -5,9 +5,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../big_vision_amd/csrc/attention3.hip"
+#include "probe_ctx.h"
 // (attention3.hip hands the unmasked backward to attention5.hip; the forward probe links without it)
 int g_a5_bias_dpp = 0;
-int bv_attn5_bwd(const void*, const void*, const float*, float*, void*, float*, int, int, int, void*) { return -100; }
+int bv_attn5_bwd(const void*, const void*, const float*, float*, void*, float*, int, int, int, void*, bool) { return -100; }
 
 __global__ void fill(unsigned short* p, size_t n, unsigned seed) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -33,10 +34,10 @@ int main(int argc, char** argv) {
 #endif
   for (int cfg : {0, 8, 0, 8}) {   // twice: the first measurement of a process runs on the ramping clock
     bv_attn_tune(cfg);
-    for (int i = 0; i < 3; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr);
+    for (int i = 0; i < 3; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr, probe_ctx());
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr);
+    for (int i = 0; i < 10; ++i) bv_attn3_fwd(qkv, o, lse, nullptr, n, L, H, nullptr, probe_ctx());
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("A3_PROBE=%d cfg %d n=%d: fwd %.1f us  (%s)\n", A3_PROBE, cfg, n, ms * 100.f, hipGetErrorString(hipGetLastError()));

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <vector>
 #include "../../big_vision_amd/csrc/gemm256.hip"
+#include "probe_ctx.h"
 
 __global__ void fill_bf16(unsigned short* d, size_t n, unsigned seed, float scale) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -94,7 +95,7 @@ int main(int argc, char** argv) {
     const int it = s.M > 200000 ? 4 : 8;
     auto tf = [&](int epi, int f32, const void* aux, void* c2, float* cs) {
       auto run = [&] {
-        const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c0, s.N, f32, s.M, s.N, s.K, epi, bias, aux, s.N, 0, c2, 1.0f, 0, cs, nullptr);
+        const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c0, s.N, f32, s.M, s.N, s.K, epi, bias, aux, s.N, 0, c2, 1.0f, 0, cs, nullptr, probe_ctx());
         if (!ok) { printf("not dispatched\n"); exit(1); }
       };
       float t = 1e30f;

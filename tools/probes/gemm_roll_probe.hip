@@ -12,6 +12,7 @@
 #include <string.h>
 #include <vector>
 #include "../../big_vision_amd/csrc/gemm256.hip"
+#include "probe_ctx.h"
 
 __global__ void fill_bf16(unsigned short* d, size_t n, unsigned seed, float scale) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -120,7 +121,7 @@ int main(int argc, char** argv) {
       bv_gemm_roll(roll ? mask : 0);
       const int ok = bv_gemm256_try(1, 1, a, s.K, b, s.K, c, ldc, f32 ? 1 : 0, s.M, s.N, s.K, s.epi, bias,
                                     f32 ? aux : nullptr, s.N, 0, s.epi == BV_EPI_GELU ? c2 : nullptr, 1.0f, 0,
-                                    nullptr, nullptr);
+                                    nullptr, nullptr, probe_ctx());
       if (!ok) { printf("%s: not dispatched to the 256x256 path\n", s.name); exit(1); }
     };
     (void)hipMemset(c0, 0xff, cbytes); (void)hipMemset(c1, pad ? 0xff : 0xee, cbytes);

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "../../big_vision_amd/csrc/gemm256.hip"
+#include "probe_ctx.h"
 
 namespace {
 
@@ -216,7 +217,7 @@ int main() {
     const int grid = p.ntiles < 256 ? p.ntiles : 256;
     auto ref = [&]() {
       if (!bv_gemm256_try(1, 1, a, s.K, b, s.K, c0, s.N, 0, s.M, s.N, s.K, BV_EPI_NONE, nullptr, nullptr, 0, 0, nullptr, 1.0f,
-                          0, nullptr, nullptr)) { printf("ref not dispatched\n"); exit(1); }
+                          0, nullptr, nullptr, probe_ctx())) { printf("ref not dispatched\n"); exit(1); }
     };
     auto w4 = [&]() { hipLaunchKernelGGL(gemm_w4_kernel, dim3(grid), dim3(256), 0, 0, p); };
     ref(); w4();

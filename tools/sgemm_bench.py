@@ -25,13 +25,13 @@ def main():
     raw = torch.empty(n, B, device=dev); dzi = torch.empty(n, E, device=dev); dzt = torch.empty(B, E, device=dev)
     row = [f"n={n} B={B}"]
     for path in (0, 1):
-      lib.bv_sgemm_path(path)
+      ops.ctx_set("sgemm_mfma", path)
       t1 = timeit(lambda: ops.sgemm(zi, E, 1, zt, 1, E, raw, n, B, E))
       t2 = timeit(lambda: ops.sgemm(G, B, 1, zt, E, 1, dzi, n, E, B))
       t3 = timeit(lambda: ops.sgemm(G, 1, B, zi, E, 1, dzt, B, E, n))
       fl = 2.0 * n * B * E / 1e6
       row.append(f"{'mfma' if path else 'valu'}: logits {t1:7.1f} us ({fl / t1:5.1f} TF) dzimg {t2:7.1f} ({fl / t2:5.1f}) dztxt {t3:7.1f} ({fl / t3:5.1f})")
-    lib.bv_sgemm_path(1)
+    ops.ctx_set("sgemm_mfma", 1)
     print(" | ".join(row), flush=True)
 
 
