@@ -193,6 +193,7 @@ def _bare_sharded_step(comm, rank, world):
   state, _ = siglip.make_train_state(model, config, (8, 64, 64, 3), (8, 16), rng=0, comm=comm, total_steps=10)
   opt, store = state["opt"], state["params"].store
   assert bool(getattr(opt, "sharded", False)) == (world > 1)
+  store.zero_grad()          # allocates the flat gradient buffer
   g = torch.Generator(device="cpu").manual_seed(7)
   full = torch.randn(store.trainable_count, generator=g) * 1e-2
   # rank r contributes (r + 1) / sum of the global gradient: the partial sums add up to `full` (not bit-exactly)
