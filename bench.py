@@ -399,13 +399,40 @@ def workload_rank_shape(dev, steps, n, stream="float32"):
   return r
 
 
+def workload_rank_shape_rccl(dev, steps, n):
+  """workload_rank_shape with the step's collectives IN the loop: a one-rank RCCL group and dp.Comm(force=True), so
+  that all_gather_into_tensor / reduce_scatter_tensor / the bucketed gradient all-reduce on the side stream / the
+  scalar all-reduce are issued exactly as N > 1 issues them (the call path the driver's N = 1 box can execute)."""
+  import torch.distributed as dist
+  from big_vision_amd import dp
+  own = not dist.is_initialized()
+  if own:
+    port = _free_port()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(dp.RESERVED_CUS))
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+  try:
+    comm = dp.Comm(force=True)
+    r = workload_siglip(dev, steps, IMAGE_CFG, TEXT_CFG, EMB, n=n, res=RES, seq=SEQ, micro=MICRO, comm=comm,
+                        gflop_per_pair=MATMUL_GFLOP_PER_PAIR,
+                        label=f"headline model, the {n} pairs one rank owns, collectives issued on a one-rank RCCL group")
+    r["metric"] = (f"image-text pairs/sec per GPU at {n} pairs per GPU with the RCCL collectives of the step in the loop "
+                   "(one-rank group)")
+    r["rccl"] = rccl_info(comm, dev)
+  finally:
+    if own:
+      dist.destroy_process_group()
+  return r
+
+
 def configs_object(dev, steps=3):
   """The `configs` object of the N = 1 line: every entry is measured here, after the headline, on the same device."""
   import gc
   out = {}
   for key, fn in (("c2", lambda: workload_c2(dev, steps)), ("c4_rank", lambda: workload_c4(dev, steps)),
                   ("c5b", lambda: workload_c5b(dev, steps)), ("rank512", lambda: workload_rank_shape(dev, steps, 512)),
-                  ("rank1024", lambda: workload_rank_shape(dev, steps, 1024))):
+                  ("rank1024", lambda: workload_rank_shape(dev, steps, 1024)),
+                  ("rank512_rccl", lambda: workload_rank_shape_rccl(dev, steps, 512))):
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
@@ -415,6 +442,8 @@ def configs_object(dev, steps=3):
                   "steps": steps, "roofline_frac": r["roofline"]["frac"], "step_frac": r.get("step_frac"),
                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                   "final_loss": r["config"].get("final_loss")}
+      if "rccl" in r:
+        out[key]["rccl"] = r["rccl"]
     except Exception as e:   # the headline must not depend on the extra workloads
       out[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
   return out

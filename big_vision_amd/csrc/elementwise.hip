@@ -269,6 +269,37 @@ __global__ __launch_bounds__(256) void pool_gap_bwd_kernel(const float* __restri
   }
 }
 
+// pool_type "max" / "gmp" of the text tower (text_transformer.py:89-90): y[b][c] = max_l x[b][l][c]; the index of the
+// (first) maximum is kept for the backward, which routes dy[b][c] to that one position (ties have measure zero in
+// float activations; jnp.max's VJP would split the cotangent between exact ties).
+__global__ __launch_bounds__(256) void pool_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int* __restrict__ arg, int n, int L, int D) {
+  const long total = (long)n * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / D;
+    const int c = (int)(i - b * D);
+    float best = x[(b * L) * D + c];
+    int at = 0;
+    for (int l = 1; l < L; ++l) {
+      const float v = x[(b * L + l) * D + c];
+      if (v > best) { best = v; at = l; }
+    }
+    y[i] = best;
+    arg[i] = at;
+  }
+}
+__global__ __launch_bounds__(256) void pool_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                                           float* __restrict__ dx, int n, int L, int D) {
+  const long total = (long)n * L * D;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long row = i / D;
+    const int c = (int)(i - row * D);
+    const long b = row / L;
+    const int l = (int)(row - b * L);
+    dx[i] = arg[b * D + c] == l ? dy[b * D + c] : 0.f;
+  }
+}
+
 // gap over the first len[b] rows only (NaFlex: padding excluded, naflex_vit.py:262-264)
 __global__ __launch_bounds__(256) void pool_gap_masked_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   const int* __restrict__ len, int n, int L, int D) {
@@ -604,6 +635,20 @@ extern "C" int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, 
   hipLaunchKernelGGL(pool_gap_bwd_kernel, dim3(grid_for((long)n * L * D / 4, 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, dy, dx, n, L, D);
   return bv_check_launch("bv_pool_gap_bwd");
+}
+
+// models/proj/image_text/text_transformer.py:89-90
+extern "C" int bv_pool_max_fwd(const float* x, float* y, int* argmax, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D > 0 && argmax != nullptr, "bv_pool_max_fwd: bad arguments");
+  hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(grid_for((long)n * D, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     argmax, n, L, D);
+  return bv_check_launch("bv_pool_max_fwd");
+}
+extern "C" int bv_pool_max_bwd(const float* dy, const int* argmax, float* dx, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D > 0 && argmax != nullptr, "bv_pool_max_bwd: bad arguments");
+  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(grid_for((long)n * L * D, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     dy, argmax, dx, n, L, D);
+  return bv_check_launch("bv_pool_max_bwd");
 }
 
 extern "C" int bv_pool_gap_masked_fwd(const float* x, float* y, const int* len, int n, int L, int D, void* stream) {

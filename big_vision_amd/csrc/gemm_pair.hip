@@ -237,7 +237,10 @@ struct PCursor {   // position of the load stream: item j of this workgroup, K-t
     __builtin_amdgcn_sched_barrier(0);                                                                                \
   } while (0)
 
-template <int EPI, bool OUTF32>
+// PROBE != 0 exists only for tools/probes/gemm_pair_probe.hip (bottleneck ablation, results are garbage): bit 0 = no
+// global->LDS requests after the prologue, bit 1 = fragment reads only for the first K-tile, bit 2 = no epilogue.
+// The library instantiates PROBE = 0 only.
+template <int EPI, bool OUTF32, int PROBE = 0>
 __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(PairParams p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x;
@@ -287,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(PairParams p) {
   const bf16* const srcA = p.A + (long)(wave * 16 + (lane >> 2)) * p.lda + chunk * 8;
   const bf16* const srcB = p.B + (long)(wave * 16 + (lane >> 2)) * p.ldb + chunk * 8;
   const long qA = 64 * p.lda, qB = 64 * p.ldb;
+  bool probe_quiet = false;   // PROBE: past the prologue / the first K-tile
   auto issue = [&](const PCursor& c, int stage) {
+    if ((PROBE & 1) && probe_quiet) return;
     char* d = smem + stage * P_STAGE + wave * 1024;
     const bf16* a = srcA + c.offA + c.t * 32;
     p_glds16(a, d);
@@ -331,12 +336,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(PairParams p) {
       const uint32_t a0 = ra + so, b0 = rb + so;
       // fragment reads of this K-tile (12 x 1 KiB), then the request for the K-tile two ahead into the stage the
       // previous K-tile used (everybody left it before the barrier that ended that iteration)
-      bfg[0] = p_lds_read128<0>(b0);  bfg[1] = p_lds_read128<O1>(b0);
-      bfg[2] = p_lds_read128<O2>(b0); bfg[3] = p_lds_read128<O3>(b0);
-      af[0] = p_lds_read128<0>(a0);    af[1] = p_lds_read128<1024>(a0);
-      af[2] = p_lds_read128<2048>(a0); af[3] = p_lds_read128<3072>(a0);
-      af[4] = p_lds_read128<4096>(a0); af[5] = p_lds_read128<5120>(a0);
-      af[6] = p_lds_read128<6144>(a0); af[7] = p_lds_read128<7168>(a0);
+      if (!((PROBE & 2) && probe_quiet)) {
+        bfg[0] = p_lds_read128<0>(b0);  bfg[1] = p_lds_read128<O1>(b0);
+        bfg[2] = p_lds_read128<O2>(b0); bfg[3] = p_lds_read128<O3>(b0);
+        af[0] = p_lds_read128<0>(a0);    af[1] = p_lds_read128<1024>(a0);
+        af[2] = p_lds_read128<2048>(a0); af[3] = p_lds_read128<3072>(a0);
+        af[4] = p_lds_read128<4096>(a0); af[5] = p_lds_read128<5120>(a0);
+        af[6] = p_lds_read128<6144>(a0); af[7] = p_lds_read128<7168>(a0);
+      }
       const bool more = ld.j < nmy;
       if (more) issue(ld, (gk + 2) % 3);
       // (waits are untied; the empty statements behind them name the registers the reads fill, so that no consumer can
@@ -382,10 +389,18 @@ __global__ __launch_bounds__(256, 2) void gemm_pair_kernel(PairParams p) {
       }
       __builtin_amdgcn_s_barrier();
       ++gk;
+      probe_quiet = true;
     }
     int m0, n0;
     item_mn(jt, m0, n0);
-    pair_epilogue<EPI, OUTF32>(p, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
+    if constexpr (PROBE & 4) {   // keep the math live, skip conversion and stores
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
+      pair_epilogue<EPI, OUTF32>(p, acc, m0 + wr * 128, n0 + wc * 64, lr, lg);
+    }
   }
 }
 

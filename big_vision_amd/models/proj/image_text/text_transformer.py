@@ -67,6 +67,11 @@ class TextExec:
       z = ops.pool_gap_fwd(yf, n, L, D)
       zb = ops.cast_bf16(z)
       ctx.update(norm=(mean, rstd))
+    elif m.pool_type in ("max", "gmp"):       # text_transformer.py:89-90
+      _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
+      z, arg = ops.pool_max_fwd(yf, n, L, D)
+      zb = ops.cast_bf16(z)
+      ctx.update(norm=(mean, rstd), argmax=arg)
     elif m.pool_type == "map":
       y, _, mean, rstd = self.enc.norm.fwd(xL, T, D)
       z, msaved = self.map.fwd(y, n, L)
@@ -103,6 +108,9 @@ class TextExec:
     elif m.pool_type in ("mean", "gap"):
       dyf = ops.pool_gap_bwd(dz, n, L, D)
       dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+    elif m.pool_type in ("max", "gmp"):
+      dyf = ops.pool_max_bwd(dz, ctx["argmax"], n, L, D)
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     else:
       dy = self.map.bwd(ctx["map"], dz, n, L)
       dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
@@ -121,7 +129,7 @@ class _Model:
                name=None):
     if dropout:
       raise NotImplementedError("dropout > 0 is not on the accelerated path")
-    if pool_type not in ("last", "first", "mean", "gap", "map"):
+    if pool_type not in ("last", "first", "mean", "gap", "max", "gmp", "map"):
       raise NotImplementedError(f"Cannot do pooling '{pool_type}'")
     if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
       raise NotImplementedError(f"attention kernels need a head_dim that is a multiple of 8 and <= 128 (64 is the "

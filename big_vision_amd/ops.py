@@ -431,6 +431,22 @@ def pool_gap_bwd(dy, n, L, D, lens=None):
   return dx
 
 
+def pool_max_fwd(x, n, L, D):
+  """max over the L positions (text pool_type "max" / "gmp"); returns (pooled [n, D], argmax int32 [n, D])."""
+  _chk(x, F32, "pool_max.x")
+  y = torch.empty((n, D), device=x.device, dtype=F32)
+  arg = torch.empty((n, D), device=x.device, dtype=torch.int32)
+  _lib.call("bv_pool_max_fwd", _p(x), _p(y), _p(arg), n, L, D, _stream())
+  return y, arg
+
+
+def pool_max_bwd(dy, arg, n, L, D):
+  _chk(dy, F32, "pool_max.dy")
+  dx = torch.empty((n * L, D), device=dy.device, dtype=F32)
+  _lib.call("bv_pool_max_bwd", _p(dy), _p(arg), _p(dx), n, L, D, _stream())
+  return dx
+
+
 def naflex_posemb_weights(yabs, xabs, P):
   """[n*N, P*P] bf16 resize-and-gather weights of the NaFlex position embedding (bv_naflex_posemb_weights)."""
   _chk(yabs, torch.int32, "naflex.yabs"); _chk(xabs, torch.int32, "naflex.xabs")

@@ -313,6 +313,11 @@ int bv_concat_cls(const float* cls, const float* x, float* y, int n, int L, int 
 /* pooled[i][c] = mean_l x[i][l][c] (pool_type="gap", models/vit.py:246); fp32. */
 int bv_pool_gap_fwd(const float* x, float* y, int n, int L, int D, void* stream);
 int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, void* stream);
+/* pooled[i][c] = max_l x[i][l][c] (pool_type "max" / "gmp" of the text tower,
+ * models/proj/image_text/text_transformer.py:89-90); argmax [n][D] int32 keeps the position of the (first) maximum,
+ * the backward writes dy[i][c] there and 0 to the other L - 1 positions; fp32. */
+int bv_pool_max_fwd(const float* x, float* y, int* argmax, int n, int L, int D, void* stream);
+int bv_pool_max_bwd(const float* dy, const int* argmax, float* dx, int n, int L, int D, void* stream);
 
 /* ------------------------------------------------------------ L2 normalise --
  * zn = z / (||z||_2 + eps), eps = 1e-8 (models/proj/image_text/two_towers.py:60-61,

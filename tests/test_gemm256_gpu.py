@@ -433,7 +433,9 @@ def test_pair_kernel_is_bit_identical_to_gemm256(dev, fast, M, N, K):
   atomics: summation order).  12544 x 3072: 4704 tiles, every persistent workgroup walks 9-10; K = 64 / 192: the
   two- and six-K-tile streams across tile boundaries; run-to-run bit-equality as the race screen."""
   from big_vision_amd import ops
-  with ops.option("gemm_pair", 0):
+  # (gemm_roll = 0: the default routes the fp32 +residual epilogue to the rolling kernel, which sums the residual
+  # FIRST - loaded into the accumulators - instead of last: same value to rounding order, not the same bits)
+  with ops.option("gemm_pair", 0), ops.option("gemm_roll", 0):
     ref = _every_km_epilogue(ops, dev, M, N, K)
   calls0 = ops.ctx_get("gemm_pair_calls")
   with ops.option("gemm_pair", PAIR_ALL):

@@ -349,6 +349,29 @@ def test_attention_delta_is_exact_for_near_uniform_rows(dev):
   # kernels) gave dq 32 (!) / dk 0.036 on the same inputs
   assert rel[0] <= 0.15 and rel[1] <= 1e-2 and rel[2] <= 1e-2, rel
 
+
+def _attention_case(dev, n, L, H):
+  from big_vision_amd import ops
+  qkv = rnd((n * L, 3 * H * 64), dev, 1, 1.5, dtype=BF16)
+  qr = qkv.double().requires_grad_(True)
+  o_ref, lse_ref = _attn_ref(qr, n, L, H)
+  o, lse = ops.attn_fwd(qkv, n, L, H)
+  assert_close(lse, lse_ref, 1e-4, 1e-3, "lse")
+  assert_close(o, o_ref, 2e-2, 2e-2, "attn out")
+  d_o = rnd((n * L, H * 64), dev, 2, dtype=BF16)
+  o_ref.backward(d_o.double())
+  dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H)
+  g = qr.grad
+  err = (dqkv.double() - g).abs().max().item()
+  assert_close(dqkv, g, 3e-2, 3e-2 * g.abs().max().item(), f"dqkv (max err {err:.3e})")
+  # fused q/k/v bias gradient: column sums of dqkv, accumulated in place
+  db = torch.full((3 * H * 64,), 0.5, device=dev)
+  dqkv2 = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=db)
+  assert torch.equal(dqkv2, dqkv)
+  cs = g.sum(0)
+  assert_close(db, 0.5 + cs, 2e-2, 2e-2 * g.abs().sum(0).max().item(), "fused qkv bias grad")
+
+
 @pytest.mark.parametrize("n,L,H", [(48, 196, 12), (40, 197, 12), (160, 64, 12), (30, 208, 4), (300, 33, 3)])
 def test_attention_one_launch_backward_walks_many_pairs(dev, n, L, H):
   """attention5.hip (the backward in one launch: persistent workgroups, loader waves prefetching the next

@@ -185,6 +185,16 @@ def test_tiny_tok_pooling(dev):
   _run_case(dev, image_cfg, text_cfg, E=128, n=6, res=48, seq=8, vocab=64, bias_init=-2.71, floor=True, rel_max=4e-2)
 
 
+@pytest.mark.parametrize("pool", ["max", "gmp", "mean", "first"])
+def test_tiny_text_pooling_variants(dev, pool):
+  """The text tower's other pool_type values (text_transformer.py:83-90; the BASELINE configs use "last" and "map"):
+  "max" / "gmp" = max over the sequence (bv_pool_max_fwd / _bwd: the cotangent goes to the arg-max position), "mean",
+  "first" - against the fp64 oracle, the bounds of every other case."""
+  image_cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, pool_type=pool)
+  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=48, seq=16, vocab=100, floor=True)
+
+
 @pytest.mark.parametrize("which", ["tiny", "tiny_tok_lit", "b16", "b16_n32", "lit_b16"])
 def test_bf16_residual_stream_step(dev, which):
   """config.residual_stream = "bfloat16": the activations between the blocks and their gradients are
