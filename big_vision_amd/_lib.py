@@ -85,7 +85,7 @@ PROTOTYPES["bv_adafactor_leaf"] = [P, P, P, c_int, P, P, P, c_int, P, c_float, c
                                    c_float, c_float, c_float, P, P]
 
 PROTOTYPES["bv_adafactor_step"] = [P, P, P, c_int, P, P, c_int, c_long, c_long, c_long, c_long, P, P, c_float, c_float,
-                                   c_float, c_float, P, c_int, P, P]
+                                   c_float, c_float, P, c_int, P, c_float, P, P]
 
 # collectives for non-Python hosts (csrc/comm.cpp; the Python host uses torch.distributed, dp.py)
 PROTOTYPES.update({

@@ -1,6 +1,6 @@
 // BigVision Adafactor (big_vision/optax.py:187-216: optax.scale_by_factored_rms(factored=True,
 // decay_rate 0.8 as 1 - t^-0.8 capped at 0.999, min_dim_size_to_factor 32, eps 1e-30) ->
-// [clip_by_block_rms: off by default] -> optax.ema(0.9, debias=False, bf16 accumulator)) fused with
+// [clip_by_block_rms(clipping_threshold): per-leaf, bv_adafactor_step only] -> optax.ema(0.9, debias=False, bf16 accumulator)) fused with
 // the rest of the bv_optax chain (optax.py:100-149: global-norm clip, lr, lr_mults, decoupled weight
 // decay, schedule, sign, apply) - per parameter LEAF, because the second-moment statistics are
 // factored along the two largest axes of each leaf.
@@ -216,19 +216,63 @@ __global__ __launch_bounds__(256) void af_rcm_batched(const bv_af_leaf* __restri
   if (threadIdx.x == 0) rcm[blockIdx.x] = s / (float)L.R;
 }
 
+// optax.clip_by_block_rms (scale_by_adafactor(clipping_threshold=...), optax.py:208): per LEAF, u /= max(1, rms(u) /
+// threshold) with u the output of scale_by_factored_rms.  This pass adds every leaf's sum of u^2 (from the statistics
+// the row / column / rcm passes just updated; an unfactored leaf's v is advanced in registers only - the update pass
+// stores it) into usq[leaf]; the update pass turns it into the scale.
+__global__ __launch_bounds__(256) void af_usq_batched(const float* __restrict__ g, const bv_af_leaf* __restrict__ leaves,
+                                                      const float* __restrict__ state, const double* gsq, float clip_norm,
+                                                      float decay, float eps, double* __restrict__ usq) {
+  __shared__ float sh[4];
+  const bv_af_leaf L = leaves[blockIdx.y];
+  const AfView v = af_view_of(L);
+  const long B = (long)v.B1 * v.B2;
+  const long total = B * v.R * v.C;
+  if ((long)blockIdx.x * 256 >= total) return;
+  const float* v_row = state + L.soff;
+  const float* v_col = v_row + B * v.R;
+  const float* rcm = v_col + B * v.C;
+  const float* vfull = state + L.soff;
+  const float cf = clip_factor(gsq, clip_norm);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int r, c;
+    long b;
+    if (L.r_fast) { r = (int)(i % v.R); const long t = i / v.R; c = (int)(t % v.C); b = t / v.C; }
+    else { c = (int)(i % v.C); const long t = i / v.C; r = (int)(t % v.R); b = t / v.R; }
+    const int b2 = (int)(b % v.B2), b1 = (int)(b / v.B2);
+    const long e = v.off + b1 * v.sB1 + b2 * v.sB2 + r * v.sR + c * v.sC;
+    const float gc = g[e] * cf;
+    float u;
+    if (L.factored) {
+      u = gc * rsqrtf(v_row[b * v.R + r] / rcm[b]) * rsqrtf(v_col[b * v.C + c]);
+    } else {
+      const long vi = (b * v.R + r) * v.C + c;
+      u = gc * rsqrtf(decay * vfull[vi] + (1.f - decay) * (gc * gc + eps));
+    }
+    acc += u * u;
+  }
+  const float s = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(usq + blockIdx.y, (double)s);
+}
+
 template <bool MOM_BF16>
 __global__ __launch_bounds__(256) void af_update_batched(float* __restrict__ p, const float* __restrict__ g,
                                                          void* __restrict__ mom, bf16* __restrict__ shadow,
                                                          const bv_af_leaf* __restrict__ leaves,
                                                          float* __restrict__ state, const double* gsq,
                                                          float clip_norm, float decay, float eps, float momentum,
-                                                         AfSched sched, double* __restrict__ stats) {
+                                                         AfSched sched, double* __restrict__ stats,
+                                                         float block_rms_clip, const double* __restrict__ usq) {
   __shared__ float sh[4];
   const bv_af_leaf L = leaves[blockIdx.y];
   const AfView v = af_view_of(L);
   const long B = (long)v.B1 * v.B2;
   const long total = B * v.R * v.C;
   if ((long)blockIdx.x * 256 >= total) return;          // (uniform per workgroup: the reductions below are safe)
+  // clip_by_block_rms: u / max(1, rms(u) / threshold), rms over the whole leaf (af_usq_batched)
+  const float bscale = block_rms_clip > 0.f
+                           ? 1.f / fmaxf(1.f, sqrtf((float)(usq[blockIdx.y] / (double)total)) / block_rms_clip) : 1.f;
   const float* v_row = state + L.soff;
   const float* v_col = v_row + B * v.R;
   const float* rcm = v_col + B * v.C;
@@ -255,6 +299,7 @@ __global__ __launch_bounds__(256) void af_update_batched(float* __restrict__ p, 
       vfull[vi] = nv;
       u = gc * rsqrtf(nv);
     }
+    u *= bscale;
     if (momentum > 0.f) {
       float m;
       if constexpr (MOM_BF16) m = (float)reinterpret_cast<bf16*>(mom)[e];
@@ -288,8 +333,10 @@ __global__ __launch_bounds__(256) void af_update_batched(float* __restrict__ p, 
 extern "C" int bv_adafactor_step(float* params, const float* grads, void* momentum, int mom_bf16, void* shadow_bf16,
                                  const bv_af_leaf* leaves, int nleaves, long max_rows, long max_cols, long max_b,
                                  long max_total, float* state, const double* gsq, float clip_norm, float decay,
-                                 float eps, float mom, const float* sched, int nsched, double* stats, void* stream) {
+                                 float eps, float mom, const float* sched, int nsched, double* stats,
+                                 float block_rms_clip, double* block_usq, void* stream) {
   BV_REQUIRE(nleaves > 0 && nleaves <= 65535 && leaves != nullptr, "bv_adafactor_step: bad leaf table (%d)", nleaves);
+  BV_REQUIRE(block_rms_clip <= 0.f || block_usq != nullptr, "bv_adafactor_step: clip_by_block_rms needs the usq scratch");
   BV_REQUIRE(nsched >= 1 && nsched <= BV_MAX_SCHED && sched != nullptr, "bv_adafactor_step: 1..%d schedule values", BV_MAX_SCHED);
   BV_REQUIRE(clip_norm <= 0.f || gsq != nullptr, "bv_adafactor_step: clipping needs gsq");
   BV_REQUIRE(max_total > 0, "bv_adafactor_step: empty model");
@@ -305,12 +352,19 @@ extern "C" int bv_adafactor_step(float* params, const float* grads, void* moment
   }
   long gsz = (max_total + 1023) / 1024;
   if (gsz > 1024) gsz = 1024;
+  if (block_rms_clip > 0.f) {
+    (void)hipMemsetAsync(block_usq, 0, sizeof(double) * (size_t)nleaves, s);
+    hipLaunchKernelGGL(af_usq_batched, dim3((unsigned)gsz, nleaves), dim3(256), 0, s, grads, leaves, (const float*)state, gsq,
+                       clip_norm, decay, eps, block_usq);
+  }
   if (mom_bf16)
     hipLaunchKernelGGL((af_update_batched<true>), dim3((unsigned)gsz, nleaves), dim3(256), 0, s, params, grads, momentum,
-                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats);
+                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats, block_rms_clip,
+                       (const double*)block_usq);
   else
     hipLaunchKernelGGL((af_update_batched<false>), dim3((unsigned)gsz, nleaves), dim3(256), 0, s, params, grads, momentum,
-                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats);
+                       (bf16*)shadow_bf16, leaves, state, gsq, clip_norm, decay, eps, mom, sc, stats, block_rms_clip,
+                       (const double*)block_usq);
   return bv_check_launch("bv_adafactor_step");
 }
 

@@ -577,12 +577,14 @@ def adafactor_leaf_(params, grads, momentum, shadow, view, state, factored, gsq,
 
 
 def adafactor_step_(params, grads, momentum, shadow, leaves, nleaves, max_rows, max_cols, max_b, max_total, state, gsq,
-                    clip_norm, decay, eps, mom, sched, stats):
+                    clip_norm, decay, eps, mom, sched, stats, block_rms_clip=0.0, block_usq=None):
   """The whole Adafactor step in four launches (bv_adafactor_step); leaves: device uint8 tensor holding the
-  bv_af_leaf table; sched: python list of this step's schedule values (<= 8)."""
+  bv_af_leaf table; sched: python list of this step's schedule values (<= 8).  block_rms_clip > 0 (with block_usq, a
+  float64 scratch of nleaves elements): optax.clip_by_block_rms per leaf (one more launch)."""
   import ctypes
   arr = (ctypes.c_float * len(sched))(*[float(v) for v in sched])
   _lib.call("bv_adafactor_step", _p(params), _p(grads), _p(momentum),
             int(momentum is not None and momentum.dtype == BF16), _p(shadow), _p(leaves), int(nleaves), int(max_rows),
             int(max_cols), int(max_b), int(max_total), _p(state), _p(gsq), float(clip_norm or 0.0), float(decay),
-            float(eps), float(mom), ctypes.cast(arr, ctypes.c_void_p), len(sched), _p(stats), _stream())
+            float(eps), float(mom), ctypes.cast(arr, ctypes.c_void_p), len(sched), _p(stats),
+            float(block_rms_clip or 0.0), _p(block_usq), _stream())

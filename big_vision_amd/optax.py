@@ -215,8 +215,9 @@ class Optimizer:
     self.af = dict(min_dim=int(okw.get("min_dim_size_to_factor", 32)), decay_rate=float(okw.get("decay_rate", 0.8)),
                    decay_offset=int(okw.get("decay_offset", 0)), beta2_cap=float(okw.get("beta2_cap", 0.999)),
                    momentum=float(okw.get("momentum", 0.9) or 0.0), eps=float(okw.get("eps", 1e-30)))
-    if okw.get("clipping_threshold"):
-      raise NotImplementedError("scale_by_adafactor(clipping_threshold=...) (clip_by_block_rms) is not implemented")
+    # scale_by_adafactor(clipping_threshold=...) = optax.clip_by_block_rms on every leaf between the factored RMS
+    # scaling and the momentum (optax.py:190,208): one more launch of the batched step
+    self.af["block_rms_clip"] = float(okw.get("clipping_threshold") or 0.0)
     mdt = okw.get("dtype_momentum", "bfloat16")
     mom_dtype = torch.float32 if str(mdt) in ("float32", "torch.float32") else torch.bfloat16
     self.af_leaves = []
@@ -353,7 +354,8 @@ class Optimizer:
     for c in self.af_classes:     # one call per size class of the leaf table (four launches each, three for unfactored)
       ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table[c["first"]:c["first"] + c["n"]], c["n"],
                           c["rows"], c["cols"], c["b"], c["total"], self.af_state, self.gsq, self.clip_norm, decay,
-                          af["eps"], af["momentum"], sched, self.stats)
+                          af["eps"], af["momentum"], sched, self.stats, block_rms_clip=af["block_rms_clip"],
+                          block_usq=self._af_usq(c["n"]) if af["block_rms_clip"] > 0 else None)
     if self.sharded:
       comm, n_tr = self.comm, st.trainable_count
       comm.all_reduce_scalars_(self.stats)
@@ -367,6 +369,13 @@ class Optimizer:
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),
             "l2_updates": torch.sqrt(self.stats[1])}
+
+  def _af_usq(self, n):
+    """Per-leaf sum-of-squares scratch of clip_by_block_rms (float64, the largest size class)."""
+    buf = getattr(self, "_af_usq_buf", None)
+    if buf is None or buf.numel() < n:
+      buf = self._af_usq_buf = torch.zeros(max(n, 1), device=self.store.device, dtype=torch.float64)
+    return buf
 
   def _gather_af_state(self):
     """"fsdp" placement, before the state is read as a whole (checkpoint): every rank's statistics and momentum of

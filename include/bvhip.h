@@ -436,7 +436,10 @@ typedef struct {
 int bv_adafactor_step(float* params, const float* grads, void* momentum, int mom_bf16, void* shadow_bf16,
                       const bv_af_leaf* leaves, int nleaves, long max_rows, long max_cols, long max_b, long max_total,
                       float* state, const double* gsq, float clip_norm, float decay, float eps, float mom,
-                      const float* sched /*host*/, int nsched, double* stats, void* stream);
+                      const float* sched /*host*/, int nsched, double* stats,
+                      float block_rms_clip /* scale_by_adafactor(clipping_threshold=...) = optax.clip_by_block_rms per leaf
+                                              (optax.py:190,208); <= 0: off */,
+                      double* block_usq /* device scratch [nleaves] when block_rms_clip > 0, else NULL */, void* stream);
 
 /* ------------------------------------------------------- Collectives (RCCL) ----
  * The exchange steps of the data-parallel step for hosts that do not go through torch.distributed (the

@@ -93,10 +93,14 @@ def test_oracle_first_steps_closed_form():
   assert abs((1 - 2 ** -0.8) - 0.42565) < 1e-4
 
 
-def test_unsupported_options_raise():
+def test_clipping_threshold_is_taken():
+  """scale_by_adafactor(clipping_threshold=...) (optax.py:190,208: optax.clip_by_block_rms per leaf) raised until round 5;
+  the batched step now applies it (GPU parity: tests/test_adafactor_gpu.py[...-clip])."""
   store = ParamStore([Entry("k", (64, 64), init_zeros)], "cpu")
-  with pytest.raises(NotImplementedError, match="clip_by_block_rms"):
-    bv_optax.make(_cfg(optax=dict(clipping_threshold=1.0)), store, sched_kw=dict(global_batch_size=1, total_steps=1))
+  opt, _ = bv_optax.make(_cfg(optax=dict(clipping_threshold=1.0)), store, sched_kw=dict(global_batch_size=1, total_steps=1))
+  assert opt.af["block_rms_clip"] == 1.0
+  opt0, _ = bv_optax.make(_cfg(), ParamStore([Entry("k", (64, 64), init_zeros)], "cpu"), sched_kw=dict(global_batch_size=1, total_steps=1))
+  assert opt0.af["block_rms_clip"] == 0.0
 
 
 def _af_store(scan_depth=0):

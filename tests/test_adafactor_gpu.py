@@ -11,8 +11,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("frozen", [False, True])
-def test_two_adafactor_steps_match_the_oracle(dev, frozen):
+@pytest.mark.parametrize("frozen,clip", [(False, None), (True, None), (False, 0.7)], ids=["all", "frozen_img", "all-clip"])
+def test_two_adafactor_steps_match_the_oracle(dev, frozen, clip):
   import bv_oracle as O
   from big_vision_amd import utils as u
   from big_vision_amd.compat.ml_collections import ConfigDict
@@ -24,6 +24,8 @@ def test_two_adafactor_steps_match_the_oracle(dev, frozen):
   c = ConfigDict()
   c.lr, c.wd, c.total_steps, c.grad_clip_norm = 1e-2, 1e-2, 10, 1.0
   c.optax_name = "big_vision.scale_by_adafactor"
+  if clip:   # scale_by_adafactor(clipping_threshold=...): clip_by_block_rms per leaf (u of a leaf has rms ~1: 0.7 clips most)
+    c.optax = dict(clipping_threshold=clip)
   sched = dict(decay_type="cosine", warmup_steps=2)
   c.schedule = [("img/.*", None), (".*", sched)] if frozen else sched
   c.lr_mults = [("txt/.*", 0.5), (".*", 1.0)]

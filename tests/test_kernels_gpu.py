@@ -821,3 +821,19 @@ def test_weight_images_follow_the_optimizer(dev):
       assert torch.equal(w._t[:, :w.bf.shape[0]], w.bf.t()), w.name
     seen.append(ws[0]._t.float().clone())
   assert not torch.equal(seen[0], seen[1]), "the optimizer did not move the weights: the test checks nothing"
+
+
+@pytest.mark.parametrize("n,L,D", [(3, 16, 128), (2, 64, 768), (5, 7, 36)])
+def test_pool_max_is_exact(dev, n, L, D):
+  """bv_pool_max_fwd / _bwd (text pool_type "max" / "gmp", text_transformer.py:89-90) vs torch: the maximum and its
+  position bit for bit, the backward = autograd of x.max(dim=1) (no ties in random floats)."""
+  from big_vision_amd import ops
+  x = rnd((n * L, D), dev, 71)
+  y, arg = ops.pool_max_fwd(x, n, L, D)
+  ref, idx = x.view(n, L, D).max(dim=1)
+  assert torch.equal(y, ref) and torch.equal(arg.long(), idx)
+  dy = rnd((n, D), dev, 72)
+  dx = ops.pool_max_bwd(dy, arg, n, L, D)
+  xr = x.clone().requires_grad_(True)
+  xr.view(n, L, D).max(dim=1).values.backward(dy)
+  assert torch.equal(dx, xr.grad)

@@ -48,7 +48,7 @@ def _cfg(total_steps=10, **kw):
 
 def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, config=None,
               tol_z=2e-2, tol_logit=0.25, frozen=(), floor=False, dirty_step=False, case=None, rel_max=None,
-              exceptions=None, text_model=None, pad_id=None):
+              exceptions=None, text_model=None, pad_id=None, cos_min=None, optimizer_check=True):
   """frozen: leaf-name prefixes config.schedule freezes (LiT).  floor: also measure the bf16-operand
   noise floor of the oracle for this case (tests/_parity.py; reported, not a bound).  exceptions:
   {leaf name: (rel_max, cos_min)} for tensors held to their own stated bound.
@@ -141,9 +141,15 @@ def _run_case(dev, image_cfg, text_cfg, E, n, res, seq, vocab, bias_init=-10.0, 
       ref["floor"] = _parity.bf16_floor(lambda p: O.siglip_step_loss(p, image.double(), text, **okw)[0], params64)
     fl = ref["floor"]
   kw_tol = {} if rel_max is None else {"rel_max": rel_max}
+  if cos_min is not None:
+    kw_tol["cos_min"] = cos_min
   gnorm, rows = _parity.compare_grads(case, gref, gours, frozen=frozen, floor=fl, exceptions=exceptions, **kw_tol)
   # l2_grads / clip norm cover the trainable leaves only (optax.py:105, siglip.py:316)
   assert abs(meas["l2_grads"].item() - gnorm) <= 2e-2 * gnorm, (meas["l2_grads"].item(), gnorm)
+  if not optimizer_check:
+    # (the fp64 optimizer oracle walks every parameter in Python: ~60 s of host time at 652 M parameters; the cases
+    # that skip it have a sibling of the same widths that runs it)
+    return rows
   # ---- optimizer: oracle chain on OUR grads must reproduce OUR new params -------
   opt = train_state["opt"]
   assert opt.mu.numel() == store.trainable_count == opt.nu.numel() == store.grad.numel()
@@ -192,7 +198,14 @@ def test_tiny_text_pooling_variants(dev, pool):
   "first" - against the fp64 oracle, the bounds of every other case."""
   image_cfg = dict(width=128, depth=1, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap")
   text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, pool_type=pool)
-  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=48, seq=16, vocab=100, floor=True)
+  # max pooling is not continuous: where two positions of a feature are closer than the bf16 rounding of the GEMM
+  # operands, the arg-max - and with it the whole cotangent of that feature - moves to another token.  The oracle
+  # ITSELF shows it: its gradients with bf16-rounded operands differ from its fp64 gradients by rel-L2 0.06-0.13
+  # (cosine 0.992-0.997) on this toy text tower (the "bf16 floor" printed next to each tensor; measured 0.124 / ours
+  # 0.107 on the worst tensor).  Forward, loss and the optimizer keep the default bounds; the gradient bound of the two
+  # max cases is the floor's order.  The kernels themselves are exact (test_kernels_gpu.py::test_pool_max_*).
+  kw = dict(rel_max=0.2, cos_min=0.98) if pool in ("max", "gmp") else {}
+  _run_case(dev, image_cfg, text_cfg, E=128, n=8, res=48, seq=16, vocab=100, floor=True, **kw)
 
 
 @pytest.mark.parametrize("which", ["tiny", "tiny_tok_lit", "b16", "b16_n32", "lit_b16"])
@@ -356,7 +369,10 @@ def test_l16_336_siglip_step_full_depth(dev):
   only claimed in a docstring; r3: un-gated, ~3 min of fp64 oracle inside the default GPU suite).  Default bounds."""
   image_cfg = dict(variant="L/16", pool_type="map")
   text_cfg = dict(variant="L")
-  _run_case(dev, image_cfg, text_cfg, E=1024, n=2, res=336, seq=64, vocab=32_000,
+  # optimizer_check=False: loss, logits and every gradient of the 48 blocks are what this case is for; the optimizer
+  # chain on these widths is checked by the depth-4 case above (profiles/r05_slowest_test_profile.txt: the Python
+  # optimizer oracle over 652 M fp64 parameters was 56 of this test's 146 s)
+  _run_case(dev, image_cfg, text_cfg, E=1024, n=2, res=336, seq=64, vocab=32_000, optimizer_check=False,
             case="siglip L/16@336 FULL depth (24 + 24 blocks) n=2")
 
 
