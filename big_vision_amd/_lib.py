@@ -100,8 +100,8 @@ RESTYPES = {"bv_gemm_workspace_bytes": c_long, "bv_ctx_create": P, "bv_ctx_destr
 
 # bv_ctx options / statistics (include/bvhip.h)
 OPTS = {"fast_path": 0, "gemm_nt": 1, "gemm_skew_mode": 2, "gemm_skew_pct": 3, "gemm_pre_issue": 4, "gemm_roll": 5,
-        "gemm_group_n": 6, "gemm_reserve_cus": 7, "attn_cfg": 8, "sgemm_mfma": 9, "gemm_pair": 10,
-        "gemm256_calls": 100, "gemm256_multi": 101, "gemm256_fused": 102, "gemm_pair_calls": 103}
+        "gemm_group_n": 6, "gemm_reserve_cus": 7, "attn_cfg": 8, "sgemm_mfma": 9,
+        "gemm256_calls": 100, "gemm256_multi": 101, "gemm256_fused": 102}
 
 EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)
 

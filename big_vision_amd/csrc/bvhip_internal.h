@@ -11,7 +11,7 @@ struct bv_ctx {
   long opt[BV_OPT_COUNT];
   void* ws;
   long ws_bytes;
-  mutable std::atomic<long> calls[4];
+  mutable std::atomic<long> calls[3];
 };
 const bv_ctx* bv_ctx_or_default(const bv_ctx* c);
 inline long bv_opt(const bv_ctx* c, int o) { return bv_ctx_or_default(c)->opt[o]; }

@@ -53,7 +53,7 @@ extern "C" void bv_ctx_destroy(bv_ctx* ctx) { delete ctx; }
 extern "C" long bv_ctx_get(const bv_ctx* ctx, int opt) {
   const bv_ctx* c = bv_ctx_or_default(ctx);
   if (opt >= 0 && opt < BV_OPT_COUNT) return c->opt[opt];
-  if (opt >= BV_STAT_GEMM256_CALLS && opt <= BV_STAT_GEMM_PAIR_CALLS)
+  if (opt >= BV_STAT_GEMM256_CALLS && opt <= BV_STAT_GEMM256_FUSED)
     return c->calls[opt - BV_STAT_GEMM256_CALLS].load(std::memory_order_relaxed);
   bv_set_error("bv_ctx_get: unknown option %d", opt);
   return BV_ERR_INVALID_ARG;

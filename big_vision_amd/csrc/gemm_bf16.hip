@@ -286,10 +286,6 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
                    void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                    const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,
                    float alpha, int split_k, float* colsum, void* stream, const bv_ctx* ctx);
-// gemm_pair.hip
-int bv_gemm_pair_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
-                     int out_f32, int M, int N, int K, int epilogue, const float* bias, const void* aux, long ldaux,
-                     int aux_rows, void* C2, float alpha, float* colsum, void* stream, const bv_ctx* ctx);
 
 // See include/bvhip.h for the contract.
 extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B,
@@ -334,10 +330,6 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
     BV_REQUIRE(epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_MUL,
                "bv_gemm_bf16_colsum: column sums are fused into the GELU_BWD / MUL epilogues only (got %d)", epilogue);
 
-  if (bv_opt(ctx, BV_OPT_FAST_PATH) && bv_opt(ctx, BV_OPT_GEMM_PAIR) &&
-      bv_gemm_pair_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K, epilogue, bias, aux, ldaux, aux_rows, C2,
-                       alpha, colsum, stream, ctx))
-    return bv_check_launch("bv_gemm_bf16(256x128 pair)");
   if (bv_opt(ctx, BV_OPT_FAST_PATH) &&
       bv_gemm256_try(a_kmajor, b_kmajor, A, lda, B, ldb, C, ldc, out_f32, M, N, K, epilogue, bias, aux, ldaux, aux_rows,
                      C2, alpha, split_k, colsum, stream, ctx))

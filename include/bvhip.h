@@ -76,11 +76,7 @@ void bv_ctx_destroy(bv_ctx* ctx);
                                       one-launch kernel reduces the bias gradients by DPP column sums */
 #define BV_OPT_SGEMM_MFMA 9        /* (1) bv_sgemm_strided on the fp32 matrix pipe wherever a 64 x 64 tile is filled;
                                       0 = always the VALU kernel (both are k-ordered fmaf chains: identical results) */
-#define BV_OPT_GEMM_PAIR 10        /* (0) round-5 experiment (gemm_pair.hip): bit e set = k-major GEMMs with epilogue e
-                                      (BV_EPI_*; M a multiple of 256, N of 128, K of 32) run as TWO independent 4-wave
-                                      workgroups per CU on 256x128 tiles, so that one workgroup's epilogue streams
-                                      while the other owns the matrix pipes.  Bit-identical results */
-#define BV_OPT_COUNT 11
+#define BV_OPT_COUNT 10
 /* Read-only statistics of a context (bv_ctx_get): launches bv_gemm_bf16[_colsum] put on the 256x256 kernels
  * through this context: all of them / those in which a persistent workgroup walks more than one tile / those of
  * the latter with a fused epilogue (anything but NONE / ATOMIC) or fused column sums.  The parity suite asserts
@@ -88,7 +84,6 @@ void bv_ctx_destroy(bv_ctx* ctx);
 #define BV_STAT_GEMM256_CALLS 100
 #define BV_STAT_GEMM256_MULTI 101
 #define BV_STAT_GEMM256_FUSED 102
-#define BV_STAT_GEMM_PAIR_CALLS 103 /* launches on the 256x128 two-workgroups-per-CU kernel (BV_OPT_GEMM_PAIR) */
 /* Sets an option and returns its previous value (>= 0); value < 0 only queries.  BV_ERR_INVALID_ARG for an
  * unknown option or a NULL context. */
 long bv_ctx_set(bv_ctx* ctx, int opt, long value);

@@ -384,82 +384,3 @@ def test_fused_epilogues_multi_tile_vs_fp64(dev, fast, M, N, K, reserve):
   finally:
     ctx_.set("gemm_reserve_cus", old)
 
-
-PAIR_ALL = sum(1 << e for e in (0, 1, 2, 3, 4, 6, 7, 8))   # every k-major epilogue (BV_OPT_GEMM_PAIR bit e = BV_EPI_* e)
-
-
-def _every_km_epilogue(ops, dev, M, N, K, seed=41):
-  """One launch of every k-major epilogue variant on an (M, N, K) problem; returns {name: tensor}."""
-  x = rnd((M, K), dev, seed, dtype=BF16)
-  w = rnd((N, K), dev, seed + 1, 1.0 / K ** 0.5, dtype=BF16)
-  b = rnd((N,), dev, seed + 2)
-  res = rnd((M, N), dev, seed + 3, 2.0)
-  resb = rnd((M, N), dev, seed + 4, 2.0, dtype=BF16)
-  hh = rnd((M, N), dev, seed + 5, dtype=BF16)
-  pos = rnd((196, N), dev, seed + 6)
-  kw = dict(a_kmajor=True, b_kmajor=True)
-  out = {}
-  out["bias bf16"] = ops.gemm(x, w, bias=b, out_dtype=BF16, **kw)
-  out["bias f32"] = ops.gemm(x, w, bias=b, out_dtype=F32, **kw)
-  out["alpha bf16"] = ops.gemm(x, w, out_dtype=BF16, alpha=0.5, **kw)
-  out["+residual f32"] = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
-  out["+residual bf16"] = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_RESIDUAL, aux=resb, **kw)
-  out["+posemb"] = ops.gemm(x, w, bias=b, out_dtype=F32, epilogue=ops.EPI_POS, aux=pos, aux_rows=196, **kw)
-  g = torch.empty((M, N), device=dev, dtype=BF16)
-  out["gelu h"] = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g, **kw)
-  out["gelu g"] = g
-  d = torch.empty((M, N), device=dev, dtype=BF16)
-  out["gelu_gd g"] = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU_GD, out2=d, **kw)
-  out["gelu_gd d"] = d
-  cs = torch.zeros((N,), device=dev)
-  out["gelu' dh"] = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD, aux=hh, colsum=cs, **kw)
-  out["gelu' colsum"] = cs
-  g2 = torch.empty((M, N), device=dev, dtype=BF16)
-  cs2 = torch.zeros((N,), device=dev)
-  out["gelu'-emit dh"] = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_GELU_BWD_EMIT, aux=hh, out2=g2, colsum=cs2, **kw)
-  out["gelu'-emit g"] = g2
-  out["gelu'-emit colsum"] = cs2
-  cs3 = torch.zeros((N,), device=dev)
-  out["mul dh"] = ops.gemm(x, w, out_dtype=BF16, epilogue=ops.EPI_MUL, aux=hh, colsum=cs3, **kw)
-  out["mul colsum"] = cs3
-  return out
-
-
-@pytest.mark.parametrize("M,N,K", [(512, 256, 64), (2304, 768, 768), (12544, 3072, 768), (12544, 768, 3072), (66816, 768, 96 * 2)])
-def test_pair_kernel_is_bit_identical_to_gemm256(dev, fast, M, N, K):
-  """gemm_pair.hip (round 5: two independent 4-wave workgroups per CU on 256x128 tiles, K-tiles of 32, behind
-  BV_OPT_GEMM_PAIR) against the 256x256 kernels on the SAME launches: same fragment maps, same k order per
-  accumulator, same epilogue arithmetic -> every output bit agrees for every epilogue (the fused column sums are fp32
-  atomics: summation order).  12544 x 3072: 4704 tiles, every persistent workgroup walks 9-10; K = 64 / 192: the
-  two- and six-K-tile streams across tile boundaries; run-to-run bit-equality as the race screen."""
-  from big_vision_amd import ops
-  # (gemm_roll = 0: the default routes the fp32 +residual epilogue to the rolling kernel, which sums the residual
-  # FIRST - loaded into the accumulators - instead of last: same value to rounding order, not the same bits)
-  with ops.option("gemm_pair", 0), ops.option("gemm_roll", 0):
-    ref = _every_km_epilogue(ops, dev, M, N, K)
-  calls0 = ops.ctx_get("gemm_pair_calls")
-  with ops.option("gemm_pair", PAIR_ALL):
-    got = _every_km_epilogue(ops, dev, M, N, K)
-    again = _every_km_epilogue(ops, dev, M, N, K)
-  assert ops.ctx_get("gemm_pair_calls") == calls0 + 2 * 11, "not every launch ran on the pair kernel"
-  for name, r in ref.items():
-    if "colsum" in name:
-      close(got[name], r, 1e-4, 2e-3 * r.abs().max().item(), name)
-    else:
-      assert not torch.isnan(got[name].float()).any(), name
-      assert torch.equal(got[name], r), f"{name}: the pair kernel differs from gemm256 ({(got[name].float() - r.float()).abs().max().item():.3e})"
-      assert torch.equal(got[name], again[name]), f"{name}: run-to-run difference"
-
-
-def test_pair_kernel_takes_odd_multiples_of_128_columns(dev, fast):
-  """N = 384 (a multiple of 128 but not of 256: gemm256 leaves it to the general kernel) vs fp64."""
-  from big_vision_amd import ops
-  M, N, K = 1024, 384, 160
-  x = rnd((M, K), dev, 61, dtype=BF16)
-  w = rnd((N, K), dev, 62, 1.0 / K ** 0.5, dtype=BF16)
-  b = rnd((N,), dev, 63)
-  calls0 = ops.ctx_get("gemm_pair_calls")
-  with ops.option("gemm_pair", PAIR_ALL):
-    y = ops.gemm(x, w, bias=b, out_dtype=F32, a_kmajor=True, b_kmajor=True)
-  assert ops.ctx_get("gemm_pair_calls") == calls0 + 1
-  close(y, x.double() @ w.double().T + b.double(), 1e-4, 2e-3, "pair kernel N = 384")

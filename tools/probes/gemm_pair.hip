@@ -1,6 +1,11 @@
 // 256x128x32 bf16 MFMA GEMM for gfx950 (MI355X), k-major operands, TWO co-resident workgroups per CU.
-// Round-5 experiment behind BV_OPT_GEMM_PAIR (include/bvhip.h); reference call sites as gemm256.hip
-// (big_vision/models/vit.py:72,77,93-98 and their backward transposes).
+// Round-5 experiment (VERDICT r4 "next" #2), a measured NEGATIVE: 0.67-0.85x of gemm256 on every step shape and epilogue
+// (profiles/r05_gemm_pair_ab.txt), because the kernel is bound by the CU's global->LDS fill path, which a half-size tile
+// loads 1.5x harder (profiles/r05_gemm_pair_probe.txt, profiles/NOTES_r05.md).  It ran inside libbvhip behind a context
+// option for its parity run - every epilogue bit-identical to gemm256 (profiles/r05_pair_kernel_parity.txt) - and left
+// the library afterwards (the per-epilogue A/B and the parity run are reproducible at commit 1890027, where the kernel sat
+// behind BV_OPT_GEMM_PAIR with tools/gemm_pair_ab.py): this file is included by tools/probes/gemm_pair_probe.hip only.
+// Reference call sites as gemm256.hip (big_vision/models/vit.py:72,77,93-98 and their backward transposes).
 //
 // Why.  gemm256.hip fills a CU with ONE 8-wave workgroup (160 KiB of LDS, 256x256 tile): at every tile boundary all
 // eight waves convert and store their accumulators and the CU's matrix pipes idle - for the fused epilogues of the MLP
@@ -24,9 +29,9 @@
 //             consecutive output columns per fragment pair); the DMA writes lane-linearly, so the swizzle is applied
 //             to the per-lane global source address
 //   results   bit-identical to gemm256.hip: same fragment maps, same k order per accumulator, same epilogue arithmetic
-//             (tests/test_gemm256_gpu.py::test_pair_kernel_*)
-#include "bv_common.h"
-#include "bvhip_internal.h"
+//             (profiles/r05_pair_kernel_parity.txt)
+#include "../../big_vision_amd/csrc/bv_common.h"
+#include "../../big_vision_amd/csrc/bvhip_internal.h"
 
 namespace {
 
@@ -415,14 +420,13 @@ void launch_pair(const PairParams& p, int grid, hipStream_t s) {
 
 }  // namespace
 
-// Internal entry used by bv_gemm_bf16_colsum (gemm_bf16.hip) in front of the 256x256 path.  Returns 1 if the problem
-// was launched here: both operands k-major, M a multiple of 256, N of 128, K of 32 and >= 64, and the epilogue's bit
-// set in BV_OPT_GEMM_PAIR of the caller's context.
+// Dispatcher (was called by bv_gemm_bf16_colsum in front of the 256x256 path during the parity run).  Returns 1 if the
+// problem was launched here: both operands k-major, M a multiple of 256, N of 128, K of 32 and >= 64, and the
+// epilogue's bit set in `mask`.
 int bv_gemm_pair_try(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                      int out_f32, int M, int N, int K, int epilogue, const float* bias, const void* aux, long ldaux,
-                     int aux_rows, void* C2, float alpha, float* colsum, void* stream, const bv_ctx* ctx_) {
+                     int aux_rows, void* C2, float alpha, float* colsum, void* stream, const bv_ctx* ctx_, long mask) {
   const bv_ctx* ctx = bv_ctx_or_default(ctx_);
-  const long mask = ctx->opt[BV_OPT_GEMM_PAIR];
   if (!a_kmajor || !b_kmajor || epilogue == BV_EPI_ATOMIC || !((mask >> epilogue) & 1)) return 0;
   if ((M & 255) || (N & 127) || (K & 31) || K < 64) return 0;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return 0;
@@ -451,11 +455,5 @@ int bv_gemm_pair_try(int a_kmajor, int b_kmajor, const void* A, long lda, const 
   else if (epilogue == BV_EPI_MUL) launch_pair<BV_EPI_MUL, false>(p, grid, s);
   else if (out_f32) launch_pair<BV_EPI_NONE, true>(p, grid, s);
   else launch_pair<BV_EPI_NONE, false>(p, grid, s);
-  ctx->calls[3].fetch_add(1, std::memory_order_relaxed);
-  ctx->calls[0].fetch_add(1, std::memory_order_relaxed);
-  if (p.ntiles > grid) {
-    ctx->calls[1].fetch_add(1, std::memory_order_relaxed);
-    if (epilogue != BV_EPI_NONE || colsum) ctx->calls[2].fetch_add(1, std::memory_order_relaxed);
-  }
   return 1;
 }

@@ -10,7 +10,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../big_vision_amd/csrc/gemm256.hip"
-#include "../../big_vision_amd/csrc/gemm_pair.hip"
+#include "gemm_pair.hip"
 #include "probe_ctx.h"
 
 __global__ void fill_bf16(unsigned short* d, size_t n, unsigned seed, float scale) {
