@@ -103,6 +103,53 @@ def pmc_traffic(world, micro):
     return None, None
 
 
+def live_pmc_traffic(micro, timeout_s=240):
+  """HBM bytes per launch of the dominant kernel family measured IN THIS RUN: two short rocprofv3 passes of this very
+  command (`--steps 1 --warmup 0`, everything optional switched off) as child processes on the same GPU, one per
+  counter - FETCH_SIZE and WRITE_SIZE in SEPARATE passes with --kernel-trace only, as MI355X_MICROARCH.md (HBM /
+  rocprofv3 section) prescribes - corrected as tools/pmc_summary.py does (FETCH_SIZE x 2 on gfx950).  Called after the
+  timed region with this process's HBM released.  Returns (bytes per launch | None, detail dict)."""
+  import glob
+  import shutil
+  import subprocess
+  import tempfile
+  rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+  if not os.path.exists(rocprof):
+    return None, {"error": "rocprofv3 not found"}
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import pmc_summary
+  tot = {}
+  t_all = time.perf_counter()
+  for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    out = tempfile.mkdtemp(prefix=f"bv_pmc_{counter.lower()}_", dir="/tmp")
+    cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--microbatch", str(micro), "--no-roofline",
+           "--no-cpu-baseline", "--no-bf16-stream", "--no-configs", "--no-live-pmc"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    try:
+      pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+      shutil.rmtree(out, ignore_errors=True)
+      return None, {"error": f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"}
+    files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+    if pr.returncode != 0 or not files:
+      shutil.rmtree(out, ignore_errors=True)
+      return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {pr.returncode}): {pr.stderr[-300:]}"}
+    t, c, _ = pmc_summary.load(files[0])
+    fam = [(k, t[k], c[k]) for k in t if k.startswith("gemm256_kernel<true") or k.startswith("gemm256r_kernel")]
+    tot[counter] = (sum(x[1] for x in fam), sum(x[2] for x in fam))
+    shutil.rmtree(out, ignore_errors=True)
+  (fk, fn), (wk, wn) = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
+  if not fn or not wn:
+    return None, {"error": "no launches of the dominant kernel in the counter files"}
+  rd, wr = fk * 1024 * 2 / fn, wk * 1024 / wn
+  return rd + wr, {"read_bytes": rd, "write_bytes": wr, "launches_per_step": fn, "passes_s": round(time.perf_counter() - t_all, 1),
+                   "command": "rocprofv3 --pmc {FETCH_SIZE | WRITE_SIZE} --kernel-trace -- python bench.py --steps 1 --warmup 0 "
+                              "--no-roofline --no-cpu-baseline --no-bf16-stream --no-configs (one child process per counter)",
+                   "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE KiB x 1024"}
+
+
 # Activations between the encoder blocks (config.residual_stream).  `value` is measured on "float32": the
 # reference's arithmetic (models/vit.py:92-110 keeps the residual stream in fp32 even with dtype_mm=bfloat16,
 # only matmul inputs are cast; SURVEY 7).  "bfloat16" (LayerNorm inputs, the +residual GEMM epilogues, the
@@ -461,6 +508,8 @@ def main():
                   help="skip the second (bf16 residual stream) measurement that N = 1 appends as `bf16_stream`")
   ap.add_argument("--no-configs", action="store_true",
                   help="skip the `configs` object (the other BASELINE workloads and rank shapes, N = 1 only)")
+  ap.add_argument("--no-live-pmc", action="store_true",
+                  help="do not measure roofline.traffic with two rocprofv3 --pmc child passes (N = 1); the committed profile is used")
   ap.add_argument("--configs-steps", type=int, default=3)
   ap.add_argument("--cpu-sample", type=int, default=16)
   ap.add_argument("--microbatch", type=int, default=MICRO, help="pairs per micro-batch and rank")
@@ -597,11 +646,27 @@ def main():
     launches, ms, flops, nbytes = obs.summary()
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     traffic, traffic_src = pmc_traffic(world, args.microbatch)
+    traffic_live, traffic_detail = False, None
+    if world == 1 and not args.no_live_pmc and args.global_batch == GLOBAL_BATCH:
+      # counters cannot be read in-process: two child rocprofv3 passes of this command, now, on this GPU (the HBM
+      # of this process is released first: the child needs all of it)
+      import gc
+      batch.clear()
+      image = text = None   # the synthetic batch (2.5 GB): every later object builds its own inputs
+      gc.collect()
+      torch.cuda.empty_cache()
+      try:
+        live, traffic_detail = live_pmc_traffic(args.microbatch)
+      except Exception as e:   # the headline must not depend on the profiler
+        live, traffic_detail = None, {"error": f"{type(e).__name__}: {e}"[:300]}
+      if live is not None:
+        traffic, traffic_src, traffic_live = live, "rocprofv3 --pmc child passes of this run", True
     line["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach,
                         "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src, "traffic_measured_in_this_run": False,
+                        "traffic_source": traffic_src, "traffic_measured_in_this_run": traffic_live,
+                        "traffic_detail": traffic_detail,
                         # whole step, PER GPU: algorithmic matmul FLOPs of the workload (forward + backward of the
                         # kept contexts; the recompute FLOPs of re-run micro-batches are NOT counted) / wall time /
                         # (world x one GPU's peak)
