@@ -41,14 +41,15 @@ def _rel(a, b):
   return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize("T", [T_IMG, T_TXT], ids=["image-401408", "text-131072"])
 @pytest.mark.parametrize("name", ["qkv bias", "out-proj +residual f32", "fc1 gelu (2 outputs)", "fc2 +residual f32",
                                   "fc2 dX gelu'-emit + colsum", "fc2 dX mul + colsum", "fc1 dX plain"])
-def test_kmajor_gemms_of_a_2048_pair_microbatch(dev, name):
-  """Every k-major GEMM variant of the step at T = 401 408 rows: the monolithic launch (1568 row tiles, 6-18 rounds of
-  the persistent grid) vs 8 launches of 50 176 rows - bit-identical outputs, fused column sums to fp32 accumulation
-  order - and 384 random rows against fp64."""
+def test_kmajor_gemms_of_a_2048_pair_microbatch(dev, name, T):
+  """Every k-major GEMM variant of the step at T = 401 408 image-token rows (1568 row tiles, 6-18 rounds of the
+  persistent grid) and at the text tower's 131 072 rows (1.5-6 rounds: the ragged last round): the monolithic launch vs
+  8 launches on its row ranges - bit-identical outputs, fused column sums to fp32 accumulation order - and 384 random
+  rows against fp64."""
   from big_vision_amd import ops
-  T = T_IMG
   N, K = {"qkv bias": (3 * D, D), "out-proj +residual f32": (D, D), "fc1 gelu (2 outputs)": (MLP, D),
           "fc2 +residual f32": (D, MLP), "fc2 dX gelu'-emit + colsum": (MLP, D), "fc2 dX mul + colsum": (MLP, D),
           "fc1 dX plain": (D, MLP)}[name]
@@ -116,11 +117,13 @@ def test_kmajor_gemms_of_a_2048_pair_microbatch(dev, name):
   assert err <= tol * max(1.0, ref.abs().max().item()), f"{name}: sampled rows vs fp64: {err:.3e}"
 
 
-@pytest.mark.parametrize("L,n", [(196, 2048), (64, 2048)])
-def test_attention_of_a_2048_pair_microbatch(dev, L, n):
+@pytest.mark.parametrize("L,n,H", [(196, 2048, 12), (64, 2048, 12), (441, 512, 16)],
+                         ids=["B16-image-196", "text-64", "L16-336-image-441"])
+def test_attention_of_a_2048_pair_microbatch(dev, L, n, H):
   """The attention forward and the one-launch backward at the micro-batch of the headline (24 576 (sample, head) pairs,
   every persistent workgroup of attention5.hip walks ~96): full launch vs 8 launches of 256 samples - bit-identical o, lse,
-  dqkv; per-sample bias-gradient rows too - and 3 random samples against fp64."""
+  dqkv - and 3 random samples against fp64.  L = 441, 16 heads: BASELINE configs[3] (L/16 at 336 px, two micro-batches of
+  the 1024-pair rank shape), the long-sequence forward and the two-launch backward of attention3.hip."""
   from big_vision_amd import ops
   qkv = _rnd((n * L, 3 * H * 64), dev, 11, 1.2, dtype=BF16)
   d_o = _rnd((n * L, H * 64), dev, 12, dtype=BF16)
@@ -244,7 +247,7 @@ def test_global_sigmoid_loss_at_batch_4096_in_eight_rank_blocks(dev):
     dzt8 += part
   assert abs(stats8[0].item() - stats1[0].item()) <= 1e-9 * abs(stats1[0].item()), "loss: 8 row blocks vs one shot"
   assert torch.equal(dzi8, dzi1), "dzimg rows do not depend on the row block they are computed in"
-  assert _rel(dzt8, dzt1) <= 1e-6 and _rel(stats8[1:], stats1[1:]) <= 1e-9
+  assert _rel(dzt8, dzt1) <= 5e-6 and _rel(stats8[1:], stats1[1:]) <= 1e-9      # (fp32 sums over 8 partials vs one k-ordered chain)
   # fp64 autograd of the reference's expression
   zi64, zt64 = zi.double().requires_grad_(True), zt.double().requires_grad_(True)
   t64, b64 = tp.double().requires_grad_(True), b.double().requires_grad_(True)
@@ -275,7 +278,7 @@ def test_adam_on_all_203m_parameters_in_slices(dev):
   assert n_tr > 200e6 and n_tr % 1024 == 0
   st.ensure_grad().copy_(_rnd((n_tr,), dev, 51, 1e-3))
   p0, sh0 = st.master.clone(), st.shadow.clone()
-  k = opt.count
+  k = 5000          # past the warm-up (the schedule is 0 at step 0: nothing would move)
   sched = [fn(k) for fn in opt.schedule_fns]
   gsq = torch.zeros(1, device=dev, dtype=F64)
   ops.sqnorm_(st.grad, gsq)
@@ -294,19 +297,21 @@ def test_adam_on_all_203m_parameters_in_slices(dev):
   for a, b_, nm in zip(full[:4], parts[:4], ("parameters", "mu", "nu", "bf16 shadow")):
     assert torch.equal(a[:n_tr], b_[:n_tr]), f"{nm}: the whole-buffer launch differs from the slices"
   assert _rel(full[4], parts[4]) <= 1e-12
-  # sampled elements against the chain in fp64 (first step: mu_hat = g, nu_hat = g^2 -> u = g / (|g| + eps)); lr
-  # multipliers, weight decay and schedules differ per segment, so the check is the direction and the magnitude bound:
-  # every element moves against its clipped gradient by at most sched * (lr + wd |p|)
+  # sampled elements against the chain in fp64 (moments start at 0: mu = (1 - b1) g, nu = (1 - b2) g^2, bias-corrected
+  # for step k); lr multipliers, weight decay and schedules differ per segment, so the check is the direction and the
+  # magnitude bound: every element moves against its clipped gradient by at most sched * (lr |u| + wd |p|)
   idx = torch.randint(0, n_tr, (200_000,), device=dev, generator=torch.Generator(device=dev).manual_seed(59))
   g = st.grad[idx].double()
   if opt.clip_norm:
     g = g * min(1.0, opt.clip_norm / math.sqrt(gsq.item()))
-  u = g / (g.abs() + opt.eps)
+  u = ((1 - opt.b1) * g / bc[0]) / (torch.sqrt((1 - opt.b2) * g * g / bc[1]) + opt.eps)
   moved = full[0][idx].double() - p0[idx].double()
-  big = u.abs() > 0.5
+  assert max(sched) > 0 and moved.abs().max().item() > 0
+  big = u.abs() > 0.5 * u.abs().max()
   assert (torch.sign(moved[big]) == -torch.sign(u[big])).double().mean().item() >= 0.999
-  bound = max(sched) * (float(config.lr) + float(config.wd) * p0[idx].abs().max().item())
+  bound = max(sched) * (float(config.lr) * u.abs().max().item() + float(config.wd) * p0[idx].abs().max().item())
   assert moved.abs().max().item() <= 1.001 * bound + 1e-12, (moved.abs().max().item(), bound)
+  assert _rel(full[1][idx], (1 - opt.b1) * g) <= 1e-6 and _rel(full[2][idx], (1 - opt.b2) * g * g) <= 1e-6, "moments vs fp64"
 
 
 def test_training_step_at_the_rank_shape_is_microbatch_invariant(dev):
