@@ -49,7 +49,7 @@ IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 DOMINANT = (("bv_gemm_bf16", "bv_gemm_bf16_colsum"), 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
-PMC_PROFILE = "r04_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
+PMC_PROFILE = "r05_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
 DOMINANT_KERNEL = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
 
 
@@ -90,7 +90,7 @@ class GemmObserver:
 
 def pmc_traffic(world, micro):
   """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
-  THIS command (profiles/r04_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
+  THIS command (profiles/r05_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
   be read from inside the process).  None when the profile does not match the configuration."""
   path = os.path.join(ROOT, "profiles", PMC_PROFILE)
   try:
@@ -159,7 +159,7 @@ def live_pmc_traffic(micro, timeout_s=240):
 # -m gpu step tests measured for that mode), never as `value`.
 RESIDUAL_STREAM = "float32"
 # the -m gpu case that runs exactly the bf16 object's mode: B/16 + text-B through micro-batches with gelu(h)-free contexts
-BF16_STREAM_PARITY = ("profiles/r04_parity_report.jsonl", "siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, bfloat16 stream")
+BF16_STREAM_PARITY = ("profiles/r05_parity_report.jsonl", "siglip B/16 n=32 microbatch=8 gelu(h)-free contexts, bfloat16 stream")
 
 
 # siglip.make_update_fn's state_cache["light"] -> what a kept micro-batch context holds
