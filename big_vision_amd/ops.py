@@ -50,6 +50,11 @@ class Context:
     if not self.ptr:
       raise RuntimeError("bv_ctx_create failed")
     self._ws = None
+    import os
+    if os.environ.get("BV_CTX_OPTS"):        # A/B runs of whole programs: "gemm_nt=1,gemm_group_n=4" applied to every new context
+      for kv in os.environ["BV_CTX_OPTS"].split(","):
+        k, v = kv.split("=")
+        self.set(k.strip(), int(v))
     self.use_workspace = True   # False: weight-gradient GEMMs combine their split-K partials with fp32 atomics (A/B)
 
   def __del__(self):
