@@ -1,5 +1,5 @@
 // Fused self-attention forward / backward for gfx950, Dh = 64, L <= 576: third generation of the
-// LDS-resident kernels.  Same mathematics and reference call sites as attention2.hip
+// LDS-resident kernels.  Same mathematics and reference call sites as its predecessor attention2.hip (rounds 2-4, git history)
 // (flax nn.MultiHeadDotProductAttention inside big_vision/models/vit.py:93-98, text tower via
 // vit.Encoder, models/proj/image_text/text_transformer.py:72-75; backward = jax.value_and_grad,
 // trainers/proj/image_text/siglip.py:311):
@@ -938,7 +938,7 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
   }
   int rc = bv_check_launch("bv_attn_bwd(dq)");
   if (rc) return rc;
-  if (g_a4_dkv && KF >= 13) {   // 32-key blocks (A/B: bv_attn_tune bits 32 = 4 waves x 2 workgroups, 64 = 7 waves x 1)
+  if (g_a4_dkv && KF >= 13) {   // 32-key blocks (A/B: BV_OPT_ATTN_CFG bits 32 = 4 waves x 2 workgroups, 64 = 7 waves x 1)
     if (g_a4_dkv == 2) {
       const size_t sh = (size_t)KF * 4096 + (size_t)KF * 16 * 8 + (size_t)7 * 128 * 4;
       set_lds(attn4_bwd_dkv_kernel<KF, 7>, sh);
@@ -974,7 +974,7 @@ int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n,
   const A3Cfg cfg = a3cfg(ctx);
   if (L <= 64) return launch_fwd3<4, 4, 4>(qkv, o, lse, kv_len, n, L, H, s);
   // 13 key fragments: 4 waves per workgroup and 3 workgroups per CU (the third one computes while
-  // another stages its K/V: 605-650 us instead of 670-730 at n = 2048); 8 waves x 2 under bv_attn_tune(8)
+  // another stages its K/V: 605-650 us instead of 670-730 at n = 2048); 8 waves x 2 under BV_OPT_ATTN_CFG = 8
   if (L <= 208 && cfg.fwd8) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 208) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);

@@ -1,4 +1,4 @@
-// Shared device helpers of the LDS-resident attention kernels (attention2.hip, attention3.hip):
+// Shared device helpers of the LDS-resident attention kernels (attention3.hip, attention5.hip; attention2.hip of rounds 2-4 left the library in round 5):
 // the "T64" tile image, fragment loads and the small cross-lane reductions.  gfx950 only.
 #pragma once
 #include "bv_common.h"

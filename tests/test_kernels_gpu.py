@@ -329,7 +329,7 @@ def test_attention_key_padding_mask(dev, n, L, H):
 def test_attention_delta_is_exact_for_near_uniform_rows(dev):
   """Repeated keys / tiny logits (random init, sticky-EOS padding): dP - delta cancels to a fraction
   of delta.  attention3 computes delta = rowsum(P o dP) in fp32; rowsum(dO o O) with the bf16 O
-  (attention2) loses the q / k gradients there.  Measured against fp64 on the same bf16 inputs."""
+  (the round-2 kernels, attention2.hip) loses the q / k gradients there.  Measured against fp64 on the same bf16 inputs."""
   from big_vision_amd import ops, _lib
   n, L, H = 2, 64, 2
   base = rnd((n, 1, 3 * H * 64), dev, 9, 1.0)

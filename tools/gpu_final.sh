@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end measurement set (round 4), in parts so that a GPU call stays short:
+# Round-end measurement set (rounds 4-5), in parts so that a GPU call stays short:
 #   bash tools/gpu_final.sh prof     rocprofv3 kernel stats of the bench command (N = 1) and of the n = 512 rank shape, the two
 #                                    --pmc passes (FETCH_SIZE / WRITE_SIZE, counters only - never combined with tracing domains)
 #   bash tools/gpu_final.sh bench    the default bench line (headline + bf16 stream + configs + CPU baseline), the rank shapes
@@ -21,14 +21,17 @@ if [[ " $* " == *" bench "* ]]; then
   timeout 300 python bench.py --global-batch 512 --steps 10 --warmup 3 --no-cpu-baseline --no-bf16-stream > $O/bench_n512.json 2> $O/bench_n512.err; cut -c1-300 $O/bench_n512.json
 fi
 if [[ " $* " == *" prof "* ]]; then
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-stream --no-configs > $O/bench_line_profiled.json 2> $O/stats.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bf16-stream --no-configs --no-live-pmc > $O/bench_line_profiled.json 2> $O/stats.err
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats512 -- python bench.py --global-batch 512 --steps 4 --warmup 2 --no-cpu-baseline --no-bf16-stream --no-roofline > $O/bench_n512_profiled.json 2> $O/stats512.err
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-bf16-stream --no-configs > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-bf16-stream --no-configs > $O/pmc_write.json 2> $O/pmc_write.err
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-bf16-stream --no-configs --no-live-pmc > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-bf16-stream --no-configs --no-live-pmc > $O/pmc_write.json 2> $O/pmc_write.err
   find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
   find $O/stats512 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_n512.csv
   F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1)
   python tools/pmc_summary.py $F $W --microbatch=2048 --n_gpus=1 > $O/pmc_traffic.json 2> $O/pmc_summary.err
+  # MFMA busy / wave cycles / LDS conflicts / waits per kernel (one pass, counters only)
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python bench.py --steps 1 --warmup 0 --no-roofline --no-cpu-baseline --no-bf16-stream --no-configs --no-live-pmc > /dev/null 2> $O/pmc_sq.err
+  python tools/pmc_sq_summary.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq.json 2>> $O/pmc_summary.err
   find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
   head -30 $O/kernel_stats.csv | cut -c1-150
 fi
