@@ -124,7 +124,7 @@ def load():
     fn = getattr(lib, name)  # AttributeError if the ABI drifted
     fn.restype = RESTYPES.get(name, c_int)
     fn.argtypes = argtypes
-  if lib.bv_version() != 1:
+  if lib.bv_version() != 2:
     raise RuntimeError("libbvhip.so ABI version mismatch")
   _lib = lib
   return lib

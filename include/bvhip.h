@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define BVHIP_VERSION 1
+/* 2 (round 5): the GEMM / attention / fp32-GEMM entry points take a trailing `const bv_ctx*`, the process-global option
+ * setters and the workspace registry are gone, bv_adafactor_step gained block_rms_clip / block_usq. */
+#define BVHIP_VERSION 2
 
 /* error codes */
 #define BV_OK 0

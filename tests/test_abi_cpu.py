@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_python_prototypes_cover_the_header(lib):
   from big_vision_amd import _lib
   assert sorted(list(_lib.PROTOTYPES) + ["bv_last_error"]) == _header_symbols()
-  assert lib.bv_version() == 1
+  assert lib.bv_version() == 2
 
 
 def test_library_keeps_no_process_global_state(lib):
