@@ -103,6 +103,16 @@ def pmc_traffic(world, micro):
     return None, None
 
 
+def pmc_family_totals(csv_path):
+  """(sum of Counter_Value in KiB, number of launches) over the dominant kernel family in one rocprofv3
+  counter_collection.csv (one counter per file)."""
+  sys.path.insert(0, os.path.join(ROOT, "tools"))
+  import pmc_summary
+  t, c, _ = pmc_summary.load(csv_path)
+  fam = [k for k in t if k.startswith("gemm256_kernel<true") or k.startswith("gemm256r_kernel")]
+  return sum(t[k] for k in fam), sum(c[k] for k in fam)
+
+
 def live_pmc_traffic(micro, timeout_s=240):
   """HBM bytes per launch of the dominant kernel family measured IN THIS RUN: two short rocprofv3 passes of this very
   command (`--steps 1 --warmup 0`, everything optional switched off) as child processes on the same GPU, one per
@@ -116,8 +126,6 @@ def live_pmc_traffic(micro, timeout_s=240):
   rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
   if not os.path.exists(rocprof):
     return None, {"error": "rocprofv3 not found"}
-  sys.path.insert(0, os.path.join(ROOT, "tools"))
-  import pmc_summary
   tot = {}
   t_all = time.perf_counter()
   for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -136,9 +144,7 @@ def live_pmc_traffic(micro, timeout_s=240):
     if pr.returncode != 0 or not files:
       shutil.rmtree(out, ignore_errors=True)
       return None, {"error": f"rocprofv3 --pmc {counter} pass failed (rc {pr.returncode}): {pr.stderr[-300:]}"}
-    t, c, _ = pmc_summary.load(files[0])
-    fam = [(k, t[k], c[k]) for k in t if k.startswith("gemm256_kernel<true") or k.startswith("gemm256r_kernel")]
-    tot[counter] = (sum(x[1] for x in fam), sum(x[2] for x in fam))
+    tot[counter] = pmc_family_totals(files[0])
     shutil.rmtree(out, ignore_errors=True)
   (fk, fn), (wk, wn) = tot["FETCH_SIZE"], tot["WRITE_SIZE"]
   if not fn or not wn:

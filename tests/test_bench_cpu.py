@@ -61,3 +61,22 @@ def test_config_matches_the_baseline_workload():
   assert c.optax_name == "scale_by_adam" and c.grad_clip_norm == 1.0 and c.schedule["decay_type"] == "cosine"
   assert bench.GLOBAL_BATCH == 4096 and (bench.RES, bench.SEQ, bench.VOCAB, bench.EMB) == (224, 64, 32_000, 768)
   assert bench.IMAGE_CFG == dict(variant="B/16", pool_type="map") and bench.TEXT_CFG["variant"] == "B"
+
+
+def test_pmc_family_totals_reads_a_counter_file(tmp_path):
+  """bench.live_pmc_traffic: the per-launch traffic of the dominant family comes from rocprofv3's
+  counter_collection.csv of a child run - k-major gemm256 / gemm256r rows only, KiB summed, launches counted."""
+  import bench
+  hdr = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"
+  rows = [("void (anonymous namespace)::gemm256_kernel<true, 0, 3, false>((anonymous namespace)::G256Params)", 1000.0),
+          ("void (anonymous namespace)::gemm256_kernel<true, 0, 0, false>((anonymous namespace)::G256Params)", 500.0),
+          ("void (anonymous namespace)::gemm256r_kernel<1, true, 0>((anonymous namespace)::G256Params)", 250.0),
+          ("void (anonymous namespace)::gemm256_kernel<false, 0, 0, false>((anonymous namespace)::G256Params)", 9999.0),   # dW: not in the family
+          ("void (anonymous namespace)::ln_bwd_kernel<false, 3, 3>(void const*)", 7777.0)]
+  p = tmp_path / "1_counter_collection.csv"
+  with open(p, "w") as f:
+    f.write(hdr + "\n")
+    for i, (name, val) in enumerate(rows):
+      f.write(f'{i},{i},0,1,1,1,131072,{i},"{name}",512,163840,0,240,0,96,"FETCH_SIZE",{val},{1000 * i},{1000 * i + 500}\n')
+  kib, n = bench.pmc_family_totals(str(p))
+  assert n == 3 and kib == 1750.0
