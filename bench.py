@@ -228,17 +228,6 @@ def cpu_baseline(sample_pairs, samples=2):
     return float(loss.detach())
 
   step(2)  # page in / thread-pool warm-up
-  # thread count: the host's default (all hardware threads) is not the fastest for this op mix on the 128-thread GPU
-  # box (an 8-core container ran the same step faster): time one 2-pair step per candidate, keep the best
-  ncpu = os.cpu_count() or cores
-  calib = {}
-  for c in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
-    torch.set_num_threads(c)
-    t0 = time.perf_counter()
-    step(2)
-    calib[c] = time.perf_counter() - t0
-  cores = min(calib, key=calib.get)
-  torch.set_num_threads(cores)
   # two sample sizes ("n = 8 / 16 / 32 ... scales ~linearly in n"): half and one-and-a-half times the
   # requested sample, together the CPU work of two samples of it (~30-40 s); `value` is the larger one's rate
   sizes = sorted({max(2, sample_pairs // 2), max(2, sample_pairs * 3 // 2)}) if samples > 1 else [sample_pairs]
@@ -251,7 +240,6 @@ def cpu_baseline(sample_pairs, samples=2):
   return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port", "samples": len(times),
           "sample_pairs": sizes, "sample_seconds": [round(t, 2) for t in times],
           "pairs_per_s_by_sample": {str(k): round(k / t, 3) for k, t in zip(sizes, times)},
-          "threads_tried_s_per_2_pair_step": {str(k): round(v, 2) for k, v in calib.items()},
           "sample": f"one full step (fwd+bwd+Adam) of the same ViT-B/16+text-B model on {n} pairs, fp32 torch-CPU oracle "
                     f"(a port: the reference's CPU-JAX path cannot run on this host), {dt:.1f} s; a second sample on "
                     f"{sizes[0]} pairs shows the rate's dependence on the sample size"}
