@@ -113,7 +113,7 @@ def pmc_family_totals(csv_path):
   return sum(t[k] for k in fam), sum(c[k] for k in fam)
 
 
-def live_pmc_traffic(micro, timeout_s=240):
+def live_pmc_traffic(micro, timeout_s=120):
   """HBM bytes per launch of the dominant kernel family measured IN THIS RUN: two short rocprofv3 passes of this very
   command (`--steps 1 --warmup 0`, everything optional switched off) as child processes on the same GPU, one per
   counter - FETCH_SIZE and WRITE_SIZE in SEPARATE passes with --kernel-trace only, as MI355X_MICROARCH.md (HBM /
