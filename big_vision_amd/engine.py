@@ -231,6 +231,21 @@ class _Twins:
       w._t_ver = ver
 
 
+def refresh_twins(store):
+  """Brings every enrolled transposed weight image of `store` up to date NOW, on the current stream.  The lazy refresh
+  in _W.bf_t() runs on whichever stream first touches a stale weight and rewrites ALL images in one launch; a caller
+  that is about to run the towers on two streams (TwoTowersExec, config.tower_streams = 2) calls this before the fork
+  so that no stream reads an image another stream is rewriting."""
+  tw = getattr(store, "_twins", None)
+  if tw is None:
+    return
+  for frozen in (False, True):
+    ver = store.static_version if frozen else store.shadow_version
+    live = [w for w in (r() for r in tw.members[frozen]) if w is not None]
+    if any(w._t_ver != ver for w in live):
+      tw.refresh(frozen, ver)
+
+
 def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
   return ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=None if b is None else b.f32, **kw)
 

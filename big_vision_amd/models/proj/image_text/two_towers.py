@@ -31,10 +31,47 @@ class TwoTowersExec:
     self.prefix, self._ranges = prefix, {}
     self.t = E._W(store, f"{prefix}t")
     self.b = E._W(store, f"{prefix}b") if m.bias_init is not None else None
+    # Opt-in (trainer option config.tower_streams = 2, default 1): the text tower on a side stream beside the image
+    # tower.  The towers share nothing until the loss (two_towers.py:56-75); their persistent GEMMs each fill the
+    # grid, so what the second stream buys is the other tower's workgroups in the ragged last round of a launch
+    # (text N = 768 GEMMs at 512 pairs: 1.5 rounds).  Same kernels on the same inputs: identical results.
+    self.streams = 1
+    self._side = None
+
+  def _fork(self):
+    """(main, side) with every transposed weight image current and the side stream behind everything enqueued so far."""
+    main = torch.cuda.current_stream()
+    if self._side is None:
+      self._side = torch.cuda.Stream(device=self.store.device)
+    E.refresh_twins(self.store)
+    # the side stream's context follows the main one's CU reservation (RCCL overlap of the backward, dp.py)
+    reserve = ops.ctx().get("gemm_reserve_cus")
+    with torch.cuda.stream(self._side):
+      ops.ctx().set("gemm_reserve_cus", reserve)
+    self._side.wait_stream(main)
+    return main, self._side
+
+  def _two_streams(self, image, text):
+    return self.streams == 2 and image is not None and text is not None and text.is_cuda
 
   def fwd(self, image, text, save=False, collect=False):
     out, ctx = {}, {}
     zimg = ztxt = None
+    if self._two_streams(image, text):
+      main, side = self._fork()
+      with torch.cuda.stream(side):
+        z, o, c = self.txt.fwd(text, save, collect)
+        ztxt, norm = ops.l2norm_fwd(z)
+      out.update({f"txt/{k}": v for k, v in o.items()})
+      out["txt/norm"] = norm.view(-1, 1)
+      out["txt/normalized"] = ztxt
+      ctx["txt"] = (c, z, norm)
+      for t_ in [ztxt, norm, z] + [v for v in o.values() if torch.is_tensor(v)]:
+        t_.record_stream(main)          # produced on the side stream, read by the loss / the caller on the main one
+      text = None                        # (done; the image tower below runs on the main stream meanwhile)
+      join = side
+    else:
+      join = None
     if text is not None:
       z, o, c = self.txt.fwd(text, save, collect)
       out.update({f"txt/{k}": v for k, v in o.items()})
@@ -49,6 +86,8 @@ class TwoTowersExec:
       out["img/norm"] = norm.view(-1, 1)
       out["img/normalized"] = zimg
       ctx["img"] = (c, z, norm)
+    if join is not None:
+      torch.cuda.current_stream().wait_stream(join)
     out["t"] = torch.exp(self.t.f32)
     out["t/parameter"] = self.t.f32
     if self.b is not None:
@@ -85,34 +124,50 @@ class TwoTowersExec:
     GEMMs), the rest of the text tower (embedding table, final norm, head) when the text backward
     is done, the image tower's final norm / MAP head together with its last block; what is left
     (stem, position embedding, t, b) is reduced by sync.finish()."""
-    store = self.store
+    two = self.streams == 2 and dztxt is not None and dzimg is not None and "txt" in ctx and "img" in ctx and dztxt.is_cuda
+    if two:
+      main, side = self._fork()
+      dztxt.record_stream(side)
+      with torch.cuda.stream(side):
+        self._bwd_txt(ctx, dztxt, sync)
+      self._bwd_img(ctx, dzimg, sync)
+      main.wait_stream(side)
+      return
     if dztxt is not None and "txt" in ctx:
-      c, z, norm = ctx["txt"]
-      on_block = None
-      if sync is not None:
-        rt = self._block_ranges(f"{self.prefix}txt/", "Encoder_0")
-        on_block = lambda i, rt=rt: sync.launch(*rt[i]) if i in rt else None
-      self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt), on_block=on_block)
-      if sync is not None:
-        r = store.grad_range(lambda n: n.startswith(f"{self.prefix}txt/"))
-        if r is not None:
-          sync.launch_gaps(*r)
+      self._bwd_txt(ctx, dztxt, sync)
     if dzimg is not None and "img" in ctx:
-      c, z, norm = ctx["img"]
-      on_block = None
-      if sync is not None:
-        ri = self._block_ranges(f"{self.prefix}img/", "Transformer")
-        stem = tuple(f"{self.prefix}img/{k}" for k in ("embedding", "pos_embedding", "cls", "patchln_pre", "patchln_post"))
-        tail = store.grad_range(lambda n: n.startswith(f"{self.prefix}img/") and "/encoderblock_" not in n
-                                and not n.startswith(stem))
-        last = max(ri) if ri else None
+      self._bwd_img(ctx, dzimg, sync)
 
-        def on_block(i, ri=ri, tail=tail, last=last):
-          if i == last and tail is not None:
-            sync.launch(*tail)          # final norm + pooling head: final before the first block's backward
-          if i in ri:
-            sync.launch(*ri[i])
-      self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg), on_block=on_block)
+  def _bwd_txt(self, ctx, dztxt, sync):
+    store = self.store
+    c, z, norm = ctx["txt"]
+    on_block = None
+    if sync is not None:
+      rt = self._block_ranges(f"{self.prefix}txt/", "Encoder_0")
+      on_block = lambda i, rt=rt: sync.launch(*rt[i]) if i in rt else None
+    self.txt.bwd(c, ops.l2norm_bwd(z, norm, dztxt), on_block=on_block)
+    if sync is not None:
+      r = store.grad_range(lambda n: n.startswith(f"{self.prefix}txt/"))
+      if r is not None:
+        sync.launch_gaps(*r)
+
+  def _bwd_img(self, ctx, dzimg, sync):
+    store = self.store
+    c, z, norm = ctx["img"]
+    on_block = None
+    if sync is not None:
+      ri = self._block_ranges(f"{self.prefix}img/", "Transformer")
+      stem = tuple(f"{self.prefix}img/{k}" for k in ("embedding", "pos_embedding", "cls", "patchln_pre", "patchln_post"))
+      tail = store.grad_range(lambda n: n.startswith(f"{self.prefix}img/") and "/encoderblock_" not in n
+                              and not n.startswith(stem))
+      last = max(ri) if ri else None
+
+      def on_block(i, ri=ri, tail=tail, last=last):
+        if i == last and tail is not None:
+          sync.launch(*tail)          # final norm + pooling head: final before the first block's backward
+        if i in ri:
+          sync.launch(*ri[i])
+    self.img.bwd(c, ops.l2norm_bwd(z, norm, dzimg), on_block=on_block)
 
 
 class Model:

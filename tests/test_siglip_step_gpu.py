@@ -386,6 +386,36 @@ def test_l16_336_siglip_step_n16(dev):
             case="siglip L/16@336 depth2 n=16")
 
 
+@pytest.mark.parametrize("micro", [0, 4])
+def test_towers_on_two_streams_change_nothing(dev, micro):
+  """config.tower_streams = 2 (opt-in): the text tower runs on a side stream beside the image tower, forward and
+  backward, with and without micro-batches.  Same kernels on the same inputs: loss, gradient norm and every gradient
+  agree with the one-stream step (LayerNorm scale / bias gradients are fp32 atomics: summation order only)."""
+  import bv_oracle as O
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+  res = {}
+  for streams in (1, 2):
+    model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+    config = _cfg(tower_streams=streams, microbatch=micro, microbatch_keep="all")
+    state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, total_steps=config.total_steps)
+    fn = siglip.make_update_fn(model, config)
+    for _ in range(2):     # two steps: the second one re-transposes the weight images before the fork
+      state, meas = fn(state, None, batch)
+    torch.cuda.synchronize()
+    res[streams] = (meas["training_loss"].item(), meas["l2_grads"].item(), state["params"].store.grad.clone(),
+                    state["params"].store.master.clone())
+  (l1, g1, v1, p1), (l2, g2, v2, p2) = res[1], res[2]
+  assert abs(l1 - l2) <= 1e-7 * abs(l1) and abs(g1 - g2) <= 1e-5 * g1, (l1, l2, g1, g2)
+  assert (v1 - v2).norm().item() <= 1e-5 * v1.norm().item()
+  assert (p1 - p2).abs().max().item() <= 2.1e-3      # (two Adam steps; a ~0 gradient may flip a sign-like first update)
+  assert ((p1 - p2).abs() > 1e-6).double().mean().item() <= 0.01
+
+
 @pytest.mark.parametrize("keep,light", [(0, False), (1, False), ("all", False), ("auto", "auto"),
                                         ("all", True), (2, True)])
 def test_microbatched_step_equals_full_batch(dev, keep, light):
