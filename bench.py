@@ -186,6 +186,8 @@ def make_config(total_steps):
   c.grad_clip_norm = 1.0
   c.total_steps = total_steps
   c.microbatch = MICRO
+  if os.environ.get("BV_TOWER_STREAMS"):      # A/B of the trainer option config.tower_streams (default: the trainer's)
+    c.tower_streams = int(os.environ["BV_TOWER_STREAMS"])
   return c
 
 
@@ -384,7 +386,7 @@ def workload_c2(dev, steps, stream="float32"):
 
 
 def workload_siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, schedule=None, label="", text_model=None,
-                    vocab=32_000, stream="float32", comm=None, gflop_per_pair=None):
+                    vocab=32_000, stream="float32", comm=None, gflop_per_pair=None, tower_streams=None):
   """One SigLIP training step (trainers.proj.image_text.siglip) on n pairs of synthetic data, this device only."""
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
@@ -394,6 +396,8 @@ def workload_siglip(dev, steps, image_cfg, text_cfg, emb, n, res, seq, micro, sc
   config = make_config(20_000)
   config.microbatch = micro
   config.residual_stream = stream
+  if tower_streams:
+    config.tower_streams = tower_streams
   if schedule is not None:
     config.schedule = schedule
   g = torch.Generator(device=dev).manual_seed(1)
@@ -450,13 +454,19 @@ def workload_c5b(dev, steps, stream="float32"):
   return r
 
 
-def workload_rank_shape(dev, steps, n, stream="float32"):
+def workload_rank_shape(dev, steps, n, stream="float32", tower_streams=None):
   """The pairs ONE rank of the headline owns at N = 4096 / n GPUs (single pass, full contexts, loss over the local
-  pairs only: no peers on a single device)."""
+  pairs only: no peers on a single device).  tower_streams = 2: the trainer's opt-in config.tower_streams (text tower
+  on a side stream beside the image tower; identical results) - its kernels overlap, so per-launch event times are
+  not exclusive and the entry carries no roofline_frac."""
   r = workload_siglip(dev, steps, IMAGE_CFG, TEXT_CFG, EMB, n=n, res=RES, seq=SEQ, micro=MICRO, stream=stream,
-                      gflop_per_pair=MATMUL_GFLOP_PER_PAIR,
-                      label=f"headline model, the {n} pairs one of {GLOBAL_BATCH // n} ranks owns (no collectives)")
-  r["metric"] = f"image-text pairs/sec per GPU at {n} pairs per GPU (rank shape of the headline at N = {GLOBAL_BATCH // n})"
+                      gflop_per_pair=MATMUL_GFLOP_PER_PAIR, tower_streams=tower_streams,
+                      label=f"headline model, the {n} pairs one of {GLOBAL_BATCH // n} ranks owns (no collectives)"
+                            + (", config.tower_streams = 2" if tower_streams == 2 else ""))
+  r["metric"] = (f"image-text pairs/sec per GPU at {n} pairs per GPU (rank shape of the headline at N = {GLOBAL_BATCH // n})"
+                 + (", text tower on a second stream (opt-in config.tower_streams = 2)" if tower_streams == 2 else ""))
+  if tower_streams == 2:
+    r["roofline"] = dict(r["roofline"], frac=None)
   return r
 
 
@@ -493,7 +503,9 @@ def configs_object(dev, steps=3):
   for key, fn in (("c2", lambda: workload_c2(dev, steps)), ("c4_rank", lambda: workload_c4(dev, steps)),
                   ("c5b", lambda: workload_c5b(dev, steps)), ("rank512", lambda: workload_rank_shape(dev, steps, 512)),
                   ("rank1024", lambda: workload_rank_shape(dev, steps, 1024)),
-                  ("rank512_rccl", lambda: workload_rank_shape_rccl(dev, steps, 512))):
+                  ("rank512_rccl", lambda: workload_rank_shape_rccl(dev, steps, 512)),
+                  ("rank512_two_streams", lambda: workload_rank_shape(dev, steps, 512, tower_streams=2)),
+                  ("rank1024_two_streams", lambda: workload_rank_shape(dev, steps, 1024, tower_streams=2))):
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
