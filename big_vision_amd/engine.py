@@ -250,32 +250,8 @@ def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
   return ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=None if b is None else b.f32, **kw)
 
 
-def set_dw_stream(stream):
-  """Opt-in (trainer option config.dw_stream, single-rank steps): every weight-gradient GEMM of this host thread is
-  enqueued on `stream` instead of the current one.  dW GEMMs are off the backward's critical path (only the optimizer
-  reads them), so a side stream lets their workgroups fill the CUs the dX GEMMs / LayerNorm / attention launches leave
-  idle in their last rounds.  Returns the previous setting; the caller joins the side stream before the optimizer."""
-  old = getattr(_tls, "dw_stream", None)
-  _tls.dw_stream = stream
-  return old
-
-
 def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
   """dW += x^T dy (split-K atomics into the grad buffer), db += colsum(dy)."""
-  side = getattr(_tls, "dw_stream", None)
-  if side is not None and x_bf.is_cuda:
-    main = torch.cuda.current_stream()
-    if main != side:
-      side.wait_stream(main)                       # the operands were produced by what main has enqueued so far
-      for t in (x_bf, dy_bf, dy_for_bias):
-        if t is not None:
-          t.record_stream(side)                    # keep their memory until the side stream has read them
-      with torch.cuda.stream(side):
-        return _linear_bwd_w(x_bf, dy_bf, w, b, dy_for_bias)
-  return _linear_bwd_w(x_bf, dy_bf, w, b, dy_for_bias)
-
-
-def _linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
   if w.grad is not None and w.kpad:
     # padded input width: the product lands in a [kpad][out] scratch (its last rows are exactly 0: the
     # pad columns of x are) and the real rows are added to the gradient

@@ -37,10 +37,6 @@ class TwoTowersExec:
     # (text N = 768 GEMMs at 512 pairs: 1.5 rounds).  Same kernels on the same inputs: identical results.
     self.streams = 1
     self._side = None
-    # Opt-in (config.dw_stream, single-rank steps only): the weight-gradient GEMMs of the backward on their own side
-    # stream (engine.set_dw_stream), joined before this method returns.
-    self.dw_stream = False
-    self._dw_side = None
 
   def _fork(self):
     """(main, side) with every transposed weight image current and the side stream behind everything enqueued so far."""
@@ -128,18 +124,6 @@ class TwoTowersExec:
     GEMMs), the rest of the text tower (embedding table, final norm, head) when the text backward
     is done, the image tower's final norm / MAP head together with its last block; what is left
     (stem, position embedding, t, b) is reduced by sync.finish()."""
-    if self.dw_stream and sync is None and torch.cuda.is_available():
-      if self._dw_side is None:
-        self._dw_side = torch.cuda.Stream(device=self.store.device)
-      old = E.set_dw_stream(self._dw_side)
-      try:
-        self.dw_stream = False          # (re-entrancy guard for the call below)
-        self.bwd(ctx, dzimg, dztxt, sync=None)
-      finally:
-        self.dw_stream = True
-        E.set_dw_stream(old)
-      torch.cuda.current_stream().wait_stream(self._dw_side)
-      return
     two = self.streams == 2 and dztxt is not None and dzimg is not None and "txt" in ctx and "img" in ctx and dztxt.is_cuda
     if two:
       main, side = self._fork()

@@ -123,7 +123,6 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     ex = model.executor(store, "", _img_shape(images), tuple(labels.shape))
     # opt-in: text tower on a side stream beside the image tower (TwoTowersExec; same kernels, identical results)
     ex.streams = int(config.get("tower_streams", 1) or 1)
-    ex.dw_stream = bool(config.get("dw_stream", False)) and comm.size == 1
     img_frozen = all(e in store.frozen for e in store.entries if e.startswith("img/"))
     txt_frozen = all(e in store.frozen for e in store.entries if e.startswith("txt/"))
     t_param = store.t("t")

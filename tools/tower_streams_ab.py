@@ -10,13 +10,12 @@ import torch
 import bench
 
 
-def run(dev, n, streams, steps=6, dw=False):
+def run(dev, n, streams, steps=6):
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
   model = two_towers.Model(image=bench.IMAGE_CFG, text=bench.TEXT_CFG, out_dim=(None, bench.EMB), temperature_init=10.0, bias_init=-10.0)
   config = bench.make_config(20_000)
   config.tower_streams = streams
-  config.dw_stream = dw
   image, text = bench.synthetic_batch(n, dev, seed=1)
   state, _ = siglip.make_train_state(model, config, (n, bench.RES, bench.RES, 3), (n, bench.SEQ), rng=0, total_steps=20_000, device=dev)
   fn = siglip.make_update_fn(model, config)
@@ -41,9 +40,9 @@ def main():
   dev = torch.device("cuda:0")
   for n in [int(a) for a in sys.argv[1:]] or [512, 1024]:
     for rep in range(2):
-      for streams, dw in ((1, False), (2, False), (1, True), (2, True)):
-        ms, loss, peak = run(dev, n, streams, dw=dw)
-        print(f"n = {n:5d}  tower_streams = {streams} dw_stream = {int(dw)}: {ms:8.2f} ms per step  loss {loss:.6f}  peak {peak:.1f} GB", flush=True)
+      for streams in (1, 2):
+        ms, loss, peak = run(dev, n, streams)
+        print(f"n = {n:5d}  tower_streams = {streams}: {ms:8.2f} ms per step  loss {loss:.6f}  peak {peak:.1f} GB", flush=True)
 
 
 if __name__ == "__main__":
