@@ -51,13 +51,14 @@ class TwoTowersExec:
     self._side.wait_stream(main)
     return main, self._side
 
-  def _two_streams(self, image, text):
-    return self.streams == 2 and image is not None and text is not None and text.is_cuda
+  def _two_streams(self, image, text, collect=False):
+    # (collect=True hands nested dicts of intermediate activations to the caller: they stay on one stream)
+    return self.streams == 2 and not collect and image is not None and text is not None and text.is_cuda
 
   def fwd(self, image, text, save=False, collect=False):
     out, ctx = {}, {}
     zimg = ztxt = None
-    if self._two_streams(image, text):
+    if self._two_streams(image, text, collect):
       main, side = self._fork()
       with torch.cuda.stream(side):
         z, o, c = self.txt.fwd(text, save, collect)
