@@ -126,3 +126,27 @@ def test_comm_layer_binds_rccl_at_run_time():
   needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
   assert "rccl" not in needed.lower(), "libbvhip.so must not link RCCL"
   assert lib.bv_comm_init(None, 0, 1, None) != 0 and b"bad arguments" in lib.bv_last_error()
+
+
+def test_python_contexts_are_per_stream_and_options_restore(lib, monkeypatch):
+  """big_vision_amd.ops keeps one bv_ctx per (device, stream); `ops.option` restores the previous value; BV_CTX_OPTS
+  seeds every new context (whole-program A/B runs).  Host logic only: no kernel is launched."""
+  from big_vision_amd import ops
+  monkeypatch.setattr(ops, "_contexts", {})
+  stream = {"id": 11}
+  monkeypatch.setattr(ops, "_stream", lambda: stream["id"])
+  a = ops.ctx()
+  assert ops.ctx() is a and a.get("gemm_roll") == 1
+  with ops.option("gemm_roll", 6) as o:
+    assert o.old == 1 and ops.ctx_get("gemm_roll") == 6
+    stream["id"] = 12                      # another stream: its own context, default options
+    b = ops.ctx()
+    assert b is not a and b.get("gemm_roll") == 1
+    stream["id"] = 11
+  assert ops.ctx_get("gemm_roll") == 1
+  with pytest.raises(KeyError):
+    a.set("no_such_option", 1)
+  monkeypatch.setenv("BV_CTX_OPTS", "gemm_nt=1, gemm_group_n=4")
+  stream["id"] = 13
+  c = ops.ctx()
+  assert c.get("gemm_nt") == 1 and c.get("gemm_group_n") == 4 and a.get("gemm_nt") == 0
