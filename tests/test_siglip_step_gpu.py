@@ -410,7 +410,7 @@ def test_towers_on_two_streams_change_nothing(dev, micro):
     res[streams] = (meas["training_loss"].item(), meas["l2_grads"].item(), state["params"].store.grad.clone(),
                     state["params"].store.master.clone())
   (l1, g1, v1, p1), (l2, g2, v2, p2) = res[1], res[2]
-  assert abs(l1 - l2) <= 1e-7 * abs(l1) and abs(g1 - g2) <= 1e-5 * g1, (l1, l2, g1, g2)
+  assert abs(l1 - l2) <= 1e-6 * abs(l1) and abs(g1 - g2) <= 1e-5 * g1, (l1, l2, g1, g2)
   assert (v1 - v2).norm().item() <= 1e-5 * v1.norm().item()
   assert (p1 - p2).abs().max().item() <= 2.1e-3      # (two Adam steps; a ~0 gradient may flip a sign-like first update)
   assert ((p1 - p2).abs() > 1e-6).double().mean().item() <= 0.01
