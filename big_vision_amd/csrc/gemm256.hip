@@ -128,10 +128,19 @@ __device__ __forceinline__ void tile_mn(int tile, int tiles_n, int ntiles, int g
   tn = grp * g + (rem - tm * w);
 }
 
-// PROBE != 0 variants exist only for tools/probes/gemm256_probe.hip (bottleneck
-// ablation, results are garbage): 1 = LDS fragment reads only for the first K-tile,
-// 2 = (TN) plain b128 reads instead of transpose reads, 3 = no DMA after the
-// prologue, 5 = no epilogue stores (bf16 outputs).  The library instantiates PROBE = 0 only.
+// PROBE != 0 variants (bottleneck ablations; most of them produce garbage results) exist ONLY when a
+// translation unit under tools/probes/ defines BV_GEMM256_PROBES before including this file: 1 = LDS fragment
+// reads only for the first K-tile, 2 = (TN) plain b128 reads instead of transpose reads, 3 = no DMA after the
+// prologue, 5 = no epilogue stores (bf16 outputs), ...  In the library build the macro is not defined: every
+// probe branch below is the constant `false`, the probe-only code blocks are not compiled, and instantiating
+// PROBE != 0 is a compile error (tests/test_codegen_cpu.py also checks the exported kernel names).
+#ifdef BV_GEMM256_PROBES
+#define BV_PROBE(n) (PROBE == (n))
+#define BV_PROBING (PROBE != 0)
+#else
+#define BV_PROBE(n) false
+#define BV_PROBING false
+#endif
 //
 // The kernel is PERSISTENT: the grid is one workgroup per CU (<= 256); each workgroup
 // walks a list of work items (tile, split) and keeps the DMA pipeline running across
@@ -158,6 +167,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 15, lg = lane >> 4;
+#ifndef BV_GEMM256_PROBES
+  static_assert(PROBE == 0, "probe variants are compiled only under tools/probes/ (BV_GEMM256_PROBES)");
+#endif
 
   // ---- XCD-aware work distribution.  Block b runs on XCD b%8.  Work ids (tile index
   // fastest, n fastest inside it, then split) are cut into 8 contiguous chunks, one per
@@ -174,13 +186,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   const int nmy = idx < cl ? (cl - idx + bpx - 1) / bpx : 0;
   if (nmy == 0) return;
   const int nk_all = p.K >> 6;
-  if (PROBE != 0 && p.skew_mode >= 2) {   // probe: only a subset of the workgroups runs (its usual work list)
+  if (BV_PROBING && p.skew_mode >= 2) {   // probe: only a subset of the workgroups runs (its usual work list)
     const int m = p.skew_mode;
     const bool on = m == 2 ? xcd == 0 : m == 3 ? (idx & 7) == 0 : m == 4 ? bid == 0 : m == 5 ? idx == 0
                   : m == 6 ? (xcd == 0 && idx < 8) : m == 7 ? xcd < 4 : true;
     if (!on) return;
   }
-  if (PROBE != 0 && p.dbg && tid == 0) {
+  if (BV_PROBING && p.dbg && tid == 0) {
     p.dbg[bid * 4 + 0] = __builtin_amdgcn_s_memtime();
     p.dbg[bid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
   }
@@ -188,11 +200,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   // at the epilogue start and one at its end.
   int stamp_n = 0;
   auto stamp = [&]() {
-    if (PROBE == 9 && p.dbg && tid == 0 && bid < 2 && stamp_n < 1000)
+    if (BV_PROBE(9) && p.dbg && tid == 0 && bid < 2 && stamp_n < 1000)
       p.dbg[1024 + bid * 1024 + stamp_n++] = __builtin_amdgcn_s_memtime();
   };
   auto tstamp = [&](int jt) {
-    if (PROBE == 10 && p.dbg && tid == 0 && (bid & 7) == 0 && jt < 30)
+    if (BV_PROBE(10) && p.dbg && tid == 0 && (bid & 7) == 0 && jt < 30)
       p.dbg[1024 + (bid >> 3) * 32 + jt] = __builtin_amdgcn_s_memrealtime();
   };
   // All workgroups of a launch run identical tiles, so left alone they stay in lockstep
@@ -265,20 +277,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 
   // issue one half-tile (2 DMA instructions per thread) of the K-tile under cursor c
   auto issueA = [&](const Cursor& c, int slot, int h) {
-    if (PROBE == 3 && probe_no_dma) return;
+    if (BV_PROBE(3) && probe_no_dma) return;
     char* d = ldsA + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcA + c.offA + (long)c.t * stepA + (h ? hA : 0);
     glds16(s, d);
     glds16(s + gA, d + 8192);
   };
   auto issueB = [&](const Cursor& c, int slot, int h) {
-    if (PROBE == 3 && probe_no_dma) return;
+    if (BV_PROBE(3) && probe_no_dma) return;
     char* d = ldsB + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcB + c.offB + (long)c.t * stepB + (h ? hB : 0);
     glds16(s, d);
     glds16(s + gB, d + 8192);
   };
 
+#ifdef BV_GEMM256_PROBES
   // PROBE 16 (tools/probes/gemm_vf_probe.hip; bit-identical to PROBE 0, timing): both operand streams go through
   // VGPRs - global_load_dwordx4 into staging registers where the DMA instruction would be issued, ds_write_b128 into
   // the same LDS positions two phases later - instead of through global_load_lds (whose issue costs a wave ~60 cycles
@@ -321,6 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     asm volatile("" ::: "memory");
     vpB[h] = false;
   };
+#endif
 
   // ---- per-lane LDS read addresses (relative to the stage base)
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -355,11 +369,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef BV_GEMM256_PROBES
   // PROBE 11 (tools/probes/gemm_r3_probe.hip, TIMING ONLY - the fragments are not re-mapped, results are
   // garbage): the same main loop issuing v_mfma_f32_32x32x16_bf16 - per quadrant 2 x 1 fragments of 32 x 32
   // x 4 k-steps of 16 = 8 MFMAs instead of 16, the same 32 accumulator and 48 operand registers.
   f32x16 acc32[4][2];
-  if constexpr (PROBE == 11) {
+  if constexpr (BV_PROBE(11)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -367,15 +382,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
   }
-#define BV_ACC(i, j, r) (PROBE == 11 ? acc32[(i) >> 1][(j) >> 1][(((i) & 1) * 2 + ((j) & 1)) * 4 + (r)] : acc[i][j][r])
+#define BV_ACC(i, j, r) (BV_PROBE(11) ? acc32[(i) >> 1][(j) >> 1][(((i) & 1) * 2 + ((j) & 1)) * 4 + (r)] : acc[i][j][r])
+#else
+#define BV_ACC(i, j, r) acc[i][j][r]
+#endif
   bf16x8 af[4][2], bfg[4][2];
 
   // A fragments of 64-row sub-tile `sub` (4 frags x 2 k-steps) of stage base `sa`
   bool probe_skip_reads = false;
   auto readA = [&](uint32_t sa, int sub) {
-    if (PROBE == 1 && probe_skip_reads) return;
-    if constexpr (KM || PROBE == 2) {
-      const uint32_t a0 = (ra0 + sa) & (PROBE == 2 ? ~15u : ~0u), a1 = (ra1 + sa) & (PROBE == 2 ? ~15u : ~0u);
+    if (BV_PROBE(1) && probe_skip_reads) return;
+    if constexpr (KM || BV_PROBE(2)) {
+      const uint32_t a0 = (ra0 + sa) & (BV_PROBE(2) ? ~15u : ~0u), a1 = (ra1 + sa) & (BV_PROBE(2) ? ~15u : ~0u);
       if (sub == 0) {
         af[0][0] = lds_read128<0>(a0);     af[0][1] = lds_read128<0>(a1);
         af[1][0] = lds_read128<2048>(a1);  af[1][1] = lds_read128<2048>(a0);
@@ -403,9 +421,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   };
   // B fragments j = 2*sub, 2*sub+1 (2 frags x 2 k-steps) of stage base `sb`
   auto readB = [&](uint32_t sb, int sub) {
-    if (PROBE == 1 && probe_skip_reads) return;
-    if constexpr (KM || PROBE == 2) {
-      const uint32_t b0 = (rb0 + sb) & (PROBE == 2 ? ~15u : ~0u), b1 = (rb1 + sb) & (PROBE == 2 ? ~15u : ~0u);
+    if (BV_PROBE(1) && probe_skip_reads) return;
+    if constexpr (KM || BV_PROBE(2)) {
+      const uint32_t b0 = (rb0 + sb) & (BV_PROBE(2) ? ~15u : ~0u), b1 = (rb1 + sb) & (BV_PROBE(2) ? ~15u : ~0u);
       constexpr int O1 = OUTF32 ? 2048 : 512, O2 = OUTF32 ? 4096 : 4096, O3 = OUTF32 ? 6144 : 4608;
       if (sub == 0) {
         bfg[0][0] = lds_read128<0>(b0);    bfg[0][1] = lds_read128<0>(b1);
@@ -433,11 +451,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
 
   // PROBE 14 / 15 (timing only): 14 = STATIC priority (waves 4-7 raise theirs once, no per-segment flips:
   // MI355X_MICROARCH.md, VALU arbitration item 4), 15 = no s_setprio at all
-  if (PROBE == 14 && wr == 1) __builtin_amdgcn_s_setprio(1);
-#define BV_MFMA_QUAD(I0, J0)                                                                   \
+  if (BV_PROBE(14) && wr == 1) __builtin_amdgcn_s_setprio(1);
+#ifdef BV_GEMM256_PROBES
+#define BV_MFMA_QUAD_32(I0, J0)                                                                \
   do {                                                                                         \
-    if (PROBE != 14 && PROBE != 15) __builtin_amdgcn_s_setprio(1);                             \
-    if constexpr (PROBE == 11) {                                                               \
       if (first) {                                                                             \
         _Pragma("unroll") for (int r2 = 0; r2 < 2; ++r2)                                       \
           acc32[((I0) >> 1) + r2][(J0) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
@@ -452,8 +469,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
           acc32[((I0) >> 1) + r2][(J0) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(        \
               bfg[(J0) + (k4 >> 1)][k4 & 1], af[r2 * 2 + (k4 >> 1)][k4 & 1],                   \
               acc32[((I0) >> 1) + r2][(J0) >> 1], 0, 0, 0);                                    \
+  } while (0)
+#else
+#define BV_MFMA_QUAD_32(I0, J0) do {} while (0)
+#endif
+#define BV_MFMA_QUAD(I0, J0)                                                                   \
+  do {                                                                                         \
+    if (!BV_PROBE(14) && !BV_PROBE(15)) __builtin_amdgcn_s_setprio(1);                             \
+    if constexpr (BV_PROBE(11)) {                                                              \
+      BV_MFMA_QUAD_32(I0, J0);                                                                 \
     } else                                                                                     \
-    if (PROBE != 4) {                                                                          \
+    if (!BV_PROBE(4)) {                                                                          \
       /* first K-tile of a work item: the k-step-0 MFMAs take C = 0 (an inline constant), so   \
          the 128 accumulator registers are never cleared by VALU moves (512 cycles per wave    \
          and tile during which the SIMD's matrix pipe had nothing to do) */                    \
@@ -473,21 +499,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
           acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                   \
               bfg[(J0) + j][1], af[i][1], acc[(I0) + i][(J0) + j], 0, 0, 0);                   \
     }                                                                                          \
-    if (PROBE != 14 && PROBE != 15) __builtin_amdgcn_s_setprio(0);                             \
+    if (!BV_PROBE(14) && !BV_PROBE(15)) __builtin_amdgcn_s_setprio(0);                             \
   } while (0)
 
   // PROBE 12 / 13 (timing only, tools/probes/gemm_r3_probe.hip): the same loop with HALF the workgroup
   // barriers - 12 drops the one behind every MFMA segment, 13 the one in front of it
 #define BV_MID()                                          \
   do {                                                    \
-    if (PROBE != 13) __builtin_amdgcn_s_barrier();        \
+    if (!BV_PROBE(13)) __builtin_amdgcn_s_barrier();        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_sched_barrier(0);                    \
   } while (0)
 #define BV_END()                                          \
   do {                                                    \
     __builtin_amdgcn_sched_barrier(0);                    \
-    if (PROBE != 12) __builtin_amdgcn_s_barrier();        \
+    if (!BV_PROBE(12)) __builtin_amdgcn_s_barrier();        \
   } while (0)
 
   // ---- prologue: B(0), A(0), B(1) in flight; K-tile 0 must have landed.
@@ -517,7 +543,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
   // leaves the stores outstanding (vmcnt(4 + NSTORE)) instead of draining them.
   constexpr int NSTORE = KM ? ((OUTF32 || EPI == BV_EPI_GELU || EPI == BV_EPI_GELU_BWD_EMIT || EPI == BV_EPI_GELU_GD) ? 32 : 16) : 32;
   bool pre = false;
+#ifdef BV_GEMM256_PROBES
   bool vf_prev = false;   // PROBE 16: the previous K-tile requested its B halves
+#endif
   for (int jt = 0; jt < nmy; ++jt) {
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
     const int nkc = cur.nk;
@@ -529,7 +557,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
       const bool moreA = ca.j < nmy, moreB = cb.j < nmy;
       const bool doA = moreA && !pre, doB = moreB && !pre;
       const bool first = t == 0;
-      if constexpr (PROBE == 16) {
+#ifdef BV_GEMM256_PROBES
+      if constexpr (BV_PROBE(16)) {
         // VGPR-fed streams: A(k+1) requested in phases 0 / 1 and written in phases 2 / 3, B(k+2) requested in phases
         // 2 / 3 and written in phases 0 / 1 of the next K-tile.  The phase-3 write is read right behind the next
         // barrier by the wave group that runs one barrier ahead: it is waited for in front of BV_MID.
@@ -560,7 +589,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
         BV_MFMA_QUAD(4, 0);
         BV_END();
         vf_prev = doB;
-      } else {
+      } else
+#endif
+      {
       // -------- phase 0: quadrant (0,0)
       readA(sa, 0);
       readB(sb, 0);
@@ -646,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     const long cstep = 16L * p.ldc;                                     // elements between row fragments
     uint32_t vc[4];                                                     // lane offsets (bytes) of its four column pieces
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vc[j] = (uint32_t)(lr * (PROBE == 7 ? 256 : (int)p.ldc) + ncl[j]) * ESZ;
+    for (int j = 0; j < 4; ++j) vc[j] = (uint32_t)(lr * (BV_PROBE(7) ? 256 : (int)p.ldc) + ncl[j]) * ESZ;
     // Everything below works on PAIRS of adjacent columns (f32x2: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32,
     // two fp32 lanes per VALU instruction): pair q of a row fragment = columns nc[q >> 1] + 2 (q & 1) + {0, 1}.
     f32x2 bv[8], cs[8];
@@ -661,7 +692,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     }
     const f32x2 alpha2 = pk_splat(p.alpha);
     const int mrow0 = m0 + wr * 128 + lr;
-    const bool nts = (p.nt & 1) || PROBE == 6, ntl = p.nt & 2;
+    const bool nts = (p.nt & 1) || BV_PROBE(6), ntl = p.nt & 2;
     // GBWD: epilogues that take a bf16 auxiliary operand of C's shape and feed the fused column sums
     constexpr bool GBWD = EPI == BV_EPI_GELU_BWD || EPI == BV_EPI_GELU_BWD_EMIT || EPI == BV_EPI_MUL;
     constexpr bool RESBF = EPI == BV_EPI_RESIDUAL && !OUTF32;   // bf16 residual stream: aux bf16, C bf16
@@ -726,9 +757,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
         } else {
           char* c = Cb + (long)i * cstep * 2;     // wave-uniform
           char* c2 = C2b + (long)i * cstep * 2;
-          if (PROBE == 7)   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back; vc: pitch 256)
+          if (BV_PROBE(7))   // probe: every tile of a block overwrites the same 64 KiB (L2-resident, no HBM write-back; vc: pitch 256)
             c = reinterpret_cast<char*>(p.C) + ((long)bid * 128 + ((wr * 128 + i * 16) & 127)) * 512 + wc * 128;
-          if (PROBE == 5) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
+          if (BV_PROBE(5)) {   // probe: keep ALL the math live (no DCE of MFMAs), skip the stores
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(v[q]));
             continue;
@@ -826,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     stamp();
     tstamp(jt);
     // ---- next work item: move the math cursor (the accumulators restart from C = 0 in the MFMAs)
-    if constexpr (PROBE == 4) {
+    if constexpr (BV_PROBE(4)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -836,10 +867,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     advance(cur);
   }
 #undef BV_MFMA_QUAD
+#undef BV_MFMA_QUAD_32
 #undef BV_MID
 #undef BV_END
 #undef BV_ACC
-  if (PROBE != 0 && p.dbg && tid == 0) {
+  if (BV_PROBING && p.dbg && tid == 0) {
     p.dbg[bid * 4 + 2] = __builtin_amdgcn_s_memtime();
     p.dbg[bid * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }

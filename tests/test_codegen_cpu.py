@@ -85,3 +85,25 @@ def test_no_mfma_result_is_read_straight_across_a_branch(src, tmp_path):
                   "--cuda-device-only", os.path.join(CSRC, src), "-o", str(out)],
                  check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
   assert audit_mfma_edges.audit(str(out)) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_library_build_holds_no_probe_variant_of_the_gemm(tmp_path):
+  """The bottleneck-ablation modes of gemm256_kernel (template argument PROBE != 0: timing-only paths, several of
+  them with wrong results by design) are compiled only when a translation unit under tools/probes/ defines
+  BV_GEMM256_PROBES.  The library build must (a) instantiate PROBE = 0 only and (b) refuse any other value."""
+  res = _resources("gemm256.hip", tmp_path)
+  names = [n for n in res if "gemm256_kernel" in n]
+  assert names
+  for n in names:   # _ZN..14gemm256_kernelILb<KM>ELi<PROBE>ELi<EPI>ELb<OUTF32>EEEv...
+    m = re.search(r"gemm256_kernelILb[01]ELi(\d+)E", n)
+    assert m and m.group(1) == "0", n
+  src = open(os.path.join(CSRC, "gemm256.hip")).read()
+  assert "#define BV_GEMM256_PROBES" not in src
+  tu = tmp_path / "probe_without_macro.hip"
+  tu.write_text('#include "gemm256.hip"\n'
+                "template __global__ void gemm256_kernel<true, 5, BV_EPI_NONE, false>(G256Params);\n")
+  r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "--cuda-device-only",
+                      "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-x", "hip", "-c", str(tu), "-o",
+                      str(tmp_path / "p.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+  assert r.returncode != 0 and "probe variants are compiled only under tools/probes" in r.stdout, r.stdout[-2000:]

@@ -42,6 +42,7 @@
 #include <string.h>
 #include <type_traits>
 #include <vector>
+#define BV_GEMM256_PROBES   // compiles the PROBE != 0 ablation paths of gemm256_kernel (absent from the library build)
 #include "../../big_vision_amd/csrc/gemm256.hip"
 
 namespace {

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#define BV_GEMM256_PROBES   // compiles the PROBE != 0 ablation paths of gemm256_kernel (absent from the library build)
 #include "../../big_vision_amd/csrc/gemm256.hip"
 #include "probe_ctx.h"
 
