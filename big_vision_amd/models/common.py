@@ -1,34 +1,49 @@
-"""Checkpoint <-> init reconciliation, mirroring big_vision/models/common.py:24-92."""
+"""Checkpoint <-> init reconciliation.
+
+Contract (what a caller of big_vision/models/common.py:24-92 relies on): the result has exactly the leaves of
+`inited`; a leaf comes from `loaded` unless one of the `dont_load` regexes full-matches its `/`-joined name; a name
+that exists on one side only and is not excused by `dont_load` is an error whose text lists both trees and the two
+difference sets (with the ` - ` / ` + ` markers tools grep for).  The error text is API; the code below is ours."""
 from big_vision_amd import utils as u
+
+_SECTIONS = (
+    ("Params in checkpoint", "  "),
+    ("Params in model (code)", "  "),
+    ("Params in model (code) but not in checkpoint and not `dont_load`ed", " - "),
+    ("Params in checkpoint but not in model (code) and not `dont_load`ed", " + "),
+)
+
+
+def _report(groups):
+  """One block per non-empty name set: a title line, then the sorted names behind that set's marker."""
+  blocks = []
+  for (title, marker), names in zip(_SECTIONS, groups):
+    blocks.append("\n".join([f"{title}:"] + [marker + n for n in sorted(names)]) if names else "")
+  return "\n".join(blocks)
 
 
 def merge_params(loaded, inited, dont_load=(), match_dtype=False):
-  """Makes `loaded` match the structure of `inited`; `dont_load` regexes keep
-  the init value.  Raises ValueError with a formatted diff on unexplained
-  mismatches (same contract as the reference)."""
-  del match_dtype
+  """`loaded` reshaped onto the structure of `inited` (see the module docstring).  `match_dtype` casts each
+  taken leaf to the dtype of the init leaf it replaces."""
   if inited is None:
     return loaded
-  dont_load = u.check_and_compile_patterns(dont_load)
+  excused = u.check_and_compile_patterns(dont_load)
+  have = dict(u.tree_flatten_with_names(loaded)[0])
+  want = dict(u.tree_flatten_with_names(inited)[0])
+  pinned = {n for n in have.keys() | want.keys() if any(rx.fullmatch(n) for rx in excused)}
 
-  def should_merge(name):
-    return not any(p.fullmatch(name) for p in dont_load)
+  only_model = want.keys() - have.keys() - pinned
+  only_ckpt = have.keys() - want.keys() - pinned
+  if only_model or only_ckpt:
+    raise ValueError(_report((have.keys(), want.keys(), only_model, only_ckpt)))
 
-  loaded_flat = dict(u.tree_flatten_with_names(loaded)[0])
-  inited_flat = dict(u.tree_flatten_with_names(inited)[0])
-  merged = {}
-  for name, init_val in inited_flat.items():
-    merged[name] = loaded_flat[name] if (name in loaded_flat and should_merge(name)) else init_val
+  def pick(name, init_leaf):
+    if name in pinned or name not in have:
+      return init_leaf
+    leaf = have[name]
+    if match_dtype and hasattr(leaf, "dtype") and leaf.dtype != init_leaf.dtype:
+      leaf = leaf.to(init_leaf.dtype) if hasattr(leaf, "to") else leaf.astype(init_leaf.dtype)
+    return leaf
 
-  def pp(title, names, indent="  "):
-    return (f"{title}:\n" + "\n".join(f"{indent}{k}" for k in sorted(names))) if names else ""
-
-  not_in_loaded = {k for k in inited_flat.keys() - loaded_flat.keys() if should_merge(k)}
-  not_in_inited = {k for k in loaded_flat.keys() - inited_flat.keys() if should_merge(k)}
-  if not_in_loaded or not_in_inited:
-    raise ValueError(
-        pp("Params in checkpoint", loaded_flat.keys()) + "\n" +
-        pp("Params in model (code)", inited_flat.keys()) + "\n" +
-        pp("Params in model (code) but not in checkpoint and not `dont_load`ed", not_in_loaded, indent=" - ") + "\n" +
-        pp("Params in checkpoint but not in model (code) and not `dont_load`ed", not_in_inited, indent=" + "))
-  return u.recover_tree(merged.keys(), merged.values())
+  names = list(want)
+  return u.recover_tree(names, [pick(n, want[n]) for n in names])

@@ -262,35 +262,42 @@ class Model:
     return zimg, ztxt, out
 
 
+# init-file keys of `config.model_init` -> (leaf of the param tree, default tower module or None for a plain array)
+_PARTS = (
+    (("image", "img"), "img", "image_model", "vit"),
+    (("text", "txt"), "txt", "text_model", "proj.image_text.text_transformer"),
+    (("temperature", "t"), "t", None, None),
+    (("bias", "b"), "b", None, None),
+)
+
+
 def load(init_params, init_files, model_cfg, img_load_kw={}, txt_load_kw={}):  # pylint: disable=dangerous-default-value
-  """Loads both towers, `init_files` is a dict with `img` and `txt` keys (two_towers.py:93-137)."""
+  """Restores the two towers and the loss scalars (contract of two_towers.py:93-137).
+
+  `init_files`: a vanity name, ONE checkpoint path (its `img` / `txt` / `t` (/ `b` when the model has a bias)
+  sub-trees are taken), or a dict {"img"|"image", "txt"|"text", "t"|"temperature", "b"|"bias"} -> path.  Towers are
+  restored by their own module's `load`; parts without an init file keep `init_params`; a key nobody consumed is
+  refused with the reference's message (a typo in a config must not pass silently)."""
   if isinstance(init_files, str):
     init_files = VANITY_NAMES.get(init_files, init_files)
   if isinstance(init_files, str):
-    keys = ("img", "txt", "t", "b") if "bias_init" in model_cfg.keys() else ("img", "txt", "t")
-    init_files = {k: f"{init_files}:{k}" for k in keys}
+    parts = ["img", "txt", "t"] + (["b"] if "bias_init" in model_cfg.keys() else [])
+    todo = {k: f"{init_files}:{k}" for k in parts}
   else:
-    init_files = {**init_files}
-  if not init_params:
-    init_params = {"img": None, "txt": None}
-  restored_params = {**init_params}
-
-  img_init = init_files.pop("image", init_files.pop("img", None))
-  if img_init:
-    restored_params["img"] = importlib.import_module(
-        f"{MODELS_PKG}.{model_cfg.get('image_model', 'vit')}"
-    ).load(init_params["img"], img_init, model_cfg.get("image"), **img_load_kw)
-  txt_init = init_files.pop("text", init_files.pop("txt", None))
-  if txt_init:
-    restored_params["txt"] = importlib.import_module(
-        f"{MODELS_PKG}.{model_cfg.get('text_model', 'proj.image_text.text_transformer')}"
-    ).load(init_params["txt"], txt_init, model_cfg.get("text"), **txt_load_kw)
-  t_init = init_files.pop("temperature", init_files.pop("t", None))
-  if t_init:
-    restored_params["t"] = utils.load_params(t_init)
-  b_init = init_files.pop("bias", init_files.pop("b", None))
-  if b_init:
-    restored_params["b"] = utils.load_params(b_init)
+    todo = dict(init_files)
+  restored_params = dict(init_params) if init_params else {"img": None, "txt": None}
+  tower_kw = {"img": img_load_kw, "txt": txt_load_kw}
+  for aliases, leaf, module_key, default_module in _PARTS:
+    found = [todo.pop(a) for a in aliases if a in todo]
+    source = found[0] if found else None
+    if not source:
+      continue
+    if module_key is None:
+      restored_params[leaf] = utils.load_params(source)
+    else:
+      tower = importlib.import_module(f"{MODELS_PKG}.{model_cfg.get(module_key, default_module)}")
+      restored_params[leaf] = tower.load(restored_params.get(leaf), source, model_cfg.get(aliases[0]), **tower_kw[leaf])
+  init_files = todo
   assert not init_files, (
       f"There's something unused left in `config.model_init`. You probably got "
       f"a typo. Here it is: {init_files}")

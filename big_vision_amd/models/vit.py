@@ -379,26 +379,25 @@ def scan_to_pyloop(params_scan):
   return p
 
 
-def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=invalid-name
-  """Load init from checkpoint, both old model and this one. +Hi-res posemb (vit.py:408-433)."""
-  init_file = VANITY_NAMES.get(init_file, init_file)
-  restored_params = utils.load_params(init_file)
-  restored_params = fix_old_checkpoints(restored_params)
-  # Bring the checkpoint to the layout the model presents (vit.py:416-424): stacked blocks for
-  # scan=True models, encoderblock_{i} otherwise.
+def _wants_stacked_blocks(init_params, model_cfg):
+  """Layout the MODEL presents: the init tree says it when there is one, otherwise `model_cfg.scan` (vit.py:416-424)."""
   if init_params:
-    want_scan = "encoderblock" in init_params.get("Transformer", {})
-  else:   # no init tree to look at: the model config decides (vit.py:416-424 reads model_cfg.scan)
-    want_scan = bool((model_cfg or {}).get("scan", False))
-  have_scan = "encoderblock" in restored_params["Transformer"]
-  if have_scan and not want_scan:
-    restored_params = scan_to_pyloop(restored_params)
-  elif want_scan and not have_scan:
-    restored_params = pyloop_to_scan(restored_params)
-  restored_params = common.merge_params(restored_params, init_params, dont_load)
-  if init_params and "pos_embedding" in init_params:
-    restored_params["pos_embedding"] = resample_posemb(
-        old=restored_params["pos_embedding"], new=init_params["pos_embedding"])
+    return "encoderblock" in init_params.get("Transformer", {})
+  return bool((model_cfg or {}).get("scan", False))
+
+
+def load(init_params, init_file, model_cfg, dont_load=()):  # pylint: disable=invalid-name
+  """Checkpoint (current or legacy layout, loop or scan blocks, any posemb grid) -> tree shaped like `init_params`
+  (contract of vit.py:408-433): legacy names fixed, blocks re-laid-out to the model's loop / scan form, leaves matching
+  `dont_load` kept at their init value, position embeddings resampled to the model's grid."""
+  ckpt = fix_old_checkpoints(utils.load_params(VANITY_NAMES.get(init_file, init_file)))
+  stacked = "encoderblock" in ckpt["Transformer"]
+  if stacked != _wants_stacked_blocks(init_params, model_cfg):
+    ckpt = scan_to_pyloop(ckpt) if stacked else pyloop_to_scan(ckpt)
+  restored_params = common.merge_params(ckpt, init_params, dont_load)
+  target_posemb = (init_params or {}).get("pos_embedding")
+  if target_posemb is not None:
+    restored_params["pos_embedding"] = resample_posemb(old=restored_params["pos_embedding"], new=target_posemb)
   return restored_params
 
 

@@ -1,14 +1,13 @@
-"""Host-side utilities PORTED from big_vision/utils.py (Copyright 2024 Big Vision Authors,
-Apache-2.0): the subset of that file the hot path uses, with the jax / flax lines removed.
+"""Host-side utilities: the subset of big_vision/utils.py (Copyright 2024 Big Vision Authors, Apache-2.0) that
+the hot path's callers use - leaf naming (utils.py:616-862), regex masks (:1169-1212), durations -> steps
+(:1002-1067), learning-rate schedules (:1070-1143), .npz parameter loading (:133-227), mixup (:1146-1154).
 
-This file is a port, not a rewrite: `_traverse_with_names`, `recover_tree`,
-`check_and_compile_patterns`, `make_mask_trees`, `steps`, `create_learning_rate_schedule`,
-`npload` and `load_checkpoint_np` are the reference's host-side contract helpers (leaf naming
-utils.py:616-862, regex masks :1169-1212, duration -> steps :1002-1067, learning-rate schedules
-:1070-1143, .npz parameter loading :133-227) kept line-compatible on purpose - configs, checkpoints
-and schedules written for the reference must mean the same thing here, and the reference's own
-known-answer tests (utils_test.py:228-281) pin them (tests/test_host_cpu.py).  Pure Python / numpy,
-no device code; nothing of the hot path's arithmetic lives here.
+What is contract here is BEHAVIOUR: configs, checkpoints and schedules written for the reference must mean the
+same thing, and the reference's own known-answer tests (utils_test.py:144-281) are restated in
+tests/test_host_cpu.py.  The tree helpers and the pattern compiler are written in this project's own structure;
+`steps` and `create_learning_rate_schedule` follow the reference's branch order closely because every branch,
+default and assertion message of theirs is observable through a config.  Pure Python / numpy, no device code;
+nothing of the hot path's arithmetic lives here.
 """
 from __future__ import annotations
 
@@ -21,23 +20,28 @@ import numpy as np
 
 # ------------------------------------------------------------- tree utils ----
 def _traverse_with_names(tree, with_inner_nodes=False):
-  """Sorted-key traversal yielding ('a/b/c', leaf) — utils.py:616-641."""
-  if tree is None:
-    return
-  if isinstance(tree, Mapping):
-    for key in sorted(tree.keys()):
-      for path, v in _traverse_with_names(tree[key], with_inner_nodes):
-        yield (key + "/" + path).rstrip("/"), v
+  """(name, leaf) pairs of a nested dict / list / tuple.  The naming contract of utils.py:616-641: children are
+  visited in sorted-key order (sequences by index), a leaf's name is its keys joined by '/', `None` nodes do not
+  exist, and with `with_inner_nodes` every container is also yielded AFTER its children under its own path."""
+  out = []
+
+  def walk(node, prefix):
+    if node is None:
+      return
+    if isinstance(node, Mapping):
+      children = [(str(k), node[k]) for k in sorted(node.keys())]
+    elif isinstance(node, (list, tuple)):
+      children = [(str(i), v) for i, v in enumerate(node)]
+    else:
+      out.append(("/".join(prefix), node))
+      return
+    for key, child in children:
+      walk(child, prefix + (key,))
     if with_inner_nodes:
-      yield "", tree
-  elif isinstance(tree, (list, tuple)):
-    for idx in range(len(tree)):
-      for path, v in _traverse_with_names(tree[idx], with_inner_nodes):
-        yield (str(idx) + "/" + path).rstrip("/"), v
-    if with_inner_nodes:
-      yield "", tree
-  else:
-    yield "", tree
+      out.append(("/".join(prefix), node))
+
+  walk(tree, ())
+  return iter(out)
 
 
 def tree_flatten_with_names(tree):
@@ -47,20 +51,16 @@ def tree_flatten_with_names(tree):
 
 
 def recover_tree(keys, values):
-  """Unflattens '/'-joined names into nested dicts — utils.py:836-862."""
-  tree = {}
-  sub_trees = {}
-  for k, v in zip(keys, values):
-    if "/" not in k:
-      tree[k] = v
-    else:
-      k_left, k_right = k.split("/", 1)
-      sub_trees.setdefault(k_left, ([], []))
-      sub_trees[k_left][0].append(k_right)
-      sub_trees[k_left][1].append(v)
-  for k, (sk, sv) in sub_trees.items():
-    tree[k] = recover_tree(sk, sv)
-  return tree
+  """Inverse of the flattening: '/'-joined names back into nested dicts (utils.py:836-862; keys appear in
+  first-seen order - every consumer walks trees in sorted-name order, so only the nesting is contract)."""
+  root = {}
+  for name, value in zip(keys, values):
+    *parents, last = name.split("/")
+    node = root
+    for part in parents:
+      node = node.setdefault(part, {})
+    node[last] = value
+  return root
 
 
 def tree_unflatten(names_and_vals):
@@ -79,17 +79,14 @@ def tree_map(f, tree, *rest):
 
 
 def check_and_compile_patterns(patterns):
-  """utils.py:1169-1192."""
+  """One regex string or a list / tuple of them -> compiled regexes (utils.py:1169-1192).  Leaf names here never
+  begin with '/', so a pattern that does can match nothing: refused with the reference's message."""
   if isinstance(patterns, str):
-    patterns = [patterns]
+    patterns = (patterns,)
   assert isinstance(patterns, (list, tuple)), patterns
-
-  def check_and_compile(pattern):
-    assert not pattern.startswith("/"), (
-        f"Big vision parameter names never start with '/': '{pattern}")
-    return re.compile(pattern)
-
-  return list(map(check_and_compile, patterns))
+  for pat in patterns:
+    assert not pat.startswith("/"), f"Big vision parameter names never start with '/': '{pat}"
+  return [re.compile(pat) for pat in patterns]
 
 
 def make_mask_trees(tree, patterns, *, log=None):
