@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void pool_max_fwd_kernel(const float* __restri
     int at = 0;
     for (int l = 1; l < L; ++l) {
       const float v = x[(b * L + l) * D + c];
-      if (v > best) { best = v; at = l; }
+      // a NaN takes the maximum and keeps it (x.max(axis=1) propagates NaN: a diverged tower must stay visible to
+      // the trainer's finiteness check); `best == best` stops later values from replacing a NaN already held
+      if ((v > best || v != v) && best == best) { best = v; at = l; }
     }
     y[i] = best;
     arg[i] = at;

@@ -246,6 +246,31 @@ def refresh_twins(store):
       tw.refresh(frozen, ver)
 
 
+def record_stream_tree(obj, stream):
+  """`record_stream(stream)` on every CUDA tensor inside a saved context (tuples / lists / dicts / objects with
+  __dict__): the allocator must not hand the blocks back to the pool of the stream that produced them while
+  `stream` still reads them."""
+  seen = set()
+
+  def walk(o):
+    if id(o) in seen:
+      return
+    seen.add(id(o))
+    if torch.is_tensor(o):
+      if o.is_cuda:
+        o.record_stream(stream)
+    elif isinstance(o, (list, tuple)):
+      for v in o:
+        walk(v)
+    elif isinstance(o, dict):
+      for v in o.values():
+        walk(v)
+    elif hasattr(o, "__dict__") and not isinstance(o, (type, _W)):
+      walk(vars(o))
+
+  walk(obj)
+
+
 def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
   return ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=None if b is None else b.f32, **kw)
 

@@ -39,15 +39,23 @@ class TwoTowersExec:
     self._side = None
 
   def _fork(self):
-    """(main, side) with every transposed weight image current and the side stream behind everything enqueued so far."""
+    """(main, side) with every transposed weight image current and the side stream behind everything enqueued so far.
+
+    The side stream's `bv_ctx` is brought to the main context's state first - EVERY option (kernel variants, the CU
+    reservation of an overlapped gradient sync, attention configuration, A/B switches set through `ops.option` /
+    `ops.ctx_set`) and `use_workspace` - so that both towers always run one configuration.
+
+    Stream-ownership invariant the allocator bookkeeping below relies on: everything the side stream ever does
+    sits between a `side.wait_stream(main)` here and a `main.wait_stream(side)` / `current.wait_stream(side)` join
+    in `fwd` / `bwd`.  Tensors produced on the side stream and consumed on the main one (ztxt, its norm, the text
+    contexts when the backward runs on one stream) are `record_stream(main)`-ed where they cross."""
     main = torch.cuda.current_stream()
     if self._side is None:
       self._side = torch.cuda.Stream(device=self.store.device)
     E.refresh_twins(self.store)
-    # the side stream's context follows the main one's CU reservation (RCCL overlap of the backward, dp.py)
-    reserve = ops.ctx().get("gemm_reserve_cus")
+    mc = ops.ctx()
     with torch.cuda.stream(self._side):
-      ops.ctx().set("gemm_reserve_cus", reserve)
+      ops.ctx().copy_options_from(mc)
     self._side.wait_stream(main)
     return main, self._side
 
@@ -55,10 +63,18 @@ class TwoTowersExec:
     # (collect=True hands nested dicts of intermediate activations to the caller: they stay on one stream)
     return self.streams == 2 and not collect and image is not None and text is not None and text.is_cuda
 
+  def _backward_will_fork(self):
+    """False when one of the towers takes no gradient (LiT / a frozen tower: `bwd` then runs the other tower alone on
+    the main stream).  A saving forward does not fork in that case either: contexts allocated from the side stream's
+    pool and freed on the main stream would only raise peak HBM for an overlap the backward cannot use."""
+    frozen = self.store.frozen
+    return all(any(n.startswith(f"{self.prefix}{tower}") and n not in frozen for n in self.store.entries)
+               for tower in ("img/", "txt/"))
+
   def fwd(self, image, text, save=False, collect=False):
     out, ctx = {}, {}
     zimg = ztxt = None
-    if self._two_streams(image, text, collect):
+    if self._two_streams(image, text, collect) and (not save or self._backward_will_fork()):
       main, side = self._fork()
       with torch.cuda.stream(side):
         z, o, c = self.txt.fwd(text, save, collect)
@@ -69,6 +85,7 @@ class TwoTowersExec:
       ctx["txt"] = (c, z, norm)
       for t_ in [ztxt, norm, z] + [v for v in o.values() if torch.is_tensor(v)]:
         t_.record_stream(main)          # produced on the side stream, read by the loss / the caller on the main one
+      ctx["txt_on_side"] = True
       text = None                        # (done; the image tower below runs on the main stream meanwhile)
       join = side
     else:
@@ -135,6 +152,8 @@ class TwoTowersExec:
       main.wait_stream(side)
       return
     if dztxt is not None and "txt" in ctx:
+      if ctx.get("txt_on_side"):   # saved by a forked forward, consumed (and freed) here on the main stream
+        E.record_stream_tree(ctx["txt"], torch.cuda.current_stream())
       self._bwd_txt(ctx, dztxt, sync)
     if dzimg is not None and "img" in ctx:
       self._bwd_img(ctx, dzimg, sync)

@@ -74,6 +74,18 @@ class Context:
   def get(self, name):
     return _lib.load().bv_ctx_get(self.ptr, _lib.OPTS[name])
 
+  def copy_options_from(self, other):
+    """Every option of `other` (the settable ids of _lib.OPTS, i.e. below 100: the rest are counters) and its
+    workspace policy: a side stream's context runs the configuration of the stream it was forked from."""
+    if other is self:
+      return
+    for name, opt_id in _lib.OPTS.items():
+      if opt_id < 100:
+        v = other.get(name)
+        if v != self.get(name):
+          self.set(name, v)
+    self.use_workspace = other.use_workspace
+
   def ensure_workspace(self, device):
     if not self.use_workspace:
       if self._ws is not None:

@@ -468,12 +468,19 @@ class Optimizer:
       return None
     return dp.GradShardSync(self.comm, self.store.grad, self.bounds, on_finish=self._mark_reduced)
 
-  def _mark_reduced(self):
+  def mark_grads_reduced(self):
+    """Public stamp: "`store.grad` already holds, on every owner, the SUM over ranks of its ranges" - good for the
+    next step() only.  Callers that reduced the gradients by other means than grad_sync() (an all-reduce of the
+    whole buffer, a second step() on gradients a previous step() already reduced) must call it, otherwise step()
+    sums the owners' ranges over the ranks once more.  Every rank must agree on whether it stamps: the fallback
+    reduction of step() is a collective."""
     self._reduced_for = self.count
 
+  _mark_reduced = mark_grads_reduced
+
   def _owner_sums_ready(self):
-    """Contract of step() under shard=True (advisor r4): `store.grad` holds this rank's PARTIAL sums and every range
-    must have been summed onto its owner - normally by the trainer's grad_sync() object during the backward.  A
+    """Contract of step() under shard=True (advisor r4, r5): step() CONSUMES partial sums - `store.grad` holds this
+    rank's PARTIAL sums and every range must have been summed onto its owner - normally by the trainer's grad_sync() object during the backward.  A
     caller that never drove one (its finish() leaves the stamp) gets the whole trainable range reduced here, after
     the backward, instead of an update from partial gradients that nothing would flag."""
     if not (self.sharded and self.comm is not None and self.comm.active):
@@ -696,7 +703,9 @@ class Optimizer:
     if self.name in ADAFACTOR_NAMES:
       self._gather_af_state()
       return {"mu": self.mu, "af_state": self.af_state, "count": self.count}
-    if self.sharded and self.comm is not None and self.comm.active:
+    # always moments of exactly `trainable_count` elements, whatever the placement (advisor r5: a sharded
+    # optimizer on an inactive one-rank group used to hand out its padded own-slice buffers)
+    if self.sharded:
       return {"mu": self._full_moment(self.mu), "nu": self._full_moment(self.nu), "count": self.count}
     return {"mu": self.mu, "nu": self.nu, "count": self.count}
 
@@ -707,7 +716,11 @@ class Optimizer:
       self.af_state.copy_(d["af_state"]); self.count = int(d["count"])
       return
     mu, nu = d["mu"], d["nu"]
-    if self.sharded and mu.numel() != self.mu.numel():     # whole moments (state_dict of any placement) -> own slice
+    n_tr = self.store.trainable_count
+    if mu.numel() != n_tr or nu.numel() != n_tr:
+      raise ValueError(f"optimizer moments of {mu.numel()} / {nu.numel()} elements do not fit this model's "
+                       f"{n_tr} trainable parameters (state_dict() of any placement holds whole moments)")
+    if self.sharded:                                       # whole moments -> own slice
       n_own = self.hi - self.lo
       self.mu.zero_(); self.nu.zero_()
       self.mu[:n_own].copy_(mu[self.lo:self.hi].to(self.mu.dtype)); self.nu[:n_own].copy_(nu[self.lo:self.hi])

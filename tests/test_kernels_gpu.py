@@ -837,3 +837,11 @@ def test_pool_max_is_exact(dev, n, L, D):
   xr = x.clone().requires_grad_(True)
   xr.view(n, L, D).max(dim=1).values.backward(dy)
   assert torch.equal(dx, xr.grad)
+  # NaN propagates like x.max(axis=1) (advisor r5): wherever it sits in the sequence, the pooled value is NaN
+  for pos in (0, L // 2, L - 1):
+    xn = x.clone()
+    xn.view(n, L, D)[0, pos, 1] = float("nan")
+    yn, argn = ops.pool_max_fwd(xn, n, L, D)
+    assert torch.isnan(yn[0, 1]) and int(argn[0, 1]) == pos
+    keep = torch.ones_like(yn, dtype=torch.bool); keep[0, 1] = False
+    assert torch.equal(yn[keep], y[keep])
