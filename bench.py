@@ -49,17 +49,32 @@ IMAGE_CFG = dict(variant="B/16", pool_type="map")
 TEXT_CFG = dict(variant="B", vocab_size=VOCAB)
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 DOMINANT = (("bv_gemm_bf16", "bv_gemm_bf16_colsum"), 1, 1)   # k-major ("NT") GEMM: forward (W^T shadow) and dX projections
-PMC_PROFILE = "r05_pmc_traffic.json"   # rocprofv3 --pmc passes of this command, this round's kernels
+# rocprofv3 --pmc passes of this command (tools/pmc_summary.py), newest first: the headline and the rank shapes of N = 2 / 4 / 8
+PMC_PROFILES = ("r06_pmc_traffic.json", "r06_pmc_traffic_rank2048.json", "r06_pmc_traffic_rank1024.json",
+                "r06_pmc_traffic_rank512.json", "r05_pmc_traffic.json")
 DOMINANT_KERNEL = "gemm256_kernel<true> + gemm256r_kernel (256x256 k-major bf16 MFMA GEMM, all epilogues)"
 
 
 class GemmObserver:
-  """Brackets every launch of the dominant kernel with HIP events on the
-  stream it is launched on (torch's current stream)."""
+  """Brackets every launch of the dominant kernel with HIP events on the stream it is launched on (torch's current
+  stream at the call: the main stream for the image tower, the side stream for the text tower since the towers run on
+  two streams by default) and reports the family's EXCLUSIVE BUSY TIME: every event is placed on one time line
+  (elapsed time from a base event recorded when the timed region starts) and the launch intervals are merged - the
+  time during which at least one launch of the family was in flight.  With a single stream this is the sum of the
+  launch durations; with two streams two overlapping launches (an image-tower GEMM beside a text-tower GEMM) count
+  their FLOPs twice and their common time once, which is what the chip delivered.  A family launch that overlaps a
+  kernel of another family on the other stream is charged the whole interval (the figure errs low, never high)."""
 
   def __init__(self):
     self.recs = []
     self.active = False
+    self.base = None
+
+  def start(self):
+    """Call with the device idle, right before the timed region."""
+    self.base = torch.cuda.Event(enable_timing=True)
+    self.base.record()
+    self.active = True
 
   def begin(self, name, args):
     if not self.active or name not in DOMINANT[0] or (args[0], args[1]) != DOMINANT[1:]:
@@ -81,26 +96,72 @@ class GemmObserver:
     tok[1].record()
     self.recs.append(tok)
 
+  def intervals(self):
+    """[(start_ms, end_ms)] of every launch on the common time line."""
+    base = self.base
+    if base is None:
+      return [(0.0, r[0].elapsed_time(r[1])) for r in self.recs]   # (no base: durations only, laid end to end below)
+    return [(base.elapsed_time(r[0]), base.elapsed_time(r[1])) for r in self.recs]
+
   def summary(self):
-    ms = sum(r[0].elapsed_time(r[1]) for r in self.recs)
-    flops = sum(r[2] for r in self.recs)
-    nbytes = sum(r[3] for r in self.recs)
-    return len(self.recs), ms, flops, nbytes
+    """(launches, exclusive busy ms, FLOPs, algorithmic bytes, sum of the per-launch event times in ms)."""
+    iv = self.intervals()
+    total = sum(b - a for a, b in iv)
+    busy = union_ms(iv) if self.base is not None else total
+    return len(self.recs), busy, sum(r[2] for r in self.recs), sum(r[3] for r in self.recs), total
 
 
-def pmc_traffic(world, micro):
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
-  THIS command (profiles/r05_pmc_traffic.json, written by tools/pmc_summary.py; counters cannot
-  be read from inside the process).  None when the profile does not match the configuration."""
-  path = os.path.join(ROOT, "profiles", PMC_PROFILE)
-  try:
-    with open(path) as f:
-      d = json.load(f)
-    if d.get("n_gpus", 1) != world or d.get("microbatch") != micro:
-      return None, None
-    return d["kernels"][DOMINANT_KERNEL]["hbm_bytes"], os.path.relpath(path, ROOT)
-  except (OSError, KeyError, ValueError):
-    return None, None
+def union_ms(intervals):
+  """Length of the union of [start, end) intervals (ms)."""
+  busy, cur_a, cur_b = 0.0, None, None
+  for a, b in sorted(intervals):
+    if cur_b is None or a > cur_b:
+      if cur_b is not None:
+        busy += cur_b - cur_a
+      cur_a, cur_b = a, b
+    elif b > cur_b:
+      cur_b = b
+  if cur_b is not None:
+    busy += cur_b - cur_a
+  return busy
+
+
+def roofline_object(obs, wall_s):
+  """The `roofline` object of a timed region from its observer (wall_s: wall time of that region, seconds)."""
+  launches, ms, flops, nbytes, sum_ms = obs.summary()
+  ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+  return {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS,
+          "unit": "TFLOP/s", "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+          "timing": "exclusive busy time of the kernel family: union of its launch intervals, HIP events on each launch "
+                    "stream over the timed region (two streams: overlapping launches share their common time)",
+          "algorithmic_bytes_per_launch": nbytes / max(1, launches), "launches": launches,
+          "avg_launch_us": 1e3 * ms / max(1, launches),
+          "sum_of_launch_event_ms": sum_ms, "busy_ms": ms,
+          "stream_overlap_factor": (sum_ms / ms) if ms > 0 else None,
+          "share_of_step_time": ms / (1e3 * wall_s) if wall_s > 0 else None}
+
+
+def pmc_traffic(world, per_gpu_batch, micro):
+  """HBM bytes per launch of the dominant kernel family from the COMMITTED rocprofv3 --pmc passes (counters cannot be
+  read from inside the process; N = 1 replaces this with passes of its own, live_pmc_traffic).  The profile is picked
+  by what ONE GPU runs - the pairs per GPU and the micro-batch size decide every launch shape - so an N > 1 line uses
+  the passes taken on one GPU at its rank shape (`bench.py --global-batch <pairs per GPU>`; no RCCL beside the
+  kernels in that profile, which the `traffic_source` string says).  (None, None) when no profile matches."""
+  passes = min(per_gpu_batch, micro)
+  for name in PMC_PROFILES:
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+      with open(path) as f:
+        d = json.load(f)
+      if d.get("per_gpu_batch", GLOBAL_BATCH) != per_gpu_batch or min(d.get("microbatch", MICRO), per_gpu_batch) != passes:
+        continue
+      src = os.path.relpath(path, ROOT)
+      if world != d.get("n_gpus", 1):
+        src += f" (one GPU at the {per_gpu_batch}-pair rank shape of N = {world})"
+      return d["kernels"][DOMINANT_KERNEL]["hbm_bytes"], src
+    except (OSError, KeyError, ValueError):
+      continue
+  return None, None
 
 
 def pmc_family_totals(csv_path):
@@ -281,6 +342,11 @@ def rccl_info(comm, dev):
     dist.all_reduce(one)
     info["allreduce_of_ones"] = float(one.item())
     info["max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+  # the two knobs of the overlapped gradient sync and the environment variables that override them without a code
+  # change (A/B on the first multi-GPU node: BV_RESERVED_CUS=4|8|0, BV_NCCL_MAX_NCHANNELS=4|8|uncapped)
+  from big_vision_amd import dp
+  info["reserved_cus"] = dp.RESERVED_CUS
+  info["env_overrides"] = {k: os.environ.get(k) for k in ("BV_RESERVED_CUS", "BV_NCCL_MAX_NCHANNELS", "BV_TOWER_STREAMS")}
   return info
 
 
@@ -339,7 +405,7 @@ def _timed(fn, steps, warmup):
   obs = GemmObserver()
   _lib.observer = obs
   torch.cuda.synchronize()
-  obs.active = True
+  obs.start()
   t0 = time.perf_counter()
   for _ in range(steps):
     fn()
@@ -347,12 +413,7 @@ def _timed(fn, steps, warmup):
   dt = (time.perf_counter() - t0) / steps
   obs.active = False
   _lib.observer = None
-  launches, ms, flops, nbytes = obs.summary()
-  ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-  roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": BF16_DENSE_PEAK_TFLOPS,
-          "unit": "TFLOP/s", "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-          "algorithmic_bytes_per_launch": nbytes / max(1, launches), "launches": launches,
-          "avg_launch_us": 1e3 * ms / max(1, launches), "share_of_step_time": ms / (1e3 * dt * steps)}
+  roof = roofline_object(obs, dt * steps)
   return dt, roof
 
 
@@ -559,6 +620,12 @@ def main():
 
   if not torch.cuda.is_available():
     raise RuntimeError("bench.py needs a GPU: the product path has no CPU fallback")
+  # N > 1: rank 0 times the CPU oracle FIRST, before the process group exists (the peers wait in the rendezvous):
+  # after the timed region the ranks leave at different times, and a rank that computes for half a minute while its
+  # peers tear their communicators down is the one asymmetry this script can avoid.  N = 1: after the GPU work.
+  cpu_early = None
+  if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cpu_baseline:
+    cpu_early = cpu_baseline(args.cpu_sample)
   comm = dp.init_from_env(overlap_channels=dp.RESERVED_CUS)   # gradient all-reduces overlap the backward's GEMMs
   world = comm.size
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -602,7 +669,7 @@ def main():
       _lib.observer = obs
     comm.barrier()
     torch.cuda.synchronize()
-    obs.active = True
+    obs.start() if roofline else None
     t0 = time.perf_counter()
     for _ in range(steps):
       state, meas = update_fn(state, None, batch)
@@ -620,7 +687,7 @@ def main():
     siglip.check_finite(meas)
     res = dict(dt=dt, host_dt=host_dt, host_unblocked_ms=host_unblocked_ms, loss=loss, obs=obs,
                keep_n=update_fn.state_cache["keep_n"], light=update_fn.state_cache["light"],
-               peak=torch.cuda.max_memory_allocated(dev))
+               peak=torch.cuda.max_memory_allocated(dev), tower_streams=int(config.get("tower_streams", 2) or 1))
     del state, update_fn, meas, model
     return res
 
@@ -645,33 +712,14 @@ def main():
     except Exception as e:   # the headline must not depend on the optional second measurement
       bf16_line = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
+  # (a collective: every rank takes part, then the others are done)
+  rccl = rccl_info(comm, dev) if (world > 1 or os.environ.get("BV_DP_FORCE_COLLECTIVES") == "1") else None
   if comm.rank != 0:
     return
-  value = args.global_batch * args.steps / dt
-  line = {
-      "metric": "image-text pairs/sec training step, ViT-B/16 SigLIP bs4096",
-      "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-      "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
-      "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-      "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
-                             "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
-                 "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
-                 "residual_stream": args.residual_stream,
-                 "recompute": (f"{max(0, n // args.microbatch - r['keep_n'])} of "
-                               f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
-                               f"(the others keep {CTX_KIND[r['light']]} "
-                               "activation contexts in HBM)")
-                              if n > args.microbatch else "none",
-                 "parallelism": f"dp{world}", "final_loss": loss,
-                 "img_per_sec_per_core": value / world,   # the reference's own rate figure (utils.py:506, Chrono.tick)
-                 "peak_hbm_gb": round(r["peak"] / 1e9, 1),
-                 "host_enqueue_ms_idle_gpu": host_unblocked_ms,
-                 "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * host_dt / args.steps},
-  }
+  roof = None
   if not args.no_roofline:
-    launches, ms, flops, nbytes = obs.summary()
-    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(world, args.microbatch)
+    roof = roofline_object(obs, dt)
+    traffic, traffic_src = pmc_traffic(world, n, args.microbatch)
     traffic_live, traffic_detail = False, None
     if world == 1 and not args.no_live_pmc and args.global_batch == GLOBAL_BATCH:
       # counters cannot be read in-process: two child rocprofv3 passes of this command, now, on this GPU (the HBM
@@ -687,31 +735,64 @@ def main():
         live, traffic_detail = None, {"error": f"{type(e).__name__}: {e}"[:300]}
       if live is not None:
         traffic, traffic_src, traffic_live = live, "rocprofv3 --pmc child passes of this run", True
-    line["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": ach,
-                        "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                        "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                        "traffic_source": traffic_src, "traffic_measured_in_this_run": traffic_live,
-                        "traffic_detail": traffic_detail,
-                        # whole step, PER GPU: algorithmic matmul FLOPs of the workload (forward + backward of the
-                        # kept contexts; the recompute FLOPs of re-run micro-batches are NOT counted) / wall time /
-                        # (world x one GPU's peak)
-                        "step_frac": (MATMUL_GFLOP_PER_PAIR * 1e9 * args.global_batch * args.steps / dt / 1e12
-                                      / (BF16_DENSE_PEAK_TFLOPS * world)),
-                        "step_frac_is": "per GPU (job FLOP/s / (n_gpus x 2.5 PF))",
-                        "algorithmic_bytes_per_launch": nbytes / max(1, launches),
-                        "launches": launches, "avg_launch_us": 1e3 * ms / max(1, launches),
-                        "share_of_step_time": ms / (1e3 * dt)}
-  if bf16_line is not None:
-    line["bf16_stream"] = bf16_line
-  if world > 1 or os.environ.get("BV_DP_FORCE_COLLECTIVES") == "1":
-    line["rccl"] = rccl_info(comm, dev)
+    roof.update(traffic=traffic, traffic_source=traffic_src, traffic_measured_in_this_run=traffic_live,
+                traffic_detail=traffic_detail)
+  configs = None
   if world == 1 and not args.no_configs and args.global_batch == GLOBAL_BATCH:
-    line["configs"] = configs_object(dev, args.configs_steps)
-  if world == 1 and not args.no_cpu_baseline:
-    line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    configs = configs_object(dev, args.configs_steps)
+  # rank 0 of ANY world size carries the CPU oracle's rate (N > 1: timed above, before the rendezvous)
+  cpu = cpu_early if cpu_early is not None else (None if args.no_cpu_baseline else cpu_baseline(args.cpu_sample))
+  line = assemble_line(args, world, n, r, roof, bf16_line, rccl, configs, cpu)
   sys.stdout.flush()
   os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
+def assemble_line(args, world, n, r, roof, bf16_line, rccl, configs, cpu):
+  """The ONE JSON line of rank 0 from the measured pieces (pure: tests/test_bench_line_cpu.py feeds it a faked
+  N = 2 measurement).  r: measure()'s result dict; roof: roofline_object() (+ traffic fields) or None."""
+  dt = r["dt"]
+  value = args.global_batch * args.steps / dt
+  line = {
+      "metric": "image-text pairs/sec training step, ViT-B/16 SigLIP bs4096",
+      "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+      "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+      "config": {"workload": "SigLIP ViT-B/16@224 (MAP) + text-B 12L/64tok/vocab32k, sigmoid loss, "
+                             "Adam+clip+wd+cosine, random-init weights (BASELINE configs[2])",
+                 "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
+                 "residual_stream": args.residual_stream,
+                 "tower_streams": r.get("tower_streams"),
+                 "recompute": (f"{max(0, n // args.microbatch - r['keep_n'])} of "
+                               f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
+                               f"(the others keep {CTX_KIND[r['light']]} "
+                               "activation contexts in HBM)")
+                              if n > args.microbatch else "none",
+                 "parallelism": f"dp{world}", "final_loss": r["loss"],
+                 "img_per_sec_per_core": value / world,   # the reference's own rate figure (utils.py:506, Chrono.tick)
+                 "peak_hbm_gb": round(r["peak"] / 1e9, 1),
+                 "host_enqueue_ms_idle_gpu": r["host_unblocked_ms"],
+                 "host_wall_ms_per_step_incl_queue_backpressure": 1e3 * r["host_dt"] / args.steps},
+  }
+  if roof is not None:
+    roof = dict(roof)
+    roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
+    # whole step, PER GPU: algorithmic matmul FLOPs of the workload (forward + backward of the kept contexts; the
+    # recompute FLOPs of re-run micro-batches are NOT counted) / wall time / (world x one GPU's peak)
+    roof["step_frac"] = (MATMUL_GFLOP_PER_PAIR * 1e9 * args.global_batch * args.steps / dt / 1e12
+                         / (BF16_DENSE_PEAK_TFLOPS * world))
+    roof["step_frac_is"] = "per GPU (job FLOP/s / (n_gpus x 2.5 PF))"
+    if world > 1:
+      roof["measured_on"] = "rank 0 (every rank runs the same launches on its 1/N of the batch)"
+    line["roofline"] = roof
+  if bf16_line is not None:
+    line["bf16_stream"] = bf16_line
+  if rccl is not None:
+    line["rccl"] = rccl
+  if configs is not None:
+    line["configs"] = configs
+  if cpu is not None:
+    line["cpu_baseline"] = cpu
+  return line
 
 
 if __name__ == "__main__":

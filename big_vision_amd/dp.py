@@ -251,7 +251,7 @@ def init_from_env(backend: str | None = None, overlap_channels: int | None = Non
       # The collectives of a step move < 1 GB per 90 ms: a few channels are plenty, and every RCCL
       # channel is a workgroup that needs a CU of its own beside the persistent GEMMs (see RESERVED_CUS).
       cap = os.environ.get("BV_NCCL_MAX_NCHANNELS", overlap_channels)
-      if cap:
+      if cap and str(cap).lower() not in ("0", "none", "uncapped"):     # "uncapped": leave RCCL's own choice (A/B)
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(cap)))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
   return Comm()
@@ -280,7 +280,8 @@ def warn_if_overlap_is_uncapped():
 # (BV_OPT_GEMM_RESERVE_CUS of the compute stream's bv_ctx): its workgroups fill a CU, so a collective launched beside it would otherwise
 # wait for - or delay - a whole GEMM launch.  4 keeps the split-K choices of the B/16 shapes intact
 # (252 = 36 x 7 = 9 x 28 work items) and costs the k-major GEMMs 1.6 % of the chip during the backward.
-RESERVED_CUS = 4
+# BV_RESERVED_CUS overrides it (A/B on a multi-GPU node without a code change; 0 = reserve nothing).
+RESERVED_CUS = int(os.environ.get("BV_RESERVED_CUS", "4"))
 
 
 class reserve_cus_for_collectives:

@@ -31,7 +31,7 @@ class TwoTowersExec:
     self.prefix, self._ranges = prefix, {}
     self.t = E._W(store, f"{prefix}t")
     self.b = E._W(store, f"{prefix}b") if m.bias_init is not None else None
-    # Opt-in (trainer option config.tower_streams = 2, default 1): the text tower on a side stream beside the image
+    # Trainer option config.tower_streams (default 2 since round 6; executors built outside a trainer start at 1): the text tower on a side stream beside the image
     # tower.  The towers share nothing until the loss (two_towers.py:56-75); their persistent GEMMs each fill the
     # grid, so what the second stream buys is the other tower's workgroups in the ragged last round of a launch
     # (text N = 768 GEMMs at 512 pairs: 1.5 rounds).  Same kernels on the same inputs: identical results.

@@ -121,8 +121,10 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     store.zero_grad()
     n = _img_shape(images)[0]
     ex = model.executor(store, "", _img_shape(images), tuple(labels.shape))
-    # opt-in: text tower on a side stream beside the image tower (TwoTowersExec; same kernels, identical results)
-    ex.streams = int(config.get("tower_streams", 1) or 1)
+    # default since round 6: the text tower on a side stream beside the image tower (TwoTowersExec; the towers share
+    # nothing until the loss, two_towers.py:56-75; same kernels on the same inputs, identical results).
+    # config.tower_streams = 1 puts both towers back on the caller's stream.
+    ex.streams = int(config.get("tower_streams", 2) or 1)
     img_frozen = all(e in store.frozen for e in store.entries if e.startswith("img/"))
     txt_frozen = all(e in store.frozen for e in store.entries if e.startswith("txt/"))
     t_param = store.t("t")

@@ -388,7 +388,7 @@ def test_l16_336_siglip_step_n16(dev):
 
 @pytest.mark.parametrize("micro", [0, 4])
 def test_towers_on_two_streams_change_nothing(dev, micro):
-  """config.tower_streams = 2 (opt-in): the text tower runs on a side stream beside the image tower, forward and
+  """config.tower_streams = 2 (the default since round 6; 1 = both towers on the caller's stream): the text tower runs on a side stream beside the image tower, forward and
   backward, with and without micro-batches.  Same kernels on the same inputs: loss, gradient norm and every gradient
   agree with the one-stream step (LayerNorm scale / bias gradients are fp32 atomics: summation order only)."""
   import bv_oracle as O
