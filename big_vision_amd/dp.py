@@ -286,10 +286,11 @@ RESERVED_CUS = int(os.environ.get("BV_RESERVED_CUS", "4"))
 
 class reserve_cus_for_collectives:
   """`with reserve_cus_for_collectives(comm):` around the part of a step whose kernels overlap RCCL
-  traffic (the backward).  No-op on one rank and without a GPU library."""
+  traffic (the backward).  No-op on an inactive communicator (one rank without forced collectives) and without a
+  GPU library."""
 
   def __init__(self, comm):
-    self.on = bool(comm is not None and comm.active and comm.size > 1 and torch.cuda.is_available())
+    self.on = bool(comm is not None and comm.active and torch.cuda.is_available())
 
   def __enter__(self):
     if self.on:

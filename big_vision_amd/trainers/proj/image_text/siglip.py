@@ -106,7 +106,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
   assert "mixup" not in config, "Mixup is not supported for SigLIP."
   micro = int(config.get("microbatch", 0) or 0)
   state_cache = {"keep_n": 0, "light": None, "per_ctx": {}}
-  if comm.size > 1 and config.get("overlap_grad_sync", True):
+  if comm.active and config.get("overlap_grad_sync", True):
     dp.warn_if_overlap_is_uncapped()   # the persistent GEMMs leave dp.RESERVED_CUS CUs to RCCL: cap its channels
 
   def update_fn(train_state, rng, batch):
@@ -132,7 +132,9 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
     # N > 1: the gradient all-reduce overlaps the (last) backward, see dp.GradSync
     # "fsdp" placement: every gradient range is summed onto its owner only (dp.GradShardSync), same overlap
     sharded = getattr(opt, "sharded", False)
-    overlap = comm.size > 1 and config.get("overlap_grad_sync", True)
+    # (comm.active: N > 1 ranks, or a ONE-rank group with forced collectives - bench.py's rank512_rccl and
+    # tests/test_dp_nccl_gpu.py run the overlapped path, CU reservation included, exactly as N > 1 does)
+    overlap = comm.active and config.get("overlap_grad_sync", True)
     sync = (opt.grad_sync() if sharded else dp.GradSync(comm, store.grad)) if overlap else None
 
     if micro and n > micro:
