@@ -1,0 +1,31 @@
+"""jax stand-in (see ../README.md): enough of the top-level namespace for the reference's model files to import and
+for their `__call__` bodies to run on numpy float64."""
+from . import numpy  # noqa: F401  (jax.numpy)
+from . import tree, random, nn, lax  # noqa: F401
+
+Array = object
+
+
+class _Policies:
+  """jax.checkpoint_policies: vit.Encoder looks its remat policy up by name; remat is the identity here."""
+  nothing_saveable = "nothing_saveable"
+  dots_with_no_batch_dims_saveable = "dots_with_no_batch_dims_saveable"
+
+
+checkpoint_policies = _Policies()
+
+
+def tree_map(f, tree_, *rest):
+  return tree.map(f, tree_, *rest)
+
+
+def local_devices():
+  return []
+
+
+def device_count():
+  return 1
+
+
+def process_index():
+  return 0

@@ -1,0 +1,13 @@
+"""jax.nn pieces the model files reach through flax.linen (gelu, softmax)."""
+import numpy as np
+
+
+def gelu(x, approximate=True):
+  assert approximate, "the reference calls nn.gelu with its default (tanh form)"
+  return 0.5 * x * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (x + 0.044715 * x ** 3)))
+
+
+def softmax(x, axis=-1):
+  m = np.max(x, axis=axis, keepdims=True)
+  e = np.exp(x - m)
+  return e / np.sum(e, axis=axis, keepdims=True)

@@ -1,0 +1,190 @@
+"""Executes the reference's own model files and writes what they produce as golden fixtures.
+
+TEST INFRASTRUCTURE (oracle/): run by hand or by tests/test_reference_wiring_cpu.py, never by the product.
+
+  python oracle/run_reference_wiring.py [out_dir]          (default tests/golden/)
+
+`/root/reference/big_vision/models/vit.py`, `models/proj/image_text/text_transformer.py`, `two_towers.py`,
+`models/common.py` and `utils.py` are imported UNMODIFIED, from where they lie, over the stand-ins of
+`oracle/refshim/` (jax / flax / absl / ... are not installed; see oracle/refshim/README.md for what that does and does
+not pin).  For every case below the reference `Model` is built from a config, initialised, its parameters are jittered
+(so that zero-initialised leaves - biases, cls token, zero-init head - carry signal) and applied to a seeded input.
+One `refwiring_<case>.npz` per case: `param/<leaf name>` (the reference's '/'-joined names), `in/image`, `in/text`,
+`out/<key>` for every array of the returned `out` dict (nested dicts flattened with '/'), `z/img`, `z/txt` (or `y`
+for a single tower) and `meta` (JSON: the config, the ordered key lists).  float64 throughout."""
+import json
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REFERENCE = os.environ.get("BV_REFERENCE_ROOT", "/root/reference")
+
+
+def _isolate_imports():
+  """`big_vision` must resolve to the REFERENCE, not to this repository's alias package of the same name."""
+  drop = {REPO, ""}
+  sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO and p not in drop]
+  sys.path.insert(0, REFERENCE)
+  sys.path.insert(0, os.path.join(HERE, "refshim"))
+  for m in list(sys.modules):
+    if m == "big_vision" or m.startswith("big_vision."):
+      del sys.modules[m]
+
+
+TINY_IMG = dict(width=32, depth=2, mlp_dim=64, num_heads=2, patch_size=(8, 8))
+TINY_TXT = dict(width=32, depth=2, mlp_dim=64, num_heads=2, vocab_size=50)
+ONE_IMG, ONE_TXT = dict(TINY_IMG, depth=1), dict(TINY_TXT, depth=1)     # branch variants: one block keeps the fixtures small
+
+CASES = {
+    # --- models/vit.py:186-276: every pool_type / posemb / rep_size / head branch, loop and scan layouts
+    "vit_gap_learn": ("vit", dict(num_classes=10, **ONE_IMG, pool_type="gap", posemb="learn")),
+    "vit_gap_headinit": ("vit", dict(num_classes=10, **ONE_IMG, pool_type="gap", head_zeroinit=False)),
+    "vit_map": ("vit", dict(num_classes=12, **TINY_IMG, pool_type="map")),
+    "vit_map_nohead": ("vit", dict(num_classes=None, **ONE_IMG, pool_type="map")),
+    "vit_tok": ("vit", dict(num_classes=None, **ONE_IMG, pool_type="tok")),
+    "vit_0": ("vit", dict(num_classes=7, **ONE_IMG, pool_type="0")),
+    "vit_sincos_rep": ("vit", dict(num_classes=10, **ONE_IMG, pool_type="gap", posemb="sincos2d", rep_size=True)),
+    "vit_rep16": ("vit", dict(num_classes=10, **ONE_IMG, pool_type="gap", rep_size=16)),
+    "vit_variant_mu16": ("vit", dict(num_classes=5, variant="mu/16", pool_type="map")),
+    "vit_scan": ("vit", dict(num_classes=12, **TINY_IMG, pool_type="map", scan=True)),
+    # --- models/proj/image_text/text_transformer.py:55-99: every pool_type
+    "txt_last": ("txt", dict(num_classes=16, **TINY_TXT, pool_type="last")),
+    "txt_first": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="first")),
+    "txt_mean": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="mean")),
+    "txt_max": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="max")),
+    "txt_map": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="map")),
+    "txt_nohead": ("txt", dict(num_classes=0, **ONE_TXT, pool_type="last")),
+    "txt_scan": ("txt", dict(num_classes=16, **TINY_TXT, pool_type="last", scan=True)),
+    # --- models/proj/image_text/two_towers.py:28-90
+    "two_map_last_bias": ("two", dict(image=dict(**TINY_IMG, pool_type="map"), text=dict(**TINY_TXT), out_dim=(None, 32),
+                                      temperature_init=10.0, bias_init=-10.0)),
+    "two_tok_int_outdim": ("two", dict(image=dict(**ONE_IMG, pool_type="tok"), text=dict(**ONE_TXT), out_dim=24,
+                                       temperature_init=2.0)),
+    "two_image_only": ("two", dict(image=dict(**ONE_IMG, pool_type="map"), text=dict(**ONE_TXT), out_dim=(None, 32),
+                                   temperature_init=10.0, bias_init=-2.71), dict(text=False)),
+    "two_text_only": ("two", dict(image=dict(**ONE_IMG, pool_type="map"), text=dict(**ONE_TXT), out_dim=(None, 32),
+                                  temperature_init=10.0, bias_init=-2.71), dict(image=False)),
+    "two_scan": ("two", dict(image=dict(**TINY_IMG, pool_type="map", scan=True), text=dict(**TINY_TXT, scan=True),
+                             out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0)),
+}
+
+
+def _flatten(tree, prefix=""):
+  out = []
+  for k, v in tree.items():
+    name = f"{prefix}{k}"
+    if isinstance(v, dict):
+      out.extend(_flatten(v, name + "/"))
+    elif v is not None:
+      out.append((name, v))
+  return out
+
+
+def _jitter(params, np):
+  def walk(t, prefix):
+    for k in t:
+      name = f"{prefix}{k}"
+      if isinstance(t[k], dict):
+        walk(t[k], name + "/")
+      else:
+        g = np.random.default_rng([7, zlib.crc32(name.encode())])
+        t[k] = np.asarray(t[k], np.float64) + 0.05 * g.standard_normal(np.shape(t[k]))
+  walk(params, "")
+
+
+def run_case(name, out_dir):
+  import jax
+  import numpy as np
+  kind, cfg, *rest = CASES[name]
+  use = dict(image=True, text=True)
+  use.update(rest[0] if rest else {})
+  g = np.random.default_rng([11, zlib.crc32(name.encode())])
+  res = 32
+  image = g.uniform(-1.0, 1.0, (2, res, res, 3))
+  text = g.integers(2, 50, (2, 8)).astype(np.int32)
+  text[:, 6:] = 1                                   # sticky EOS / padding id 1
+  arrays, meta = {}, {"case": name, "kind": kind, "config": cfg}
+  if kind == "vit":
+    from big_vision.models import vit
+    model = vit.Model(**cfg)
+    params = model.init(jax.random.PRNGKey(0), image)["params"]
+    _jitter(params, np)
+    y, out = model.apply({"params": params}, image, train=False)
+    arrays.update({"in/image": image, "y": y})
+  elif kind == "txt":
+    from big_vision.models.proj.image_text import text_transformer
+    model = text_transformer.Model(**cfg)
+    params = model.init(jax.random.PRNGKey(0), text)["params"]
+    _jitter(params, np)
+    y, out = model.apply({"params": params}, text, train=False)
+    arrays.update({"in/text": text, "y": y})
+  else:
+    from big_vision.models.proj.image_text import two_towers
+    model = two_towers.Model(**cfg)
+    params = model.init(jax.random.PRNGKey(0), image, text)["params"]      # both towers exist in the tree
+    _jitter(params, np)
+    im = image if use["image"] else None
+    tx = text if use["text"] else None
+    zimg, ztxt, out = model.apply({"params": params}, im, tx)
+    if im is not None:
+      arrays.update({"in/image": image, "z/img": zimg})
+    if tx is not None:
+      arrays.update({"in/text": text, "z/txt": ztxt})
+    meta["inputs"] = use
+  flat_p, flat_o = _flatten(params), _flatten(out)
+  meta["param_names"] = [n for n, _ in flat_p]
+  meta["param_shapes"] = {n: list(np.shape(v)) for n, v in flat_p}
+  meta["out_keys"] = [n for n, _ in flat_o]
+  arrays.update({f"param/{n}": np.asarray(v, np.float64) for n, v in flat_p})
+  arrays.update({f"out/{n}": np.asarray(v, np.float64) for n, v in flat_o})
+  arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)
+  np.savez_compressed(os.path.join(out_dir, f"refwiring_{name}.npz"), **arrays)
+  return meta
+
+
+def scan_roundtrip(out_dir):
+  """The reference's own layout converters (vit.py:363-405) on the reference's own scan model: applying the LOOP model
+  to scan_to_pyloop(params of the scan model) must give the scan model's output.  Written next to the fixtures."""
+  import jax
+  import numpy as np
+  from big_vision.models import vit
+  cfg = dict(CASES["vit_scan"][1])
+  image = np.random.default_rng(5).uniform(-1, 1, (2, 32, 32, 3))
+  scan_model = vit.Model(**cfg)
+  p_scan = scan_model.init(jax.random.PRNGKey(0), image)["params"]
+  _jitter(p_scan, np)
+  y_scan, _ = scan_model.apply({"params": p_scan}, image)
+  cfg["scan"] = False
+  loop_model = vit.Model(**cfg)
+  p_loop = vit.scan_to_pyloop(p_scan)
+  y_loop, _ = loop_model.apply({"params": p_loop}, image)
+  back = vit.pyloop_to_scan(p_loop)
+  fb, fs = dict(_flatten(back)), dict(_flatten(p_scan))
+  same = fb.keys() == fs.keys() and all(np.array_equal(fb[k], fs[k]) for k in fs)
+  return {"max_abs_diff_scan_vs_loop": float(np.max(np.abs(y_scan - y_loop))), "pyloop_to_scan_inverts": bool(same),
+          "loop_names": [n for n, _ in _flatten(p_loop)]}
+
+
+def main():
+  out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "tests", "golden")
+  if not os.path.isdir(os.path.join(REFERENCE, "big_vision")):
+    raise SystemExit(f"{REFERENCE}/big_vision not found: the reference's files are needed to run them")
+  _isolate_imports()
+  os.makedirs(out_dir, exist_ok=True)
+  import big_vision
+  assert os.path.abspath(os.path.dirname(big_vision.__file__ or big_vision.__path__[0])).startswith(REFERENCE), big_vision
+  summary = {}
+  for name in CASES:
+    meta = run_case(name, out_dir)
+    summary[name] = {"params": len(meta["param_names"]), "out_keys": len(meta["out_keys"])}
+    print(f"{name:22s} {len(meta['param_names']):3d} parameters, {len(meta['out_keys']):3d} out entries", flush=True)
+  summary["scan_roundtrip"] = scan_roundtrip(out_dir)
+  print("scan round trip:", {k: v for k, v in summary["scan_roundtrip"].items() if k != "loop_names"})
+  with open(os.path.join(out_dir, "refwiring_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+  main()

@@ -1,0 +1,86 @@
+"""The PRODUCT (HIP kernels through the C ABI) on the fixtures the reference's own model files produced
+(tests/golden/refwiring_*.npz, oracle/run_reference_wiring.py; "reference wiring over restated primitives",
+oracle/refshim/README.md): `Model.apply` with the reference's parameter tree, loaded by the reference's leaf names,
+must return the reference's outputs within the bf16-operand tolerance of SURVEY.md 8c, and an `out` dict with exactly
+the reference's keys (8b contract) whose entries agree too."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import run_reference_wiring as RW  # noqa: E402  (the case table only)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _nest(flat):
+  tree = {}
+  for k, v in flat.items():
+    node = tree
+    *parents, last = k.split("/")
+    for p in parents:
+      node = node.setdefault(p, {})
+    node[last] = v
+  return tree
+
+
+def _flat(tree, prefix=""):
+  out = {}
+  for k, v in tree.items():
+    if isinstance(v, dict):
+      out.update(_flat(v, f"{prefix}{k}/"))
+    elif v is not None:
+      out[f"{prefix}{k}"] = v
+  return out
+
+
+def _close(got, ref, what):
+  got = got.detach().float().cpu().numpy().astype(np.float64)
+  assert got.shape == ref.shape, (what, got.shape, ref.shape)
+  scale = max(1e-6, float(np.sqrt(np.mean(ref * ref))))
+  err = float(np.max(np.abs(got - ref)))
+  # bf16 matmul operands, fp32 accumulation and residual stream: 2e-2 of the tensor's rms (unit-norm embeddings:
+  # SURVEY 8c's max-abs 2e-2), a few blocks deep at toy widths
+  assert err <= 3e-2 * scale + 1e-3, (what, err, scale)
+
+
+@pytest.mark.parametrize("name", sorted(RW.CASES))
+def test_product_matches_the_executed_reference(name):
+  from big_vision_amd.models import vit
+  from big_vision_amd.models.proj.image_text import text_transformer, two_towers
+  z = np.load(os.path.join(GOLDEN, f"refwiring_{name}.npz"))
+  meta = json.loads(bytes(z["meta"]).decode())
+  cfg, kind = meta["config"], meta["kind"]
+  dev = torch.device("cuda", 0)
+  params = _nest({k[len("param/"):]: torch.from_numpy(np.asarray(z[k], np.float32)) for k in z.files if k.startswith("param/")})
+  image = torch.from_numpy(z["in/image"].astype(np.float32)).to(dev) if "in/image" in z.files else None
+  text = torch.from_numpy(z["in/text"].astype(np.int32)).to(dev) if "in/text" in z.files else None
+  if kind == "vit":
+    if "patch_size" in cfg:
+      cfg["patch_size"] = tuple(cfg["patch_size"])
+    y, out = vit.Model(**cfg).apply({"params": params}, image)
+    ys = {"y": y}
+  elif kind == "txt":
+    y, out = text_transformer.Model(**cfg).apply({"params": params}, text)
+    ys = {"y": y}
+  else:
+    cfg["image"]["patch_size"] = tuple(cfg["image"]["patch_size"])
+    if not isinstance(cfg["out_dim"], int):
+      cfg["out_dim"] = tuple(cfg["out_dim"])
+    zi, zt, out = two_towers.Model(**cfg).apply({"params": params}, image, text)
+    ys = {k: v for k, v in (("z/img", zi), ("z/txt", zt)) if v is not None}
+  torch.cuda.synchronize()
+  for k, v in ys.items():
+    _close(v, z[k], k)
+  got = _flat(out)
+  want = meta["out_keys"]
+  assert set(got) == set(want), (sorted(set(got) - set(want)), sorted(set(want) - set(got)))
+  for k in want:
+    if torch.is_tensor(got[k]):
+      _close(got[k], z[f"out/{k}"], k)
