@@ -685,7 +685,33 @@ def main():
     dt = float(t.item())
     loss = float(meas["training_loss"].item())
     siglip.check_finite(meas)
-    res = dict(dt=dt, host_dt=host_dt, host_unblocked_ms=host_unblocked_ms, loss=loss, obs=obs,
+    # One EXTRA, untimed step with both towers on one stream and the same per-launch events: launches are serialised,
+    # so the family's busy time there is exclusive by construction.  Reported as `roofline.one_stream` beside the
+    # timed region's figure (on two streams a family launch that runs beside the other tower's LayerNorm / attention
+    # kernels in its last, ragged round is charged that whole interval).
+    obs1 = None
+    if roofline and int(config.get("tower_streams", 2) or 1) == 2:
+      try:
+        torch.cuda.empty_cache()          # blocks cached by the side stream's pool are of no use to a one-stream step
+        config.tower_streams = 1
+        obs1 = GemmObserver()
+        _lib.observer = obs1
+        comm.barrier()
+        torch.cuda.synchronize()
+        obs1.start()
+        t1 = time.perf_counter()
+        state, meas1 = update_fn(state, None, batch)
+        torch.cuda.synchronize()
+        obs1.wall_s = time.perf_counter() - t1
+        obs1.active = False
+        del meas1
+      except Exception as e:   # the headline must not depend on the extra step
+        obs1 = None
+        print(f"one-stream roofline step failed: {type(e).__name__}: {e}", file=sys.stderr)
+      finally:
+        _lib.observer = None
+        config.tower_streams = 2
+    res = dict(dt=dt, host_dt=host_dt, host_unblocked_ms=host_unblocked_ms, loss=loss, obs=obs, obs_one_stream=obs1,
                keep_n=update_fn.state_cache["keep_n"], light=update_fn.state_cache["light"],
                peak=torch.cuda.max_memory_allocated(dev), tower_streams=int(config.get("tower_streams", 2) or 1))
     del state, update_fn, meas, model
@@ -719,6 +745,12 @@ def main():
   roof = None
   if not args.no_roofline:
     roof = roofline_object(obs, dt)
+    if r.get("obs_one_stream") is not None:
+      one = roofline_object(r["obs_one_stream"], r["obs_one_stream"].wall_s)
+      roof["one_stream"] = {"frac": one["frac"], "achieved": one["achieved"], "avg_launch_us": one["avg_launch_us"],
+                            "launches": one["launches"], "ms_of_this_step": 1e3 * r["obs_one_stream"].wall_s,
+                            "what": "the same launches serialised: one extra, untimed step with config.tower_streams = 1 "
+                                    "after the timed region (per-launch HIP events are exclusive there)"}
     traffic, traffic_src = pmc_traffic(world, n, args.microbatch)
     traffic_live, traffic_detail = False, None
     if world == 1 and not args.no_live_pmc and args.global_batch == GLOBAL_BATCH:
