@@ -1,7 +1,7 @@
 """jax stand-in (see ../README.md): enough of the top-level namespace for the reference's model files to import and
 for their `__call__` bodies to run on numpy float64."""
 from . import numpy  # noqa: F401  (jax.numpy)
-from . import tree, random, nn, lax  # noqa: F401
+from . import tree, random, nn, lax, scipy  # noqa: F401
 
 Array = object
 
@@ -24,7 +24,18 @@ def local_devices():
 
 
 def device_count():
-  return 1
+  return lax.device_count()
+
+
+class _Config:
+  def parse_flags_with_absl(self):
+    pass
+
+  def update(self, *a, **k):
+    pass
+
+
+config = _Config()
 
 
 def process_index():

@@ -11,3 +11,9 @@ def softmax(x, axis=-1):
   m = np.max(x, axis=axis, keepdims=True)
   e = np.exp(x - m)
   return e / np.sum(e, axis=axis, keepdims=True)
+
+
+def log_sigmoid(x):
+  """-softplus(-x), the stable form."""
+  x = np.asarray(x, np.float64)
+  return np.minimum(x, 0.0) - np.log1p(np.exp(-np.abs(x)))

@@ -1,7 +1,7 @@
 """jax.numpy stand-in = numpy, with ONE policy: every floating-point array is float64, whatever float dtype is asked
 for (../README.md: dtype promotion is not pinned here; the comparison against the fp64 oracle needs full precision)."""
 import numpy as _np
-from numpy import (arange, concatenate, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
+from numpy import (arange, roll, eye, diag, dot, clip, not_equal, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
                    linalg, maximum, minimum, where, stack, transpose, zeros_like, ones_like, tanh, abs, max, min,
                    argmin, argmax, take, expand_dims, squeeze, ndarray, pi, newaxis, inf, int32, int64, uint32, bool_)
 
@@ -40,3 +40,12 @@ def ones(shape, dtype=float32):
 
 def zeros(shape, dtype=float32):
   return _np.zeros(shape, _dt(dtype))
+
+
+def concatenate(arrays, axis=0):
+  """numpy's, plus jax's handling of ONE array argument (its leading axis is the sequence: axes 0 and 1 are merged,
+  also when that leaves zero rows - the "no other devices" case of the reference's all_gather on one device)."""
+  if isinstance(arrays, _np.ndarray):
+    assert axis == 0 and arrays.ndim >= 2
+    return arrays.reshape((arrays.shape[0] * arrays.shape[1],) + arrays.shape[2:])
+  return _np.concatenate(arrays, axis)

@@ -5,7 +5,8 @@ TEST INFRASTRUCTURE (oracle/): run by hand or by tests/test_reference_wiring_cpu
   python oracle/run_reference_wiring.py [out_dir]          (default tests/golden/)
 
 `/root/reference/big_vision/models/vit.py`, `models/proj/image_text/text_transformer.py`, `two_towers.py`,
-`models/common.py` and `utils.py` are imported UNMODIFIED, from where they lie, over the stand-ins of
+`models/common.py`, `utils.py` and (for the three loss functions, run_losses) `trainers/proj/image_text/
+_deprecated_contrastive.py` are imported UNMODIFIED, from where they lie, over the stand-ins of
 `oracle/refshim/` (jax / flax / absl / ... are not installed; see oracle/refshim/README.md for what that does and does
 not pin).  For every case below the reference `Model` is built from a config, initialised, its parameters are jittered
 (so that zero-initialised leaves - biases, cls token, zero-init head - carry signal) and applied to a seeded input.
@@ -167,6 +168,59 @@ def scan_roundtrip(out_dir):
           "loop_names": [n for n, _ in _flatten(p_loop)]}
 
 
+def _stub_reference_modules():
+  """`_deprecated_contrastive.py` imports three sibling REFERENCE modules at its top that drag in tensorflow / tf.data /
+  optax (`big_vision.evaluators.common`, `big_vision.input_pipeline`, `big_vision.optax`).  None of them is touched by
+  the loss functions executed here, so empty modules stand in for them (the trainer file itself stays unmodified)."""
+  import types
+  import big_vision
+  for name in ("big_vision.evaluators", "big_vision.evaluators.common", "big_vision.input_pipeline", "big_vision.optax"):
+    if name not in sys.modules:
+      m = types.ModuleType(name)
+      m.__path__ = []
+      sys.modules[name] = m
+      parent, _, leaf = name.rpartition(".")
+      setattr(sys.modules[parent], leaf, m)
+
+
+LOSS_WORLDS = (1, 2, 4)
+
+
+def run_losses(out_dir):
+  """trainers/proj/image_text/_deprecated_contrastive.py:80-200 - softmax_loss, sigmoid_loss, chunked_sigmoid_loss - the
+  reference's own per-device functions, run as N virtual devices (jax.lax collectives emulated, refshim/jax/lax.py) on
+  seeded unit-norm embeddings: per device the loss and every entry of its measurement dict."""
+  import jax
+  import numpy as np
+  _stub_reference_modules()
+  from big_vision.trainers.proj.image_text import _deprecated_contrastive as C
+  g = np.random.default_rng(123)
+  B, E = 16, 24
+  zimg = g.standard_normal((B, E)); zimg /= np.linalg.norm(zimg, axis=1, keepdims=True)
+  ztxt = zimg * 0.6 + 0.8 * g.standard_normal((B, E)); ztxt /= np.linalg.norm(ztxt, axis=1, keepdims=True)
+  t, b = 7.5, -4.25
+  arrays = {"zimg": zimg, "ztxt": ztxt, "t": np.float64(t), "b": np.float64(b)}
+  keys = {}
+  for world in LOSS_WORLDS:
+    n = B // world
+    shards = [(zimg[r * n:(r + 1) * n], ztxt[r * n:(r + 1) * n]) for r in range(world)]
+    runs = {
+        "sigmoid": lambda zi, zt: C.sigmoid_loss(zi, zt, t, bias=b),
+        "chunked_sigmoid": lambda zi, zt: C.chunked_sigmoid_loss(zi, zt, t, bias=b),
+        "softmax": lambda zi, zt: C.softmax_loss(zi, zt, t),
+    }
+    for kind, fn in runs.items():
+      res = jax.lax.spmd(fn, world, shards)
+      for r, (l, extras) in enumerate(res):
+        arrays[f"{kind}/w{world}/r{r}/loss"] = np.float64(l)
+        for k, v in extras.items():
+          arrays[f"{kind}/w{world}/r{r}/{k}"] = np.float64(v)
+        keys[kind] = sorted(extras)
+  arrays["meta"] = np.frombuffer(json.dumps({"worlds": LOSS_WORLDS, "extras": keys, "B": B, "E": E}, sort_keys=True).encode(), np.uint8)
+  np.savez_compressed(os.path.join(out_dir, "refwiring_losses.npz"), **arrays)
+  return keys
+
+
 def main():
   out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "tests", "golden")
   if not os.path.isdir(os.path.join(REFERENCE, "big_vision")):
@@ -180,6 +234,8 @@ def main():
     meta = run_case(name, out_dir)
     summary[name] = {"params": len(meta["param_names"]), "out_keys": len(meta["out_keys"])}
     print(f"{name:22s} {len(meta['param_names']):3d} parameters, {len(meta['out_keys']):3d} out entries", flush=True)
+  summary["losses"] = run_losses(out_dir)
+  print("losses:", summary["losses"])
   summary["scan_roundtrip"] = scan_roundtrip(out_dir)
   print("scan round trip:", {k: v for k, v in summary["scan_roundtrip"].items() if k != "loop_names"})
   with open(os.path.join(out_dir, "refwiring_summary.json"), "w") as f:

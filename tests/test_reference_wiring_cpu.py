@@ -189,3 +189,43 @@ def test_no_reference_source_under_the_stand_ins():
   for path in glob.glob(os.path.join(ROOT, "oracle", "refshim", "**", "*.py"), recursive=True):
     src = open(path).read()
     assert "Big Vision Authors" not in src and "class Encoder1DBlock" not in src and "class MAPHead" not in src, path
+
+
+# ------------------------------------------------------------------------------------------------- losses --
+def _loss_fixture():
+  z = np.load(os.path.join(GOLDEN, "refwiring_losses.npz"))
+  return z, json.loads(bytes(z["meta"]).decode())
+
+
+@pytest.mark.parametrize("world", RW.LOSS_WORLDS)
+def test_oracle_losses_reproduce_the_executed_reference(world):
+  """trainers/proj/image_text/_deprecated_contrastive.py:80-200 executed as `world` virtual devices (run_losses) vs the
+  restated per-device losses and measurement dicts of the oracle - and vs the GLOBAL form of the GSPMD trainer
+  (siglip.py:291-306), which the mean over devices of the per-device sigmoid loss must equal."""
+  z, meta = _loss_fixture()
+  zimg, ztxt = torch.from_numpy(z["zimg"]), torch.from_numpy(z["ztxt"])
+  t, b = float(z["t"]), float(z["b"])
+  n = zimg.shape[0] // world
+  zi = [zimg[r * n:(r + 1) * n] for r in range(world)]
+  zt = [ztxt[r * n:(r + 1) * n] for r in range(world)]
+  close = lambda a, ref, what: (abs(float(a) - float(ref)) <= 1e-10 * max(1.0, abs(float(ref)))) or pytest.fail(f"{what}: {float(a)} vs {float(ref)}")
+  sig, chk, smx = [], [], []
+  for r in range(world):
+    l = O.sigmoid_loss_per_device(zi[r], zt, r, t, b)
+    close(l, z[f"sigmoid/w{world}/r{r}/loss"], f"sigmoid r{r}")
+    sig.append(float(z[f"sigmoid/w{world}/r{r}/loss"]))
+    stats = O.sigmoid_logit_stats_per_device(zi[r], zt, r, t, b)
+    assert sorted(stats) == meta["extras"]["sigmoid"]
+    for k, v in stats.items():
+      close(v, z[f"sigmoid/w{world}/r{r}/{k}"], f"sigmoid {k} r{r}")
+    lc = O.chunked_sigmoid_loss_per_device(zi[r], zt, r, t, b)
+    close(lc, z[f"chunked_sigmoid/w{world}/r{r}/loss"], f"chunked r{r}")
+    for k in meta["extras"]["chunked_sigmoid"]:          # the local subset of the same dict
+      close(stats[k], z[f"chunked_sigmoid/w{world}/r{r}/{k}"], f"chunked {k} r{r}")
+    chk.append(float(lc))
+    smx.append(float(O.softmax_loss_per_device(zi[r], zt[r], zi, zt, r, t)))
+  for r in range(world):                                  # softmax_loss returns the pmean over devices (:100)
+    close(np.mean(smx), z[f"softmax/w{world}/r{r}/loss"], f"softmax r{r}")
+  glob, _ = O.siglip_loss_global(zimg, ztxt, t, b)
+  close(np.mean(sig), glob, "mean over devices of the per-device sigmoid loss vs the global form")
+  close(np.mean(chk), glob, "chunked form vs the global form")
