@@ -26,7 +26,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  workloads and the per-rank shapes of the headline on this one GPU, a few steps each:
                  c2 (ViT-B/16 tower fwd+bwd, batch 256), c4_rank (SigLIP L/16@336, the 1024 pairs one of
                  8 ranks owns), c5b (LiT step with the BERT-base text tower, batch 512), rank512 /
-                 rank1024 (the 4096 / 8 and 4096 / 4 pairs one rank of the headline owns).  Each entry:
+                 rank1024 (the 4096 / 8 and 4096 / 4 pairs one rank of the headline owns; *_one_stream: the same with
+                 config.tower_streams = 1, the A/B partner of the two-stream default), rank512_rccl.  Each entry:
                  value, unit, ms_per_step, steps, roofline_frac (the same GEMM family, live HIP
                  events), step_frac where the workload's matmul FLOPs are known, peak_hbm_gb.
 """
@@ -517,17 +518,15 @@ def workload_c5b(dev, steps, stream="float32"):
 
 def workload_rank_shape(dev, steps, n, stream="float32", tower_streams=None):
   """The pairs ONE rank of the headline owns at N = 4096 / n GPUs (single pass, full contexts, loss over the local
-  pairs only: no peers on a single device).  tower_streams = 2: the trainer's opt-in config.tower_streams (text tower
-  on a side stream beside the image tower; identical results) - its kernels overlap, so per-launch event times are
-  not exclusive and the entry carries no roofline_frac."""
+  pairs only: no peers on a single device).  tower_streams = 1: both towers on one stream (the trainer's default since
+  round 6 is 2: text tower on a side stream beside the image tower; identical results) - the A/B partner of the
+  default entry."""
   r = workload_siglip(dev, steps, IMAGE_CFG, TEXT_CFG, EMB, n=n, res=RES, seq=SEQ, micro=MICRO, stream=stream,
                       gflop_per_pair=MATMUL_GFLOP_PER_PAIR, tower_streams=tower_streams,
                       label=f"headline model, the {n} pairs one of {GLOBAL_BATCH // n} ranks owns (no collectives)"
-                            + (", config.tower_streams = 2" if tower_streams == 2 else ""))
+                            + (", config.tower_streams = 1" if tower_streams == 1 else ""))
   r["metric"] = (f"image-text pairs/sec per GPU at {n} pairs per GPU (rank shape of the headline at N = {GLOBAL_BATCH // n})"
-                 + (", text tower on a second stream (opt-in config.tower_streams = 2)" if tower_streams == 2 else ""))
-  if tower_streams == 2:
-    r["roofline"] = dict(r["roofline"], frac=None)
+                 + (", both towers on ONE stream (config.tower_streams = 1)" if tower_streams == 1 else ""))
   return r
 
 
@@ -565,8 +564,8 @@ def configs_object(dev, steps=3):
                   ("c5b", lambda: workload_c5b(dev, steps)), ("rank512", lambda: workload_rank_shape(dev, steps, 512)),
                   ("rank1024", lambda: workload_rank_shape(dev, steps, 1024)),
                   ("rank512_rccl", lambda: workload_rank_shape_rccl(dev, steps, 512)),
-                  ("rank512_two_streams", lambda: workload_rank_shape(dev, steps, 512, tower_streams=2)),
-                  ("rank1024_two_streams", lambda: workload_rank_shape(dev, steps, 1024, tower_streams=2))):
+                  ("rank512_one_stream", lambda: workload_rank_shape(dev, steps, 512, tower_streams=1)),
+                  ("rank1024_one_stream", lambda: workload_rank_shape(dev, steps, 1024, tower_streams=1))):
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)

@@ -36,7 +36,9 @@
 #define A5_UNROLL_1A 16   // fully unrolled (like 1b and phase 2): every LDS address is a base register + an immediate
 #endif
 // A5_ABL != 0 only in tools/probes/attn5_probe.hip (ablations, results are garbage): 1 = no phase 1a loop, 2 = no
-// phase 1b loop, 4 = no phase 2 loop, 16 = no global stores, 32 = the loader waves load nothing; A5_STAMPS: s_memtime
+// phase 1b loop, 4 = no phase 2 loop, 16 = no global stores, 32 = the loader waves load nothing, 64 = every second
+// fragment step re-uses the previous step's Q / dO / K operand reads (HALF the operand LDS reads of all three phases,
+// same MFMA / VALU counts: the upper bound of what two key fragments per wave could save); A5_STAMPS: s_memtime
 // stamps of waves 0 / KF-1 / KF (first loader) of four mid-launch workgroups
 #ifndef A5_ABL
 #define A5_ABL 0
@@ -454,7 +456,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       Ops a = rd(0), b = a;
 #pragma unroll A5_UNROLL_1A
       for (int f = 0; f < NF; f += 2) {
-        if (f + 1 < NF) b = rd(f + 1);
+        if (f + 1 < NF) b = (A5_ABL & 64) ? a : rd(f + 1);
         done(f, go(f, a));
         if (f + 1 < NF) {
           if (f + 2 < NF) a = rd(f + 2);
@@ -532,6 +534,7 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         // the tile occupied (read above; LDS operations of one wave complete in order)
         *reinterpret_cast<s16x4*>(pwr + f * TS) = pack4(ds);
       };
+      bf16x8 gtr[4], qtr[4];   // transposed dO / Q operands of the current fragment pair
 #pragma unroll A5_UNROLL_1B
       for (int ip = 0; ip < ((A5_ABL & 2) ? 1 : KF / 2); ++ip) {
         s16x4 pp[2];
@@ -548,10 +551,12 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
         if (A5_SB_1B) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          const bf16x8 gt = trd2(tq[d] + C::OFF_G + (2 * ip) * 2048);
-          const bf16x8 qt = trd2(tq[d] + (2 * ip) * 2048);
-          dv[d] = mfma16(gt, pf, dv[d]);    // D[d = 4 lg + r][key = lr]
-          dk[d] = mfma16(qt, dsf, dk[d]);
+          if (!(A5_ABL & 64) || !(ip & 1)) {
+            gtr[d] = trd2(tq[d] + C::OFF_G + (2 * ip) * 2048);
+            qtr[d] = trd2(tq[d] + (2 * ip) * 2048);
+          }
+          dv[d] = mfma16(gtr[d], pf, dv[d]);    // D[d = 4 lg + r][key = lr]
+          dk[d] = mfma16(qtr[d], dsf, dk[d]);
         }
       }
       if constexpr (KF & 1) {
@@ -641,11 +646,15 @@ __global__ __launch_bounds__((KF + LW) * 64) void attn5_bwd_kernel(const bf16* _
       f32x4 dq[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 ktr[4];   // transposed K operands of the current fragment pair
 #pragma unroll A5_UNROLL_P2
       for (int fp = 0; fp < ((A5_ABL & 4) ? 1 : KF / 2); ++fp) {
         const bf16x8 dsf = trd2(sa + fp * 256, 128);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) dq[d] = mfma16(trd2(tk[d] + fp * 4096, 2048), dsf, dq[d]);
+        for (int d = 0; d < 4; ++d) {
+          if (!(A5_ABL & 64) || !(fp & 1)) ktr[d] = trd2(tk[d] + fp * 4096, 2048);
+          dq[d] = mfma16(ktr[d], dsf, dq[d]);
+        }
       }
       if constexpr (KF & 1) {
         const s16x4 dsf = trd(sa + (KF - 1) * 128);

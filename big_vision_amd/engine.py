@@ -176,6 +176,13 @@ class _W:
     self.kpad = None
     if self.bf.dim() == 2 and self.bf.shape[0] % 8:
       self.kpad = (self.bf.shape[0] + 7) // 8 * 8
+    # output width not a multiple of 8 (a classification head with 10 or 1000 + 1 classes, rep_size = 12): the
+    # GEMMs run on operands padded with zero columns to npad (linear_fwd / linear_bwd_w / linear_bwd_x below) and
+    # the results are cut back; only heads and pre_logits ever take this path, their GEMMs are tiny
+    self.npad = None
+    if self.bf.dim() == 2 and self.bf.shape[1] % 8:
+      self.npad = (self.bf.shape[1] + 7) // 8 * 8
+    self._np, self._np_ver = None, -1
 
   def bf_t(self):
     """[out][in] bf16 image of a 2-D (in,out) kernel, re-transposed only when the
@@ -187,14 +194,26 @@ class _W:
     if self._t_ver != ver:
       if self._t is None:
         K, N = self.bf.shape
-        self._t = (torch.zeros((N, self.kpad), device=self.bf.device, dtype=BF16) if self.kpad
-                   else torch.empty((N, K), device=self.bf.device, dtype=BF16))
-        ops.transpose_bf16(self.bf, self._t[:, :K])
+        self._t = (torch.zeros((self.npad or N, self.kpad or K), device=self.bf.device, dtype=BF16)
+                   if (self.kpad or self.npad) else torch.empty((N, K), device=self.bf.device, dtype=BF16))
+        ops.transpose_bf16(self.bf, self._t[:N, :K])
         self._t_ver = ver
         _Twins.of(self.store).add(self)
       else:
         _Twins.of(self.store).refresh(self.frozen, ver)
     return self._t
+
+  def bf_np(self):
+    """[in (padded to kpad)][out (padded to npad)] bf16 copy of a kernel with a ragged width (zero padding): the k-major
+    B operand of the dX GEMM.  Re-copied when the shadow changed."""
+    ver = self.store.static_version if self.frozen else self.store.shadow_version
+    if self._np_ver != ver:
+      K, N = self.bf.shape
+      if self._np is None:
+        self._np = torch.zeros((self.kpad or K, self.npad or N), device=self.bf.device, dtype=BF16)
+      self._np[:K, :N].copy_(self.bf)
+      self._np_ver = ver
+    return self._np
 
 
 class _Twins:
@@ -223,7 +242,7 @@ class _Twins:
     live = [w for w in (r() for r in self.members[frozen]) if w is not None]
     if self.batch[frozen] is None or len(live) != len(self.members[frozen]):
       self.members[frozen] = [weakref.ref(w) for w in live]
-      pairs = [(w.bf, w._t[:, :w.bf.shape[0]]) for w in live]
+      pairs = [(w.bf, w._t[:w.bf.shape[1], :w.bf.shape[0]]) for w in live]
       self.batch[frozen] = ops.transpose_table(pairs, live[0].bf.device) + (pairs,)
     table, n, tiles, _ = self.batch[frozen]
     ops.transpose_bf16_batched(table, n, tiles)
@@ -271,12 +290,47 @@ def record_stream_tree(obj, stream):
   walk(obj)
 
 
+def _pad_cols(t, width):
+  """[rows, N] -> [rows, width] with zero columns on the right (heads / pre_logits only: tiny tensors)."""
+  return torch.nn.functional.pad(t, (0, width - t.shape[-1]))
+
+
+def _ragged(x_bf, w: _W):
+  """True when this product needs host-side padding: a ragged OUTPUT width, or a ragged INPUT width whose activation
+  arrives unpadded (the head behind a rep_size = 12 pre_logits; the So400m/14 stem hands over padded patches)."""
+  return bool(w.npad or (w.kpad and x_bf is not None and x_bf.shape[-1] != w.kpad))
+
+
 def linear_fwd(x_bf, w: _W, b: Optional[_W], **kw):
+  if _ragged(x_bf, w):
+    assert "out" not in kw and "out2" not in kw and "aux" not in kw, "padded widths: plain epilogue only"
+    N = w.bf.shape[1]
+    if w.kpad and x_bf.shape[-1] != w.kpad:
+      x_bf = _pad_cols(x_bf, w.kpad)
+    bias = None if b is None else (_pad_cols(b.f32, w.npad) if w.npad else b.f32)
+    y = ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=bias, **kw)
+    return y[:, :N].contiguous() if w.npad else y
   return ops.gemm(x_bf, w.bf_t(), a_kmajor=True, b_kmajor=True, bias=None if b is None else b.f32, **kw)
 
 
 def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
   """dW += x^T dy (split-K atomics into the grad buffer), db += colsum(dy)."""
+  if _ragged(x_bf, w):
+    # ragged widths: the product of the zero-padded operands lands in a [K (padded)][N (padded)] scratch, its real
+    # block is added to the gradient; the bias gradient is a column sum of the (tiny) cotangent
+    K, N = w.bf.shape
+    if w.grad is not None:
+      xp = _pad_cols(x_bf, w.kpad) if (w.kpad and x_bf.shape[-1] != w.kpad) else x_bf
+      dyp = _pad_cols(dy_bf, w.npad) if w.npad else dy_bf
+      tmp = torch.zeros((w.kpad or K, w.npad or N), device=x_bf.device, dtype=F32)
+      ops.gemm(xp, dyp, a_kmajor=False, b_kmajor=False, out=tmp, epilogue=ops.EPI_ATOMIC)
+      w.grad.add_(tmp[:K, :N])
+    if b is not None and b.grad is not None:
+      if w.npad:
+        b.grad.add_((dy_bf if dy_for_bias is None else dy_for_bias).float().sum(0))
+      else:
+        ops.colsum(dy_bf if dy_for_bias is None else dy_for_bias, b.grad)
+    return
   if w.grad is not None and w.kpad:
     # padded input width: the product lands in a [kpad][out] scratch (its last rows are exactly 0: the
     # pad columns of x are) and the real rows are added to the gradient
@@ -291,6 +345,13 @@ def linear_bwd_w(x_bf, dy_bf, w: _W, b: Optional[_W], dy_for_bias=None):
 
 
 def linear_bwd_x(dy_bf, w: _W, out_dtype=BF16, **kw):
+  if w.npad or w.kpad:
+    # ragged widths: the contraction runs over the padded output width and produces the padded input width (zero rows
+    # / columns on the operands), cut back to the real one
+    K = w.bf.shape[0]
+    dyp = _pad_cols(dy_bf, w.npad) if w.npad else dy_bf
+    dx = ops.gemm(dyp, w.bf_np(), a_kmajor=True, b_kmajor=True, out_dtype=out_dtype, **kw)
+    return dx[:, :K].contiguous() if w.kpad else dx
   return ops.gemm(dy_bf, w.bf, a_kmajor=True, b_kmajor=True, out_dtype=out_dtype, **kw)
 
 
@@ -436,10 +497,11 @@ class Encoder:
   """vit.Encoder without the final encoder_norm (the caller applies it, because
   which rows it must cover depends on the pooling)."""
 
-  def __init__(self, store, prefix, depth, D, H, M):
+  def __init__(self, store, prefix, depth, D, H, M, scan=False):
     self.blocks = [Block(store, f"{prefix}/encoderblock_{i}", D, H, M) for i in range(depth)]
     self.norm = LN(store, f"{prefix}/encoder_norm")
     self.D = D
+    self.scan = bool(scan)   # presentation only: stacked leaf names and the `out` keys of the reference's scan branch
 
   def fwd(self, x, n, L, save, out=None, kv_len=None):
     """x: fp32 [n*L, D].  Returns the last block's output in the stream dtype (the callers hand it to
@@ -456,7 +518,7 @@ class Encoder:
         x1 = s[7]
         v = lambda t: t.view(n, L, -1)   # the reference's activations are [n, L, D]
         out[f"block{i:02d}"] = {"sa": v(x1 - x_in), "+sa": v(x1), "mlp": v(x - x1), "+mlp": v(x)}
-    if out is not None:
+    if out is not None and not self.scan:   # (the reference's scan branch publishes no `pre_ln` alias, vit.py:129-157)
       out["pre_ln"] = x.view(n, L, -1)
     return x, saved
 

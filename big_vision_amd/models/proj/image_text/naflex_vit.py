@@ -66,7 +66,7 @@ class NaflexExec:
     self.pos = E._W(store, f"{prefix}pos_embedding", (P * P, D))
     self.ln_pre = E.LN(store, f"{prefix}patchln_pre") if m.patchln_pre else None
     self.ln_post = E.LN(store, f"{prefix}patchln_post") if m.patchln_post else None
-    self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M)
+    self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M, scan=getattr(m, "scan", False))
     self.map = E.MAPHead(store, f"{prefix}MAPHead_0", D, H, M) if m.pool_type == "map" else None
     self.pre = (E._W(store, f"{prefix}pre_logits/kernel"), E._W(store, f"{prefix}pre_logits/bias")) if m.rep_size else None
     self.head = (E._W(store, f"{prefix}head/kernel"), E._W(store, f"{prefix}head/bias")) if m.num_classes else None

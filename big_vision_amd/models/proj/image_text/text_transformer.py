@@ -28,7 +28,7 @@ class TextExec:
     D, H, M = m.width, m.num_heads, m.mlp_dim
     self.table = E._W(store, f"{prefix}Embed_0/embedding")
     self.pos = E._W(store, f"{prefix}pos_embedding", (seq_len, D))
-    self.enc = E.Encoder(store, f"{prefix}Encoder_0", m.depth, D, H, M)
+    self.enc = E.Encoder(store, f"{prefix}Encoder_0", m.depth, D, H, M, scan=getattr(m, "scan", False))
     self.map = E.MAPHead(store, f"{prefix}MAPHead_0", D, H, M) if m.pool_type == "map" else None
     self.head = None
     if m.num_classes:

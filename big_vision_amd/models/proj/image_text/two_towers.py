@@ -260,16 +260,30 @@ class Model:
       self._execs[key] = TwoTowersExec(self, store, prefix, hw, sl)
     return self._execs[key]
 
+  def _image_shape_of(self, params):
+    """(1, H, W, 3) of the images an ad-hoc parameter tree was built for, from its learned position embedding (a
+    square grid of patches; sincos2d towers carry no such leaf: pass an image, or a tree bound to a store)."""
+    pe = params.get("img", {}).get("pos_embedding")
+    if pe is None:
+      raise ValueError("cannot size the image tower from this parameter tree (no img/pos_embedding): pass an image")
+    tokens = int(pe.shape[1])
+    side = int(round(math.sqrt(tokens)))
+    if side * side != tokens:
+      raise ValueError(f"img/pos_embedding has {tokens} positions, not a square grid: pass an image")
+    ph, pw = self.image_tower.patch_size
+    return (1, side * ph, side * pw, 3)
+
   def apply(self, variables, image, text=None, *, train=False, rngs=None, collect=True, **kw):
     del rngs, train, kw
     params = variables["params"]
     if isinstance(params, ParamTree) and params.store is not None:
       store, prefix = params.store, params.prefix
     else:
-      if image is None or text is None:
-        raise ValueError("ad-hoc parameter trees need both inputs to size the store")
-      ishape = tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape)
-      tshape = tuple(text.shape)
+      # two_towers.py:43: either input may be None.  The store holds BOTH towers' parameters, so the geometry of the
+      # absent input is read off the tree itself (position-embedding lengths)
+      ishape = (tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape)) if image is not None \
+          else self._image_shape_of(params)
+      tshape = tuple(text.shape) if text is not None else (1, int(params["txt"]["pos_embedding"].shape[1]))
       store = adhoc_store(self._execs, ("two_towers", ishape[1:], tshape[1:], torch.cuda.current_device()),
                           params, lambda: self.make_store(ishape, tshape))
       prefix = ""

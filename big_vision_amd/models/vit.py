@@ -79,7 +79,7 @@ class VitExec:
       self.pos = None
       self.pos_const = torch.from_numpy(posemb_sincos_2d(hw[0], hw[1], D)[0]).to(store.device)
     self.cls = E._W(store, f"{prefix}cls", (1, D)) if m.pool_type == "tok" else None
-    self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M)
+    self.enc = E.Encoder(store, f"{prefix}Transformer", m.depth, D, H, M, scan=getattr(m, "scan", False))
     self.map = E.MAPHead(store, f"{prefix}MAPHead_0", D, H, M) if m.pool_type == "map" else None
     self.pre = None
     if m.rep_size:   # pre_logits = tanh(Dense(x)), vit.py:259-262

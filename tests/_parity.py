@@ -73,12 +73,15 @@ def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen
   missing = [k for k in live if k not in gours]
   assert not missing, f"{case}: no gradient for {missing[:4]}"
   gnorm = math.sqrt(sum((v ** 2).sum().item() for v in live.values()))
-  rows, bad = [], []
+  rows, bad, small = [], [], []
   for k, gr in live.items():
     go = gours[k]
     nr = gr.norm().item()
     err = (go - gr).norm().item()
     if nr < SMALL * gnorm:
+      # the loose branch ("the report does not list which leaves took it"): recorded by name with
+      # the tensor's share of the global norm and its error in units of that norm
+      small.append((err / gnorm, k, nr / gnorm))
       if err > ABS_SMALL * gnorm:
         bad.append(f"{k}: small tensor, abs err {err / gnorm:.2e} of the global norm")
       continue
@@ -91,7 +94,8 @@ def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen
       bad.append(f"{k}: cosine {cos:.5f} (>= {cmin:.5f}) rel-L2 {rel:.4f} (<= {rmax:.4f}) "
                  f"share of global norm {nr / gnorm:.3f}, bf16 floor rel {frel:.4f}")
   rows.sort(reverse=True)
-  report(case, rows, gnorm, cos_min, rel_max)
+  small.sort(reverse=True)
+  report(case, rows, gnorm, cos_min, rel_max, small)
   if os.environ.get("BV_PARITY_REPORT_ONLY"):   # diagnostics runs: collect the table for every case, assert nothing
     if bad:
       print(f"[parity] {case}: WOULD FAIL:\n  " + "\n  ".join(bad))
@@ -100,13 +104,19 @@ def compare_grads(case, gref, gours, *, cos_min=COS_MIN, rel_max=REL_MAX, frozen
   return gnorm, rows
 
 
-def report(case, rows, gnorm, cos_min, rel_max):
+def report(case, rows, gnorm, cos_min, rel_max, small=()):
   worst = rows[:5]
   print(f"\n[parity] {case}: {len(rows)} tensors, global grad norm {gnorm:.4e}; worst rel-L2 / cosine:")
   for rel, cos, k, share, frel, fcos in worst:
     print(f"[parity]   {k:70s} rel-L2 {rel:.4f} cos {cos:.6f} share {share:.3f}"
           + (f"  [bf16 floor rel {frel:.4f} cos {fcos:.6f}]" if frel else ""))
+  if small:
+    print(f"[parity]   {len(small)} tensors below {SMALL:g} of the global norm (absolute bound {ABS_SMALL:g} of it); "
+          f"largest error {small[0][0]:.2e} of the global norm: {small[0][1]} (its share {small[0][2]:.2e})")
   rec = {"case": case, "tensors": len(rows), "bounds": {"cos_min": cos_min, "rel_max": rel_max},
+         "small": {"count": len(small), "threshold_share": SMALL, "abs_bound_of_global_norm": ABS_SMALL,
+                   "worst_abs_err_of_global_norm": small[0][0] if small else 0.0,
+                   "leaves": [{"name": k, "share": sh, "abs_err_of_global_norm": e} for e, k, sh in small]},
          "worst_rel": max((r[0] for r in rows), default=0.0), "worst_cos": min((r[1] for r in rows), default=1.0),
          "worst": [{"name": k, "rel_l2": rel, "cos": cos, "share": share, "floor_rel": frel, "floor_cos": fcos}
                    for rel, cos, k, share, frel, fcos in worst]}

@@ -10,17 +10,22 @@ import bench  # noqa: E402
 
 
 def test_pmc_traffic_is_tied_to_its_configuration():
-  path = os.path.join(ROOT, "profiles", bench.PMC_PROFILE)
-  t, src = bench.pmc_traffic(1, bench.MICRO)
-  if not os.path.exists(path):          # counters not collected for this round's kernels yet: no number
-    assert (t, src) == (None, None)
-    return
-  with open(path) as f:
-    d = json.load(f)
-  assert d["microbatch"] == bench.MICRO and d["n_gpus"] == 1
-  assert src == "profiles/" + bench.PMC_PROFILE and t == d["kernels"][bench.DOMINANT_KERNEL]["hbm_bytes"]
-  assert bench.pmc_traffic(8, bench.MICRO) == (None, None)        # other world size: no number
-  assert bench.pmc_traffic(1, bench.MICRO // 2) == (None, None)   # other micro-batch: no number
+  """The committed counter profile a line may quote is picked by what ONE GPU runs (pairs per GPU, micro-batch): the
+  headline finds this round's headline passes, a rank of N = 8 the passes taken at its 512-pair shape, anything else
+  nothing (the rest of the selection logic: tests/test_bench_line_cpu.py)."""
+  first = bench.PMC_PROFILES[0]
+  path = os.path.join(ROOT, "profiles", first)
+  t, src = bench.pmc_traffic(1, bench.GLOBAL_BATCH, bench.MICRO)
+  if os.path.exists(path):
+    with open(path) as f:
+      d = json.load(f)
+    assert d["microbatch"] == bench.MICRO and d["n_gpus"] == 1 and d.get("per_gpu_batch", bench.GLOBAL_BATCH) == bench.GLOBAL_BATCH
+    assert src == "profiles/" + first and t == d["kernels"][bench.DOMINANT_KERNEL]["hbm_bytes"]
+  t8, src8 = bench.pmc_traffic(8, bench.GLOBAL_BATCH // 8, bench.MICRO)
+  if os.path.exists(os.path.join(ROOT, "profiles", "r06_pmc_traffic_rank512.json")):
+    assert t8 and t8 < t and "rank512" in src8
+  assert bench.pmc_traffic(1, bench.GLOBAL_BATCH, bench.MICRO // 2) == (None, None)   # other micro-batch: no number
+  assert bench.pmc_traffic(3, 1365, bench.MICRO) == (None, None)                      # no profile of that shape
 
 
 def test_plain_multi_gpu_invocation_spawns_its_own_ranks(monkeypatch):

@@ -93,6 +93,14 @@ def test_tiny_step_on_the_bf16_residual_stream(dev):
        "softmax_xent", 0.7, residual_stream="bfloat16")
 
 
+def test_ragged_class_count_and_rep_size(dev):
+  """num_classes = 10 and rep_size = 12: output widths that are not multiples of 8 (found by running the product on
+  the executed-reference fixtures, tests/test_reference_wiring_gpu.py: the GEMM entry point takes N % 8 == 0 only).
+  The engine pads such heads with zero columns (engine._W.npad); forward, loss and every gradient vs the oracle."""
+  _run(dev, dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="gap", rep_size=12), 10, 6,
+       64, "softmax_xent", None)
+
+
 def test_unknown_loss_raises(dev):
   from big_vision_amd import train
   config = _cfg(model=dict(variant="S/16"), num_classes=10, loss="hinge")

@@ -41,7 +41,7 @@ def load(path):
 def main():
   ft, fc, fd = load(sys.argv[1])
   wt, wc, _ = load(sys.argv[2])
-  opts = dict(a.lstrip("-").split("=") for a in sys.argv[3:])   # --microbatch=2048 --n_gpus=1
+  opts = dict(a.lstrip("-").split("=", 1) for a in sys.argv[3:])   # --microbatch=2048 --n_gpus=1
   out = {"n_gpus": int(opts.get("n_gpus", 1)), "microbatch": int(opts.get("microbatch", 2048)),
          "per_gpu_batch": int(opts.get("per_gpu_batch", 4096)), "workload": opts.get("workload", "headline (bench.py)"),
          "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --steps 1 --warmup 0 "

@@ -44,10 +44,10 @@ int main(int argc, char** argv) {
 #endif
   for (int rep = 0; rep < 4; ++rep) {   // 1, 0, 1, 0: the first measurement of a process also warms the clocks up
     const int withb = (rep & 1) ^ 1;
-    for (int i = 0; i < 3; ++i) bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, withb ? dbias : nullptr, n, L, H, nullptr);
+    for (int i = 0; i < 3; ++i) bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, withb ? dbias : nullptr, n, L, H, nullptr, false);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < 10; ++i) bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, withb ? dbias : nullptr, n, L, H, nullptr);
+    for (int i = 0; i < 10; ++i) bv_attn5_bwd(qkv, d_o, lse, delta, dqkv, withb ? dbias : nullptr, n, L, H, nullptr, false);
     (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     printf("A5_ABL=%d n=%d L=%d dbias=%d: bwd %.1f us  (%s)\n", A5_ABL, n, L, withb, ms * 100.f, hipGetErrorString(hipGetLastError()));

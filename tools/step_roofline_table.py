@@ -2,7 +2,7 @@
 `rNN_bench_kernel_stats.csv` (rocprofv3 --kernel-trace --stats) for time shares and `rNN_pmc_traffic.json`
 (FETCH_SIZE x 2 + WRITE_SIZE per launch, tools/pmc_summary.py) for the HBM-side bytes.  Prints markdown.
 
-  python tools/step_roofline_table.py r05 [steps_in_trace]
+  python tools/step_roofline_table.py r05 [steps_in_trace] [workload tag: c4 | c5b -> rNN_<tag>_kernel_stats.csv, rNN_<tag>_pmc_traffic.json]
 """
 import csv
 import json
@@ -20,8 +20,11 @@ HBM_PEAK = 8.0   # TB/s, MI355X_MICROARCH.md
 def main():
   rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
   steps = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
-  rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_kernel_stats.csv"))))
-  traffic = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")))["kernels"]
+  tag = sys.argv[3] if len(sys.argv) > 3 else None
+  stats = f"{rnd}_{tag}_kernel_stats.csv" if tag else f"{rnd}_bench_kernel_stats.csv"
+  pmc = f"{rnd}_{tag}_pmc_traffic.json" if tag else f"{rnd}_pmc_traffic.json"
+  rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", stats))))
+  traffic = json.load(open(os.path.join(ROOT, "profiles", pmc)))["kernels"]
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
   print(f"| kernel | share of GPU time | launches / step | avg us | HBM-side bytes / launch (PMC) | TB/s | of the {HBM_PEAK:.0f} TB/s peak |")
   print("|---|---|---|---|---|---|---|")
