@@ -91,7 +91,10 @@ class GemmObserver:
     nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4.0 if out_f32 else 2.0)
     nbytes += {1: 4.0, 4: 2.0, 6: 2.0}.get(epi, 0.0) * M * N      # aux
     nbytes += {3: 2.0, 6: 2.0}.get(epi, 0.0) * M * N              # C2
-    return (e0, e1, 2.0 * M * N * K, nbytes)
+    # (kernel variant of the launch, as rocprofv3 names it: gemm256_kernel<true, 0, EPI, OUTF32> / the rolling-epilogue
+    # gemm256r_kernel for the plain, GELU and fp32 +residual epilogues - the split is the library's, the key here is
+    # just (epilogue id, fp32 output))
+    return (e0, e1, 2.0 * M * N * K, nbytes, (int(epi), bool(out_f32)))
 
   def end(self, tok):
     tok[1].record()
@@ -103,6 +106,16 @@ class GemmObserver:
     if base is None:
       return [(0.0, r[0].elapsed_time(r[1])) for r in self.recs]   # (no base: durations only, laid end to end below)
     return [(base.elapsed_time(r[0]), base.elapsed_time(r[1])) for r in self.recs]
+
+  def by_epilogue(self):
+    """{"epi<id>[_f32]": {launches, algorithmic bytes per launch, GFLOP per launch}}: the algorithmic side of the
+    per-variant PMC bytes in profiles/rNN_pmc_traffic.json (epilogue ids: include/bvhip.h BV_EPI_*)."""
+    acc = {}
+    for r in self.recs:
+      epi, f32 = r[4] if len(r) > 4 else (-1, False)
+      a = acc.setdefault(f"epi{epi}" + ("_f32" if f32 else ""), [0, 0.0, 0.0])
+      a[0] += 1; a[1] += r[3]; a[2] += r[2]
+    return {k: {"launches": n, "algorithmic_bytes_per_launch": b / n, "gflop_per_launch": f / n / 1e9} for k, (n, b, f) in sorted(acc.items())}
 
   def summary(self):
     """(launches, exclusive busy ms, FLOPs, algorithmic bytes, sum of the per-launch event times in ms)."""
@@ -139,7 +152,8 @@ def roofline_object(obs, wall_s):
           "avg_launch_us": 1e3 * ms / max(1, launches),
           "sum_of_launch_event_ms": sum_ms, "busy_ms": ms,
           "stream_overlap_factor": (sum_ms / ms) if ms > 0 else None,
-          "share_of_step_time": ms / (1e3 * wall_s) if wall_s > 0 else None}
+          "share_of_step_time": ms / (1e3 * wall_s) if wall_s > 0 else None,
+          "by_epilogue": obs.by_epilogue()}
 
 
 def pmc_traffic(world, per_gpu_batch, micro):

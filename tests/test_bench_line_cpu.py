@@ -17,7 +17,7 @@ class _FakeObserver(bench.GemmObserver):
   def __init__(self, iv, flops_each, bytes_each):
     super().__init__()
     self._iv, self.base = iv, object()
-    self.recs = [(None, None, flops_each, bytes_each)] * len(iv)
+    self.recs = [(None, None, flops_each, bytes_each, (3, False))] * len(iv)
 
   def intervals(self):
     return self._iv
@@ -41,6 +41,7 @@ def test_live_roofline_counts_overlapping_launches_once():
   assert abs(roof["frac"] - roof["achieved"] / bench.BF16_DENSE_PEAK_TFLOPS) < 1e-12
   assert abs(roof["stream_overlap_factor"] - 1.2) < 1e-12
   assert abs(roof["share_of_step_time"] - 0.75) < 1e-12
+  assert roof["by_epilogue"] == {"epi3": {"launches": 4, "algorithmic_bytes_per_launch": 1e9, "gflop_per_launch": 1e3}}
 
 
 def _args(**kw):

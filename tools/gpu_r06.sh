@@ -3,6 +3,7 @@
 #   tests      the whole -m gpu suite (what the driver runs at round end)
 #   bench      the default bench line (headline + bf16 stream + configs + CPU baseline)
 #   prof       rocprofv3 kernel stats + exclusive family busy time of the bench command, FETCH / WRITE / SQ --pmc passes
+#   prof1      kernel stats of the bench command with both towers on ONE stream (exclusive per-kernel durations)
 #   prof_cfg   kernel stats + FETCH / WRITE passes of BASELINE configs[3] (c4) and configs[4] (c5b)
 #   prof_rank  FETCH / WRITE passes at the rank shapes of N = 2 / 4 / 8 (2048 / 1024 / 512 pairs on one GPU)
 #   rccl3      the rank shape with the towers on two streams AND the one-rank RCCL collectives on their side stream
@@ -37,6 +38,13 @@ if [[ " $* " == *" prof "* ]]; then
   python tools/pmc_sq_summary.py $(find $O/pmc_sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq.json 2>> $O/pmc_summary.err
   rm -rf $O/pmc_sq
   head -24 $O/bench_kernel_stats.csv | cut -c1-150; cut -c1-600 $O/family_busy.json
+fi
+if [[ " $* " == *" prof1 "* ]]; then
+  # per-kernel durations are exclusive only when the towers share one stream: the per-kernel roofline table is built from this trace
+  BV_TOWER_STREAMS=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-bf16-stream --no-configs --no-live-pmc > $O/bench_line_profiled_one_stream.json 2> $O/stats1.err
+  find $O/stats1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/bench_kernel_stats_one_stream.csv
+  rm -rf $O/stats1
+  head -16 $O/bench_kernel_stats_one_stream.csv | cut -c1-150
 fi
 if [[ " $* " == *" prof_cfg "* ]]; then
   for w in c4 c5b; do
