@@ -17,7 +17,13 @@ LiT B/16 n=8 0.0223), worst cosine 0.99976 - all inside the SURVEY bounds; round
 bf16 O) had 0.05-0.107 on the same cases.
 Tensors whose reference gradient is below SMALL x the global gradient norm (e.g. the key bias,
 whose gradient is exactly zero by the shift invariance of softmax) are held to an absolute error
-of ABS_SMALL x the global norm instead: their relative error is noise over noise.
+of ABS_SMALL x the global norm instead: their relative error is noise over noise.  Round 6: every
+leaf that takes this branch is listed in the report (name, share of the global norm, error in
+units of it); over the 35 end-to-end cases these are 1-78 leaves per case - key / query biases and
+kernels, a few LayerNorm_1 scales - and the worst error measured is 3.5e-5 of the global norm
+(profiles/r06_parity_report.jsonl), so ABS_SMALL went from 2e-3 to 1e-4: a leaf right at the
+threshold is held to 10 % of its own norm, and no leaf may contribute more than 1e-4 of the global
+gradient norm in error.
 """
 import json
 import math
@@ -26,7 +32,7 @@ import os
 COS_MIN = 0.999
 REL_MAX = 3e-2
 SMALL = 1e-3
-ABS_SMALL = 2e-3
+ABS_SMALL = 1e-4
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
