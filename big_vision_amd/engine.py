@@ -160,10 +160,14 @@ class _W:
   def __init__(self, store: ParamStore, name: str, shape2d=None):
     self.name = name
     sh = store.t(name, "shadow")
-    ma = store.t(name, "master")
+    try:
+      ma = store.t(name, "master")
+    except KeyError:       # sharded parameters: the fp32 master of a matmul kernel another rank owns (never read by a kernel)
+      ma = None
     g = store.g(name) if getattr(store, "want_grads", False) else None
     if shape2d is not None:
-      sh, ma = sh.view(shape2d), ma.view(shape2d)
+      sh = sh.view(shape2d)
+      ma = ma.view(shape2d) if ma is not None else None
       g = g.view(shape2d) if g is not None else None
     self.bf, self.f32, self.grad = sh, ma, g
     self.store = store

@@ -199,6 +199,12 @@ class Optimizer:
       self.lo, self.hi, n_own = 0, n_tr, n_tr
     self.mu = torch.zeros(n_own, device=dev, dtype=mu_dtype)
     self.nu = torch.zeros(n_own, device=dev, dtype=torch.float32)
+    # "fsdp": the PARAMETERS are sharded too (reference sharding.py:104-139) - the store keeps this rank's slice of the
+    # fp32 master plus the replicated entries from here on (ParamStore.shard_master_); config.fsdp_shard_params = False
+    # keeps the round-4 form (state and update sharded, fp32 master replicated)
+    if self.sharded and config.get("fsdp_shard_params", True) and not store.master_sharded:
+      store.refresh_shadow()
+      store.shard_master_(self.lo, self.hi, self.S, self.comm)
     self.count = 0
     self.gsq = torch.zeros(1, device=dev, dtype=torch.float64)
     self.stats = torch.zeros(2, device=dev, dtype=torch.float64)
@@ -430,7 +436,9 @@ class Optimizer:
   def frozen_sqnorm(self):
     if self._frozen_sq is None:
       acc = torch.zeros(1, device=self.store.device, dtype=torch.float64)
-      tail = self.store.master[self.store.trainable_count:]
+      st = self.store
+      # (sharded parameters: the frozen tensors are the replicated tail of master_small; its padding is zero)
+      tail = st.master_small[st.small_trainable:] if st.master_sharded else st.master[st.trainable_count:]
       if tail.numel():
         ops.sqnorm_(tail, acc)
       self._frozen_sq = acc
@@ -510,17 +518,25 @@ class Optimizer:
       ops.sqnorm_(st.grad[lo:hi], self.gsq)
     comm.all_reduce_scalars_(self.gsq)
     self.stats.zero_()
+    master_slice = st.master_own[:n_own] if st.master_sharded else st.master[lo:hi]
     if n_own:
-      ops.adam_step_(st.master[lo:hi], st.grad[lo:hi], self.mu[:n_own], self.nu[:n_own], st.shadow[lo:hi], self.segs,
+      ops.adam_step_(master_slice, st.grad[lo:hi], self.mu[:n_own], self.nu[:n_own], st.shadow[lo:hi], self.segs,
                      self.chunk_seg[lo // 1024:], n_own, sched, self.gsq, self.clip_norm, self.b1, self.b2, self.eps,
                      1.0 - self.b1 ** (k + 1), 1.0 - self.b2 ** (k + 1), self.stats)
     comm.all_reduce_scalars_(self.stats)
-    comm.broadcast_ranges_(st.master[:n_tr], self.bounds)   # every rank's updated slice into every rank's master
     self.count = k + 1
-    if comm.active:
-      for a, b in ((0, lo), (hi, n_tr)):
-        if b > a:
-          ops.cast_bf16(st.master[a:b], st.shadow[a:b])
+    if st.master_sharded:
+      # sharded PARAMETERS: nobody holds the other ranks' fp32 kernels.  What every rank needs after the update is the
+      # bf16 compute copy - all-gathered in place (the Adam kernel wrote this rank's slice of it): HALF the bytes of
+      # the fp32 exchange below - and the fp32 values of the replicated entries (biases, LayerNorm, embeddings, t, b)
+      comm.all_gather_flat_(st.shadow[:n_tr], lo, hi, S)
+      st.exchange_small_()
+    else:
+      comm.broadcast_ranges_(st.master[:n_tr], self.bounds)   # every rank's updated slice into every rank's master
+      if comm.active:
+        for a, b in ((0, lo), (hi, n_tr)):
+          if b > a:
+            ops.cast_bf16(st.master[a:b], st.shadow[a:b])
     st.shadow_version += 1     # the trainable prefix changed; frozen tensors (static_version) did not
     return {"l2_grads": torch.sqrt(self.gsq[0]),
             "l2_params": torch.sqrt(self.stats[0] + self.frozen_sqnorm()[0]),

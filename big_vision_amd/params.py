@@ -138,6 +138,11 @@ class ParamStore:
       self.ext_of[leaf] = ext
       self.ext_index.setdefault(ext, []).append((i if i is not None else 0, leaf))
     self.ext_index = {k: [l for _, l in sorted(v)] for k, v in self.ext_index.items()}
+    # parameter sharding ("fsdp" placement, shard_master_): fp32 master split into this rank's slice + the replicated entries
+    self.master_sharded = False
+    self.master_own = self.master_small = None
+    self.small_off: Dict[str, int] = {}
+    self.own = (0, self.trainable_count)
     self._shadow_dirty = True
     self.shadow_version = 0   # bumped whenever the bf16 shadow changes (cast / optimizer step)
     self.static_version = 0   # bumped only by a full cast (init / load): the version of the FROZEN tensors, which an optimizer step never touches
@@ -154,8 +159,20 @@ class ParamStore:
     return self.grad
 
   def t(self, name: str, buf: str = "master") -> torch.Tensor:
-    """Storage tensor `name` (kernel layout) from one of the flat buffers."""
+    """Storage tensor `name` (kernel layout) from one of the flat buffers.  With a SHARDED fp32 master
+    (`shard_master_`, the "fsdp" placement) `buf="master"` resolves a replicated entry (everything kernels read in fp32,
+    and every frozen tensor) to its view of `master_small`, a matmul kernel that lies inside this rank's slice to its
+    view of `master_own`, and raises KeyError for a kernel another rank owns (`full_tree()` gathers)."""
     e = self.entries[name]
+    if buf == "master" and self.master_sharded:
+      if name in self.small_off:
+        o = self.small_off[name]
+        return self.master_small[o:o + e.numel].view(e.shape)
+      lo, hi = self.own
+      if lo <= e.offset and e.offset + e.numel <= hi:
+        return self.master_own[e.offset - lo:e.offset - lo + e.numel].view(e.shape)
+      raise KeyError(f"{name}: the fp32 master of this kernel lives on its owner rank (sharded parameters); "
+                     "ParamStore.full_tree() gathers it")
     b = self._buf(buf)
     if e.offset + e.numel > b.numel():
       raise KeyError(f"{name} is frozen: it has no entry in buffer '{buf}'")
@@ -196,6 +213,8 @@ class ParamStore:
     v0 = views[0]
     if len(views) == 1:
       return v0.unsqueeze(0)
+    if buf == "master" and self.master_sharded:
+      return torch.stack(views)     # (a copy: the replicated entries are packed, not at their flat offsets)
     step = views[1].storage_offset() - v0.storage_offset()
     for k, v in enumerate(views):
       if (tuple(v.shape), v.stride(), v.storage_offset()) != (tuple(v0.shape), v0.stride(), v0.storage_offset() + k * step):
@@ -212,12 +231,109 @@ class ParamStore:
     return [self.leaf_index[l][0] for l in self.ext_index[leaf_name]]
 
   def tree(self, buf: str = "master") -> ParamTree:
+    """Leaves of buffer `buf` as a nested ParamTree.  With a sharded fp32 master the tree stays COMPLETE and LIVE without
+    holding a gathered copy: replicated leaves (biases, LayerNorm, embeddings, t, b, frozen tensors) are views of their
+    fp32 values, matmul kernels are views of the replicated bf16 compute copy (what every forward reads); the fp32 kernels
+    are a collective away: `full_tree()`."""
     flat = {}
     for n in self.leaf_names():
       if buf == "grad" and any(e in self.frozen for e in self.entries_of(n)):
         continue
+      if buf == "master" and self.master_sharded and not all(e in self.small_off for e in self.entries_of(n)):
+        flat[n] = self.leaf(n, "shadow")
+        continue
       flat[n] = self.leaf(n, buf)
     return _nest(flat, self, buf)
+
+  # ------------------------------------------------- sharded fp32 master --
+  def shard_master_(self, lo: int, hi: int, S: int, comm):
+    """"fsdp" placement (reference sharding.py:104-139: parameters AND optimizer state 1/N per device): from here on
+    this rank keeps the fp32 master of its slice [lo, hi) of the flat trainable buffer only (`master_own`), plus
+    `master_small`: every entry a kernel reads in fp32 (everything that is not a `.../kernel`: biases, LayerNorm,
+    position / token embeddings, cls, t, b) and every frozen tensor, replicated.  The full flat master is released.
+    Matmul kernels reach the GEMMs through the replicated bf16 shadow, which the sharded optimizer step all-gathers
+    (optax.Optimizer._sharded_adam_step); `exchange_small_` carries the updated fp32 of the replicated entries.
+    slices are S apart (a whole number of 1024-element chunks)."""
+    assert self.master is not None and not self.master_sharded
+    self.own, self.own_S, self._comm = (int(lo), int(hi)), int(S), comm
+    self.master_own = self.master[lo:hi].clone()
+    small = [e for e in self.entries.values() if e.name in self.frozen or not e.name.endswith("/kernel")]
+    small.sort(key=lambda e: (e.name in self.frozen, e.offset))      # trainable ones first: only they are exchanged
+    off, self.small_off = 0, {}
+    for e in small:
+      self.small_off[e.name] = off
+      off += (e.numel + ALIGN - 1) // ALIGN * ALIGN
+      if e.name not in self.frozen:
+        self.small_trainable = off
+    if not any(e.name not in self.frozen for e in small):
+      self.small_trainable = 0
+    self.master_small = torch.zeros(off, device=self.device, dtype=torch.float32)
+    for e in small:
+      o = self.small_off[e.name]
+      self.master_small[o:o + e.numel] = self.master[e.offset:e.offset + e.numel]
+    # pieces of trainable replicated entries inside the own slice: (offset in master_own, offset in master_small, length)
+    self._own_small = []
+    for e in small:
+      if e.name in self.frozen:
+        continue
+      a, b = max(lo, e.offset), min(hi, e.offset + e.numel)
+      if b > a:
+        self._own_small.append((a - lo, self.small_off[e.name] + (a - e.offset), b - a))
+    self._small_tmp = None
+    self.master = None
+    self.master_sharded = True
+
+  def exchange_small_(self):
+    """After a sharded optimizer step: the updated fp32 values of the replicated entries - each was updated by the
+    rank whose slice holds it - reach every rank's `master_small` (in place: kernel-side views stay valid).  One
+    all-reduce over the trainable part of `master_small` with every rank contributing the pieces it owns."""
+    comm = self._comm
+    n = self.small_trainable
+    if n == 0:
+      return
+    if comm is None or not comm.active:
+      for so, do, ln in self._own_small:
+        self.master_small[do:do + ln] = self.master_own[so:so + ln]
+      return
+    if self._small_tmp is None:
+      self._small_tmp = torch.zeros(n, device=self.device, dtype=torch.float32)
+    tmp = self._small_tmp
+    tmp.zero_()
+    for so, do, ln in self._own_small:
+      tmp[do:do + ln] = self.master_own[so:so + ln]
+    comm.all_reduce_sum_(tmp)
+    self.master_small[:n].copy_(tmp)
+
+  def gather_master(self) -> torch.Tensor:
+    """The whole flat fp32 master as a TEMPORARY tensor.  A COLLECTIVE on N > 1 ranks (checkpointing, tests)."""
+    if not self.master_sharded:
+      return self.master
+    lo, hi = self.own
+    full = torch.zeros(self.count, device=self.device, dtype=torch.float32)
+    full[lo:hi] = self.master_own
+    if self._comm is not None:
+      self._comm.all_gather_flat_(full[:self.trainable_count], lo, hi, self.own_S)
+    for name, o in self.small_off.items():      # replicated entries (the frozen ones exist nowhere else)
+      e = self.entries[name]
+      full[e.offset:e.offset + e.numel] = self.master_small[o:o + e.numel]
+    return full
+
+  def full_tree(self) -> ParamTree:
+    """fp32 values of EVERY leaf (a copy when the master is sharded; a collective then, see gather_master)."""
+    if not self.master_sharded:
+      return self.tree()
+    full = self.gather_master()
+    flat = {}
+    for n in self.leaf_names():
+      per = []
+      for leaf in self.ext_index[n]:
+        sname, sl = self.leaf_index[leaf]
+        e = self.entries[sname]
+        t = full[e.offset:e.offset + e.numel].view(e.shape)
+        per.append(t if sl is None else t.select(sl[0], sl[1]))
+      group = self.ext_index[n]
+      flat[n] = per[0] if (len(per) == 1 and group[0] == n) else torch.stack(per)
+    return _nest(flat, None, "master")
 
   # ---------------------------------------------------------------- I / O --
   def init_random(self, seed: int):
@@ -231,6 +347,16 @@ class ParamStore:
     self._shadow_dirty = True
 
   def load_tree(self, tree, strict: bool = True):
+    if self.master_sharded:      # materialise the flat master (collective), load into it, shard again
+      (lo, hi), S, comm = self.own, self.own_S, self._comm
+      self.master = self.gather_master()
+      self.master_sharded, self.master_own, self.master_small = False, None, None
+      try:
+        self.load_tree(tree, strict)
+        self.refresh_shadow()
+      finally:
+        self.shard_master_(lo, hi, S, comm)
+      return
     flat = flatten_tree(tree)
     # accept the presented layout (stacked for scanned encoders) and the per-block one
     known = set(self.ext_index) | set(self.leaf_index)
@@ -253,6 +379,22 @@ class ParamStore:
   def refresh_shadow(self, force: bool = False):
     """bf16 shadow <- master (HIP cast kernel).  The optimizer kernel keeps the
     trainable prefix in sync itself; this is for init / load / frozen tensors."""
+    if (self._shadow_dirty or force) and self.master_sharded:
+      # (an in-place edit of the sharded master: own slice and replicated entries are cast, the slices gathered)
+      from big_vision_amd import ops
+      lo, hi = self.own
+      if hi > lo:
+        ops.cast_bf16(self.master_own, self.shadow[lo:hi])
+      if self._comm is not None:
+        self._comm.all_gather_flat_(self.shadow[:self.trainable_count], lo, hi, self.own_S)
+      for name, o in self.small_off.items():
+        e = self.entries[name]
+        n8 = (e.numel + ALIGN - 1) // ALIGN * ALIGN
+        ops.cast_bf16(self.master_small[o:o + n8], self.shadow[e.offset:e.offset + n8])
+      self._shadow_dirty = False
+      self.shadow_version += 1
+      self.static_version += 1
+      return
     if self._shadow_dirty or force:
       from big_vision_amd import ops
       ops.cast_bf16(self.master, self.shadow)

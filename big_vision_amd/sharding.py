@@ -23,9 +23,16 @@ RCCL all-reduce (big_vision_amd/dp.py).  Two placements exist:
              1024-element chunks (a slice of the FLAT buffer, not a cut along each tensor's axis: the same bytes
              per rank, no per-tensor bookkeeping, identical arithmetic - Adam is elementwise, the clip norm is
              all-reduced).  Adafactor (round 4): runs of WHOLE tensors (its factored statistics are per tensor).
-             The gathered parameters stay resident between steps - every kernel of the step reads them and
-             0.8 GB is 0.3 % of the HBM - where XLA would re-gather per use; what is sharded is the optimizer
-             work and (Adam) the moments.
+             Round 6, Adam: the fp32 PARAMETERS are sharded as well (`ParamStore.shard_master_`): a rank keeps
+             the fp32 master of its own slice, plus - replicated - every entry a kernel reads in fp32 (biases,
+             LayerNorm, position / token embeddings, cls, t, b: everything that is not a `.../kernel`; the
+             reference keeps arrays under `min_size_to_shard_mb` replicated too, the embedding TABLE is this
+             implementation's exception to its rule) and every frozen tensor.  The matmul kernels reach the GEMMs
+             through the bf16 compute copy, which stays resident and is all-gathered after every update (half
+             the bytes of the fp32 exchange it replaces) where XLA would re-gather per use; the updated fp32 of
+             the replicated entries travels in one all-reduce.  `store.tree()` stays complete and live (bf16
+             views for sharded kernels), `store.full_tree()` / `u.save_train_state` gather the fp32 slices.
+             `config.fsdp_shard_params = False` keeps the round-4 form; Adafactor always does.
 `shard_dim` and `logical_partitioning` raise NotImplementedError naming the parameter - instead of silently
 running replicated under a config that asked for something else.
 A spec is a tuple with one entry per array axis (None = not sharded), like the reference's

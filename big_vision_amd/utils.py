@@ -242,10 +242,14 @@ def save_train_state(fname, train_state):
   (`params/<leaf>`, `opt/<chain index>/...`, utils.py:616-641 + trainers/.../siglip.py:263-268): what
   `load_params("file.npz")` / `load_train_state` read back.
 
-  Under the "fsdp" placement on N > 1 ranks `opt.state_tree()` is a COLLECTIVE (the owners' moments / statistics are
-  gathered first): EVERY rank must call this function - a call on rank 0 only deadlocks - and the ranks that should not
+  Under the "fsdp" placement on N > 1 ranks `opt.state_tree()` and the parameter gather are COLLECTIVES (the owners'
+  fp32 parameter slices, moments / statistics are gathered first): EVERY rank must call this function - a call on rank 0 only deadlocks - and the ranks that should not
   write pass `fname=None` (advisor r4)."""
-  tree = {"params": train_state["params"], "opt": train_state["opt"].state_tree()}
+  params = train_state["params"]
+  store = getattr(params, "store", None)
+  if store is not None and getattr(store, "master_sharded", False):
+    params = store.full_tree()     # sharded parameters: the owners' fp32 slices are gathered first (a collective, like the moments)
+  tree = {"params": params, "opt": train_state["opt"].state_tree()}
   if fname is not None:
     save_params_npz(fname, tree)
 

@@ -98,3 +98,60 @@ def test_train_state_roundtrip_resumes(dev, tmp_path):
   assert m2["training_loss"].item() == m2b["training_loss"].item()
   worst = max((v - after[k]).abs().max().item() for k, v in u.tree_flatten_with_names(state_b["params"])[0])
   assert worst <= 2 * 5e-4 + 1e-6, worst
+
+
+def test_train_state_of_a_parameter_sharded_run_resumes(dev, tmp_path):
+  """"fsdp" placement (sharding.py:104-139): the optimizer holds its slice of the fp32 master and moments only
+  (ParamStore.shard_master_).  A checkpoint of such a state holds WHOLE fp32 parameters and moments (gathered on save);
+  it resumes a replicated run and a sharded run alike, and the sharded run's next step is the replicated run's."""
+  import bv_oracle as O
+  from big_vision_amd import utils as u
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  base = dict(lr=1e-3, wd=1e-2, optax_name="scale_by_adam", total_steps=10, grad_clip_norm=1.0,
+              schedule=dict(decay_type="cosine", warmup_steps=2))
+  c_rep = ConfigDict(base)
+  c_fsdp = ConfigDict(dict(base, sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)")]))
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+
+  def fresh(c, rng):
+    model = two_towers.Model(image=IMG, text=TXT, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+    state, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=rng, total_steps=10)
+    return state, siglip.make_update_fn(model, c)
+
+  state, fn = fresh(c_fsdp, 0)
+  store = state["params"].store
+  assert store.master_sharded and store.master is None
+  # the live tree is complete: fp32 views for the replicated leaves, the bf16 compute copy for matmul kernels
+  live = dict(u.tree_flatten_with_names(state["params"])[0])
+  assert live["txt/head/bias"].dtype == torch.float32 and live["txt/head/kernel"].dtype == torch.bfloat16
+  state, _ = fn(state, None, batch)
+  f = str(tmp_path / "state.npz")
+  u.save_train_state(f, state)
+  saved = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(store.full_tree())[0]}
+  assert all(v.dtype == torch.float32 for v in saved.values())
+  sd = state["opt"].state_dict()
+  saved_mu, saved_nu = sd["mu"].clone(), sd["nu"].clone()
+  state, m2 = fn(state, None, batch)
+  after = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(store.full_tree())[0]}
+  # (a) into a REPLICATED state of another seed: whole fp32 parameters and moments, bit for bit
+  state_r, fn_r = fresh(c_rep, 5)
+  u.load_train_state(f, state_r)
+  for k, v in u.tree_flatten_with_names(state_r["params"])[0]:
+    assert torch.equal(v, saved[k]), k
+  assert state_r["opt"].count == 1 and torch.equal(state_r["opt"].mu, saved_mu) and torch.equal(state_r["opt"].nu, saved_nu)
+  state_r, m2r = fn_r(state_r, None, batch)
+  assert m2["training_loss"].item() == m2r["training_loss"].item()
+  worst = max((v - after[k]).abs().max().item() for k, v in u.tree_flatten_with_names(state_r["params"])[0])
+  assert worst <= 2 * 5e-4 + 1e-6, worst
+  # (b) into a SHARDED state of another seed: the slice, the replicated entries and the bf16 compute copy are the file's
+  state_s, fn_s = fresh(c_fsdp, 7)
+  u.load_train_state(f, state_s)
+  st_s = state_s["params"].store
+  assert st_s.master_sharded
+  for k, v in u.tree_flatten_with_names(st_s.full_tree())[0]:
+    assert torch.equal(v, saved[k]), k
+  state_s, m2s = fn_s(state_s, None, batch)
+  assert m2["training_loss"].item() == m2s["training_loss"].item()

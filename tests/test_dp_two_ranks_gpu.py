@@ -55,11 +55,18 @@ def _step(comm, image, text, **kw):
   state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, comm=comm,
                                      total_steps=config.total_steps)
   fn = siglip.make_update_fn(model, config, comm=comm)
+  if "sharding_strategy" in kw and "adafactor" not in kw.get("optax_name", ""):
+    # "fsdp" with Adam shards the PARAMETERS too (round 6): no rank holds the flat fp32 master, each holds its slice and
+    # the replicated entries (everything that is not a matmul kernel)
+    st0, opt0 = state["params"].store, state["opt"]
+    assert st0.master_sharded and st0.master is None and st0.master_own.numel() == opt0.hi - opt0.lo
+    assert st0.master_own.numel() + st0.master_small.numel() < (0.6 if comm.size > 1 else 1.3) * st0.count
   state, meas = fn(state, None, {"image": image, "labels": text})
   torch.cuda.synchronize()
   store = state["params"].store
   grads = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
-  params = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(state["params"])[0]}
+  # (fsdp: the fp32 parameters are sharded - full_tree() gathers the owners' slices; a plain tree otherwise)
+  params = {k: v.detach().cpu().double().clone() for k, v in u.tree_flatten_with_names(store.full_tree())[0]}
   more = int(kw.get("extra_steps", 0))
   if more:   # further steps on the same batch; `more_digest` = a hash of every parameter's BITS after them
     for _ in range(more):
@@ -67,7 +74,7 @@ def _step(comm, image, text, **kw):
     torch.cuda.synchronize()
     import hashlib
     h = hashlib.sha256()
-    for k, v in u.tree_flatten_with_names(state["params"])[0]:
+    for k, v in u.tree_flatten_with_names(store.full_tree())[0]:
       h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
     sh = store.shadow.detach().cpu().view(torch.int16).numpy().tobytes()
     params["__bits__"] = (h.hexdigest(), hashlib.sha256(sh).hexdigest(), float(meas2["training_loss"].item()))
@@ -206,7 +213,7 @@ def _bare_sharded_step(comm, rank, world):
   sd = opt.state_dict()                        # whole moments on every rank (a collective under fsdp)
   assert sd["mu"].numel() == store.trainable_count and sd["nu"].numel() == store.trainable_count
   dig = hashlib.sha256(sd["mu"].float().cpu().numpy().tobytes() + sd["nu"].float().cpu().numpy().tobytes()).hexdigest()
-  return store.master.detach().cpu().numpy(), dig, float(sd["mu"].float().abs().sum().item())
+  return store.gather_master().detach().cpu().numpy(), dig, float(sd["mu"].float().abs().sum().item())   # (fsdp: the owners' fp32 slices gathered)
 
 
 def test_sharded_step_without_a_driven_grad_sync_still_sums_onto_the_owners(dev):
