@@ -377,12 +377,15 @@ def spawn_ranks(n):
   GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), exactly
   what `python -m torch.distributed.run --nproc-per-node N bench.py ...` would start."""
   import subprocess
-  if torch.cuda.is_available() and torch.cuda.device_count() < n:
+  # BV_BENCH_SHARE_GPU=1 (with BV_DP_BACKEND=gloo): every rank on GPU 0 - a functional run of the N > 1 line on a one-GPU
+  # box (tests/test_dp_nccl_gpu.py); its `value` measures nothing and the line says so (config.shared_gpu)
+  share = os.environ.get("BV_BENCH_SHARE_GPU") == "1"
+  if torch.cuda.is_available() and torch.cuda.device_count() < n and not share:
     raise RuntimeError(f"--gpus {n} but only {torch.cuda.device_count()} GPU(s) are visible")
   port = str(_free_port())
   procs = []
   for r in range(n):
-    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
   # Poll ALL children: a rank that dies while the others sit in an RCCL collective would otherwise leave a
@@ -807,6 +810,8 @@ def assemble_line(args, world, n, r, roof, bf16_line, rccl, configs, cpu):
                  "global_batch": args.global_batch, "per_gpu_batch": n, "microbatch": args.microbatch,
                  "residual_stream": args.residual_stream,
                  "tower_streams": r.get("tower_streams"),
+                 **({"shared_gpu": "all ranks on ONE GPU over gloo: a functional run, not a measurement"}
+                    if os.environ.get("BV_BENCH_SHARE_GPU") == "1" else {}),
                  "recompute": (f"{max(0, n // args.microbatch - r['keep_n'])} of "
                                f"{n // args.microbatch} micro-batches re-run their forward in pass 2 "
                                f"(the others keep {CTX_KIND[r['light']]} "

@@ -244,8 +244,8 @@ def init_from_env(backend: str | None = None, overlap_channels: int | None = Non
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if backend is None:
-      backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:     # BV_DP_BACKEND=gloo: ranks that share ONE GPU (RCCL refuses that; tests, bench smoke runs)
+      backend = os.environ.get("BV_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
       torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
       # The collectives of a step move < 1 GB per 90 ms: a few channels are plenty, and every RCCL

@@ -168,3 +168,27 @@ def test_bv_comm_c_layer_on_one_rank(dev):
     assert b"bad arguments" in lib.bv_last_error()
   finally:
     assert lib.bv_comm_destroy(comm) == 0
+
+
+def test_bench_line_of_two_ranks_sharing_one_gpu():
+  """The N > 1 path of bench.py end to end on a one-GPU box: `python bench.py --gpus 2` spawns its two ranks (both on
+  GPU 0, gloo: RCCL refuses two ranks per device), rank 0 times the CPU oracle before the rendezvous, both ranks run the
+  sharded-loss step with the overlapped gradient sync, EVERY rank takes part in the closing all-reduce of ones (round 6
+  found it issued by rank 0 alone: a hang on the first multi-GPU run) and rank 0 prints ONE complete line."""
+  import json
+  import subprocess
+  env = dict(os.environ, BV_BENCH_SHARE_GPU="1", BV_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--global-batch", "64", "--steps", "2",
+                      "--warmup", "1", "--cpu-sample", "2"], env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, r.stdout[-1000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["config"]["per_gpu_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+  assert d["rccl"]["ranks"] == 2 and d["rccl"]["allreduce_of_ones"] == 2.0 and d["rccl"]["backend"] == "gloo"
+  assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+  assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches"] > 0 and "measured_on" in d["roofline"]
+  assert "shared_gpu" in d["config"] and d["value"] > 0 and math.isfinite(d["config"]["final_loss"])
+
