@@ -37,6 +37,7 @@ class TwoTowersExec:
     # (text N = 768 GEMMs at 512 pairs: 1.5 rounds).  Same kernels on the same inputs: identical results.
     self.streams = 1
     self._side = None
+    self._will_fork = None
 
   def _fork(self):
     """(main, side) with every transposed weight image current and the side stream behind everything enqueued so far.
@@ -67,9 +68,11 @@ class TwoTowersExec:
     """False when one of the towers takes no gradient (LiT / a frozen tower: `bwd` then runs the other tower alone on
     the main stream).  A saving forward does not fork in that case either: contexts allocated from the side stream's
     pool and freed on the main stream would only raise peak HBM for an overlap the backward cannot use."""
-    frozen = self.store.frozen
-    return all(any(n.startswith(f"{self.prefix}{tower}") and n not in frozen for n in self.store.entries)
-               for tower in ("img/", "txt/"))
+    if self._will_fork is None:     # (the frozen set of a store is fixed at construction)
+      frozen = self.store.frozen
+      self._will_fork = all(any(n.startswith(f"{self.prefix}{tower}") and n not in frozen for n in self.store.entries)
+                            for tower in ("img/", "txt/"))
+    return self._will_fork
 
   def fwd(self, image, text, save=False, collect=False):
     out, ctx = {}, {}
