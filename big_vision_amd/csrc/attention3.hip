@@ -885,10 +885,11 @@ struct A3Cfg {
   int dkv32;        // bits 32 / 64: 32-key-block dK/dV kernel, 1 = 4 waves x 2 workgroups per CU, 2 = 7 waves x 1
   bool a5_off;      // bit 128: keep the two-launch backward also where the one-launch kernel (attention5.hip) applies
   bool a5_bias_dpp; // bit 256: attention5.hip reduces the bias gradients with DPP column sums instead of the identities
+  bool dkv_classic; // bit 1024: the 16-key-fragment dK/dV kernel also for the long sequences (28+ fragments), see launch_bwd3
 };
 A3Cfg a3cfg(const bv_ctx* ctx) {
   const long c = bv_opt(ctx, BV_OPT_ATTN_CFG);
-  return A3Cfg{(c & 15) == 8, !(c & 16), (c & 64) ? 2 : (c & 32) ? 1 : 0, (c & 128) != 0, (c & 256) != 0};
+  return A3Cfg{(c & 15) == 8, !(c & 16), (c & 64) ? 2 : (c & 32) ? 1 : 0, (c & 128) != 0, (c & 256) != 0, (c & 1024) != 0};
 }
 
 template <typename K>
@@ -917,7 +918,11 @@ template <int KF, int NW, int WPS, int WPS2, int NW2 = NW>
 int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                 float* dbias, const int* kv_len, int n, int L, int H, hipStream_t s, const A3Cfg& cfg) {
   const bool g_a3_one_sweep = cfg.one_sweep;
-  const int g_a4_dkv = cfg.dkv32;
+  // Long sequences (28+ key fragments: L/16 at 336 px = 441 tokens, 576 at 384 px), unmasked: the 32-key-block dK/dV
+  // kernel with 7 waves is the default since round 6 - bit-identical results, whole backward 1360 -> 1249 us at n = 256,
+  // L = 441, H = 16 and 716 -> 686 us at L = 576 (tools/attn_longseq_cfg_ab.py, profiles/r06_attn_longseq_cfg_ab.txt);
+  // at 13-17 fragments it loses (L = 256: 366 -> 461 us) and stays opt-in
+  const int g_a4_dkv = cfg.dkv32 ? cfg.dkv32 : ((KF >= 28 && !kv_len && !cfg.dkv_classic) ? 2 : 0);
   const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
   if (o && g_a3_one_sweep) {
     if (!kv_len && L > (KF - 1) * 16) {

@@ -75,7 +75,9 @@ void bv_ctx_destroy(bv_ctx* ctx);
 #define BV_OPT_ATTN_CFG 8          /* (0) attention A/B switches: 8 = forward of the L <= 208 kernels as 8 waves x 2
                                       workgroups; +16 = two-sweep dQ kernel; +32 / +64 = 32-key dK/dV kernels;
                                       +128 = two-launch backward where the one-launch kernel applies; +256 = the
-                                      one-launch kernel reduces the bias gradients by DPP column sums */
+                                      one-launch kernel reduces the bias gradients by DPP column sums; +1024 = the
+                                      16-key dK/dV kernel also at 28+ key fragments (L > 272), where the 32-key
+                                      7-wave kernel is the default since round 6 */
 #define BV_OPT_SGEMM_MFMA 9        /* (1) bv_sgemm_strided on the fp32 matrix pipe wherever a 64 x 64 tile is filled;
                                       0 = always the VALU kernel (both are k-ordered fmaf chains: identical results) */
 #define BV_OPT_COUNT 10
