@@ -505,7 +505,7 @@ LIT_SCHEDULE = [("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=
 def workload_c4(dev, steps, stream="float32"):
   """BASELINE configs[3]: SigLIP ViT-L/16@336 + text-L, global batch 8192 on 8 GPUs: ONE rank's 1024 pairs."""
   r = workload_siglip(dev, steps, dict(variant="L/16", pool_type="map"), dict(variant="L", vocab_size=32_000), 1024,
-                      n=1024, res=336, seq=64, micro=256, stream=stream,
+                      n=1024, res=336, seq=64, micro=256, stream=stream,   # (A/B round 6: 512 -> 769 pairs/s, 256 -> 823)
                       gflop_per_pair=981.4,   # SURVEY.md 8(d): matmul FLOPs of one L/16@336 + text-L pair per step
                       label="SigLIP ViT-L/16@336 + text-L: one rank's 1024 pairs of the global batch 8192 (loss over the "
                             "local 1024 only: no peers on a single device), micro-batches of 256, Adam+clip+wd+cosine")
