@@ -76,6 +76,9 @@ PROTOTYPES = {
     "bv_tanh_fwd": [P, P, c_long, P],
     "bv_tanh_bwd": [P, P, P, c_long, P],
     "bv_mixup": [P, P, c_float, c_int, c_long, P],
+    "bv_dropout_f32": [P, P, P, P, c_long, ctypes.c_ulonglong, c_float, P],
+    "bv_dropout_bf16": [P, P, c_long, ctypes.c_ulonglong, c_float, P],
+    "bv_dropout_mask": [P, c_long, ctypes.c_ulonglong, c_float, P],
     "bv_sqnorm": [P, c_long, P, P],
     "bv_adam_step": [P, P, P, c_int, P, P, P, P, c_long, P, c_int, P, c_float, c_float, c_float,
                      c_float, c_float, c_float, P, P],

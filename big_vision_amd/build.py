@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbvhip.so")
 SOURCES = ["c_api.cpp", "comm.cpp", "gemm_bf16.hip", "gemm256.hip", "attention.hip", "attention3.hip", "attention5.hip", "attention_dh.hip", "layernorm.hip",
-           "elementwise.hip", "loss_optim.hip", "adafactor.hip"]
+           "elementwise.hip", "loss_optim.hip", "adafactor.hip", "dropout.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
          "-DNDEBUG"]
 

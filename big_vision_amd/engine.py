@@ -359,6 +359,43 @@ def linear_bwd_x(dy_bf, w: _W, out_dtype=BF16, **kw):
   return ops.gemm(dy_bf, w.bf, a_kmajor=True, b_kmajor=True, out_dtype=out_dtype, **kw)
 
 
+class Dropout:
+  """Dropout state of one forward pass: the rate and a 64-bit key from which every dropout site (models/vit.py:76,
+  100, 109, 228) derives its own key.  The kernels regenerate the keep bits from (site key, element index), so a
+  saved context only remembers keys; `fold(...)` derives the state of a sub-computation (tower, micro-batch)."""
+  M64 = (1 << 64) - 1
+
+  def __init__(self, rate, key=0):
+    if not 0.0 <= float(rate) < 1.0:
+      raise ValueError(f"dropout rate must be in [0, 1), got {rate}")
+    self.rate, self.base = float(rate), int(key) & self.M64
+
+  @classmethod
+  def _mix(cls, h, v):
+    # splitmix64 finaliser over the running key and the next id
+    z = (h + 0x9E3779B97F4A7C15 + (int(v) & cls.M64) * 0xBF58476D1CE4E5B9) & cls.M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & cls.M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & cls.M64
+    return z ^ (z >> 31)
+
+  def key(self, *ids):
+    h = self.base
+    for v in ids:
+      if isinstance(v, str):
+        for ch in v.encode():
+          h = self._mix(h, ch)
+      else:
+        h = self._mix(h, v)
+    return h
+
+  def fold(self, *ids):
+    return Dropout(self.rate, self.key(*ids))
+
+
+# ids of the dropout sites of one encoder block (Block._fwd_drop) and of the tower stem
+DROP_SA, DROP_GELU, DROP_MLP, DROP_POSEMB = 1, 2, 3, 4
+
+
 class LN:
   def __init__(self, store, prefix):
     self.scale = _W(store, f"{prefix}/scale")
@@ -380,6 +417,17 @@ class MLP:
     self.w1 = _W(store, f"{prefix}/Dense_0/kernel"); self.b1 = _W(store, f"{prefix}/Dense_0/bias")
     self.w2 = _W(store, f"{prefix}/Dense_1/kernel"); self.b2 = _W(store, f"{prefix}/Dense_1/bias")
     self.M = M
+
+  def fwd_drop(self, y_bf, resid, rate, k_gelu, k_out):
+    """resid + drop(fc2(drop(gelu(fc1(y))))) (models/vit.py:72-77,109) on the fp32 stream; returns (out, hd, g) in
+    the form of full contexts: g = drop(gelu(h)) is fc2's operand and hd = gelu'(h) scaled by the SAME keep bits, so the
+    unchanged backward (dW2 = g^T dout, dH = (dout W2^T) o hd, BV_EPI_MUL) differentiates the dropped activation."""
+    g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
+    hd = torch.empty_like(g)
+    linear_fwd(y_bf, self.w1, self.b1, out=g, epilogue=ops.EPI_GELU_GD, out2=hd)
+    ops.dropout_bf16_(g, k_gelu, rate, b=hd)
+    branch = linear_fwd(g, self.w2, self.b2, out_dtype=F32)
+    return ops.dropout_f32(branch, k_out, rate, addend=resid, out=branch), hd, g
 
   def fwd(self, y_bf, resid, keep_g=True):
     """resid + fc2(gelu(fc1(y))) ; returns (out, hd bf16, g bf16 or None).
@@ -436,12 +484,15 @@ class Block:
     self.bo = _W(store, f"{A}/out/bias")
     self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
 
-  def fwd(self, x, n, L, light=False, kv_len=None):
+  def fwd(self, x, n, L, light=False, kv_len=None, drop=None):
     """kv_len (int32 [n], optional): key-padding length per sample (NaFlex, naflex_vit.py:84-113).
+    drop (Dropout of THIS block, rate > 0): the dropout sites of vit.py:100,109 and :76, see _fwd_drop.
     light (True, or "g" = only the second item): the saved context drops what the backward can re-derive cheaply - the two
     LayerNorm outputs (re-normalised from x / x1) and gelu(h) (re-emitted by the fc2 dX
     GEMM) - one third of the block's activation bytes."""
     T, D, H = n * L, self.D, self.H
+    if drop is not None and drop.rate > 0.0:
+      return self._fwd_drop(x, n, L, kv_len, drop)
     y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
     o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
@@ -452,10 +503,53 @@ class Block:
       y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
+  def _fwd_drop(self, x, n, L, kv_len, drop):
+    """Encoder1DBlock in train mode with dropout > 0 (vit.py:90-111): x1 = x + drop(attention branch), x2 = x1 +
+    drop(MLP branch), drop(gelu(h)) inside the MLP.  fp32 stream, full contexts.  The residual adds cannot ride in
+    the GEMM epilogues here: each branch GEMM writes fp32 and ONE element-wise kernel applies the mask and adds the
+    stream (bv_dropout_f32).  The context carries the three site keys as a 14th entry."""
+    if x.dtype != F32:
+      raise NotImplementedError("dropout > 0 runs on the float32 residual stream only")
+    T, D, H = n * L, self.D, self.H
+    k_sa, k_gelu, k_mlp = drop.key(DROP_SA), drop.key(DROP_GELU), drop.key(DROP_MLP)
+    y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
+    qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
+    o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
+    branch = linear_fwd(o, self.wo, self.bo, out_dtype=F32)
+    x1 = ops.dropout_f32(branch, k_sa, drop.rate, addend=x, out=branch)
+    y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
+    x2, hd, g = self.mlp.fwd_drop(y1, x1, drop.rate, k_gelu, k_mlp)
+    return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (drop.rate, k_sa, k_mlp))
+
+  def _bwd_drop(self, saved, dx2, n, L, kv_len):
+    """Backward of _fwd_drop.  The gradient of a dropped branch is the stream's gradient under the branch's mask:
+    the bf16 operand of the branch's dX / dW GEMMs is written by the dropout kernel (instead of the LayerNorm
+    backward's plain bf16 copy) and the branch biases take ITS column sums (the fused column sums of the LayerNorm
+    backward would be those of the unmasked stream)."""
+    x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (rate, k_sa, k_mlp) = saved
+    T, D, H = n * L, self.D, self.H
+    dmlp_bf = ops.dropout_f32(dx2, k_mlp, rate, out_bf16=torch.empty((T, D), device=dx2.device, dtype=BF16))
+    dy1 = self.mlp.bwd(None, dmlp_bf, y1, hd, g, bias2_done=False)
+    del dmlp_bf
+    dx1 = self.ln1.bwd(dy1, x1, mean1, rstd1, T, D, dres=dx2)
+    dsa_bf = ops.dropout_f32(dx1, k_sa, rate, out_bf16=torch.empty((T, D), device=dx2.device, dtype=BF16))
+    linear_bwd_w(o, dsa_bf, self.wo, self.bo)
+    d_o = linear_bwd_x(dsa_bf, self.wo)
+    del dsa_bf
+    dqkv = ops.attn_bwd(qkv, o, d_o, lse, n, L, H, dbias=self.bqkv.grad, kv_len=kv_len)
+    linear_bwd_w(y0, dqkv, self.wqkv, None)
+    dy0 = linear_bwd_x(dqkv, self.wqkv)
+    dx_bf = torch.empty((T, D), device=dx2.device, dtype=BF16)
+    dx = self.ln0.bwd(dy0, x, mean0, rstd0, T, D, dres=dx1, dx_bf16=dx_bf)
+    return dx, dx_bf
+
   def bwd(self, saved, dx2, dx2_bf, n, L, b2_done=False, next_b2=None, kv_len=None):
     """b2_done: this block's MlpBlock Dense_1 bias gradient was fused into the producer of dx2;
     next_b2: gradient buffer of the PREVIOUS block's Dense_1 bias, to be fused into the
     LayerNorm_0 backward that produces that block's dx2 (bias grads = column sums of dx)."""
+    if len(saved) == 14:   # saved by _fwd_drop (b2_done / next_b2 are never set for such contexts, see Encoder.bwd)
+      assert not b2_done and next_b2 is None
+      return self._bwd_drop(saved, dx2, n, L, kv_len)
     x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g = saved
     T, D, H = n * L, self.D, self.H
     if x.dtype == BF16:   # bf16 residual stream: the gradient stream IS the GEMM operand
@@ -507,15 +601,21 @@ class Encoder:
     self.D = D
     self.scan = bool(scan)   # presentation only: stacked leaf names and the `out` keys of the reference's scan branch
 
-  def fwd(self, x, n, L, save, out=None, kv_len=None):
+  def fwd(self, x, n, L, save, out=None, kv_len=None, drop=None):
     """x: fp32 [n*L, D].  Returns the last block's output in the stream dtype (the callers hand it to
-    encoder_norm, whose kernel takes either) and the saved contexts."""
+    encoder_norm, whose kernel takes either) and the saved contexts.
+    drop (Dropout, rate > 0; train mode of vit.py:100,109,76): every block gets its own fold of it; contexts are full
+    ones whatever `save` asks for (the light kinds re-derive activations the mask would have to be re-applied to)."""
     saved = []
+    dropping = drop is not None and drop.rate > 0.0
+    if dropping and residual_stream() == BF16:
+      raise NotImplementedError("dropout > 0 runs on the float32 residual stream only")
     if residual_stream() == BF16 and x.dtype == F32:
       x = ops.cast_bf16(x)
     for i, blk in enumerate(self.blocks):
       x_in = x
-      x, s = blk.fwd(x, n, L, light=(True if save == "light" else ("g" if save == "g" else False)), kv_len=kv_len)
+      x, s = blk.fwd(x, n, L, light=(True if save == "light" else ("g" if save == "g" else False)), kv_len=kv_len,
+                     drop=(drop.fold("block", i) if dropping else None))
       if save:
         saved.append(s)
       if out is not None:
@@ -526,9 +626,17 @@ class Encoder:
       out["pre_ln"] = x.view(n, L, -1)
     return x, saved
 
-  def last_b2_grad(self):
+  @staticmethod
+  def dropped(saved):
+    """True for contexts saved by a forward with dropout > 0 (Block._fwd_drop)."""
+    return bool(saved) and len(saved[0]) == 14
+
+  def last_b2_grad(self, saved=None):
     """Gradient buffer of the last block's Dense_1 bias: the kernel that produces the
-    encoder's incoming dx (encoder_norm backward) accumulates its column sums there."""
+    encoder's incoming dx (encoder_norm backward) accumulates its column sums there.  None for contexts saved under
+    dropout: that bias takes the column sums of the MASKED gradient (Block._bwd_drop)."""
+    if saved is not None and self.dropped(saved):
+      return None
     return self.blocks[-1].mlp.b2.grad if self.blocks else None
 
   def bwd(self, saved, dx, dx_bf, n, L, b2_done=False, on_block=None, kv_len=None):
@@ -537,9 +645,12 @@ class Encoder:
     that produced its incoming dx; block i's backward also finishes block i-1's Dense_1 bias)."""
     last = len(self.blocks) - 1
     bf_stream = bool(saved) and saved[0][0].dtype == BF16   # the contexts remember the stream they were built on
+    dropped = self.dropped(saved)
+    assert not (dropped and b2_done), "contexts saved under dropout: the caller must not fuse the Dense_1 bias gradient"
     for i in range(last, -1, -1):
-      nb2 = self.blocks[i - 1].mlp.b2.grad if i > 0 else None
-      dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L, b2_done=(b2_done if i == last else True),
+      nb2 = self.blocks[i - 1].mlp.b2.grad if (i > 0 and not dropped) else None
+      dx, dx_bf = self.blocks[i].bwd(saved[i], dx, dx_bf, n, L,
+                                     b2_done=(False if dropped else (b2_done if i == last else True)),
                                      next_b2=nb2, kv_len=kv_len)
       if on_block is not None:
         on_block(i)

@@ -34,7 +34,8 @@ class TextExec:
     if m.num_classes:
       self.head = (E._W(store, f"{prefix}head/kernel"), E._W(store, f"{prefix}head/bias"))
 
-  def fwd(self, text, save=False, collect=False):
+  def fwd(self, text, save=False, collect=False, drop=None):
+    """drop (engine.Dropout): train mode with dropout > 0 - the encoder blocks' sites (text_transformer.py:72-75)."""
     m = self.m
     D = m.width
     out = {}
@@ -43,7 +44,7 @@ class TextExec:
     assert L == self.seq_len, f"text length {L} != initialised length {self.seq_len}"
     x = ops.embed_fwd(ids, self.table.f32, self.pos.f32, n, L)
     enc_out = {} if collect else None
-    xL, saved = self.enc.fwd(x, n, L, save, enc_out)
+    xL, saved = self.enc.fwd(x, n, L, save, enc_out, drop=drop)
     if collect:
       out.update(enc_out)
     ctx = dict(n=n, L=L, ids=ids, enc=saved, xL=xL)
@@ -104,17 +105,17 @@ class TextExec:
       dxL = torch.zeros((T, D), device=xL.device, dtype=F32)
       dxL_bf.zero_()
       self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=ctx["off"],
-                        dx_colsum=self.enc.last_b2_grad())
+                        dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
     elif m.pool_type in ("mean", "gap"):
       dyf = ops.pool_gap_bwd(dz, n, L, D)
-      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
     elif m.pool_type in ("max", "gmp"):
       dyf = ops.pool_max_bwd(dz, ctx["argmax"], n, L, D)
-      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
     else:
       dy = self.map.bwd(ctx["map"], dz, n, L)
-      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
-    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True, on_block=on_block)
+      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
+    dx0, _ = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=not self.enc.dropped(ctx["enc"]), on_block=on_block)
     if self.table.grad is not None:
       ops.embed_bwd(ctx["ids"].view(-1), dx0, self.table.grad)
     if self.pos.grad is not None:
@@ -127,8 +128,9 @@ class _Model:
   def __init__(self, num_classes, width=512, depth=12, mlp_dim=2048, num_heads=8, dropout=0.0,
                vocab_size=32_000, pool_type="last", scan=False, remat_policy="nothing_saveable",
                name=None):
-    if dropout:
-      raise NotImplementedError("dropout > 0 is not on the accelerated path")
+    if not 0.0 <= float(dropout) < 1.0:
+      raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+    self.dropout = float(dropout)
     if pool_type not in ("last", "first", "mean", "gap", "max", "gmp", "map"):
       raise NotImplementedError(f"Cannot do pooling '{pool_type}'")
     if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
@@ -171,7 +173,7 @@ class _Model:
     return self._execs[key]
 
   def apply(self, variables, text, *, train=False, rngs=None, collect=True, **kw):
-    del rngs, train, kw
+    del kw
     params = variables["params"]
     if isinstance(params, ParamTree) and params.store is not None:
       store, prefix = params.store, params.prefix
@@ -182,7 +184,8 @@ class _Model:
                                              scan_prefixes=self.scan_prefixes()))
       prefix = ""
     store.refresh_shadow()
-    x, out, _ = self.executor(store, prefix, text.shape[1]).fwd(text, save=False, collect=collect)
+    x, out, _ = self.executor(store, prefix, text.shape[1]).fwd(text, save=False, collect=collect,
+                                                                drop=vit.dropout_for(self.dropout, train, rngs))
     return x, out
 
 

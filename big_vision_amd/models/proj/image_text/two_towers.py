@@ -74,13 +74,24 @@ class TwoTowersExec:
                             for tower in ("img/", "txt/"))
     return self._will_fork
 
-  def fwd(self, image, text, save=False, collect=False):
+  def _drop_kw(self, tower, name, drop_key):
+    """{"drop": engine.Dropout} for a tower whose config asks for dropout > 0 when the pass is a training one
+    (`drop_key`: the pass's 64-bit dropout key, None = deterministic; two_towers.py:56,69 hand **kw - train - to both
+    towers, flax gives each module path its own stream of the "dropout" rng)."""
+    rate = float(getattr(tower, "dropout", 0.0) or 0.0)
+    if drop_key is None or rate <= 0.0:
+      return {}
+    return {"drop": E.Dropout(rate, drop_key).fold(name)}
+
+  def fwd(self, image, text, save=False, collect=False, drop_key=None):
     out, ctx = {}, {}
     zimg = ztxt = None
+    tkw = self._drop_kw(self.m.text_tower, "txt", drop_key)
+    ikw = self._drop_kw(self.m.image_tower, "img", drop_key)
     if self._two_streams(image, text, collect) and (not save or self._backward_will_fork()):
       main, side = self._fork()
       with torch.cuda.stream(side):
-        z, o, c = self.txt.fwd(text, save, collect)
+        z, o, c = self.txt.fwd(text, save, collect, **tkw)
         ztxt, norm = ops.l2norm_fwd(z)
       out.update({f"txt/{k}": v for k, v in o.items()})
       out["txt/norm"] = norm.view(-1, 1)
@@ -94,14 +105,14 @@ class TwoTowersExec:
     else:
       join = None
     if text is not None:
-      z, o, c = self.txt.fwd(text, save, collect)
+      z, o, c = self.txt.fwd(text, save, collect, **tkw)
       out.update({f"txt/{k}": v for k, v in o.items()})
       ztxt, norm = ops.l2norm_fwd(z)
       out["txt/norm"] = norm.view(-1, 1)
       out["txt/normalized"] = ztxt
       ctx["txt"] = (c, z, norm)
     if image is not None:
-      z, o, c = self.img.fwd(image, save, collect)
+      z, o, c = self.img.fwd(image, save, collect, **ikw)
       out.update({f"img/{k}": v for k, v in o.items()})
       zimg, norm = ops.l2norm_fwd(z)
       out["img/norm"] = norm.view(-1, 1)
@@ -277,7 +288,14 @@ class Model:
     return (1, side * ph, side * pw, 3)
 
   def apply(self, variables, image, text=None, *, train=False, rngs=None, collect=True, **kw):
-    del rngs, train, kw
+    """train=True: the towers' dropout (if their configs ask for any) is drawn from rngs["dropout"] (siglip.py:288-290)."""
+    del kw
+    drop_key = None
+    if train and any(float(getattr(t, "dropout", 0.0) or 0.0) > 0.0 for t in (self.image_tower, self.text_tower)):
+      if not rngs or "dropout" not in rngs:
+        raise ValueError("train=True with dropout > 0 needs rngs={'dropout': key}")
+      from big_vision_amd.models import vit as _vit
+      drop_key = _vit._seed_of(rngs["dropout"])
     params = variables["params"]
     if isinstance(params, ParamTree) and params.store is not None:
       store, prefix = params.store, params.prefix
@@ -293,7 +311,7 @@ class Model:
     store.refresh_shadow()
     ishape = None if image is None else (tuple(image[0].shape) if isinstance(image, (tuple, list)) else tuple(image.shape))
     ex = self.executor(store, prefix, ishape, None if text is None else tuple(text.shape))
-    zimg, ztxt, out, _ = ex.fwd(image, text, save=False, collect=collect)
+    zimg, ztxt, out, _ = ex.fwd(image, text, save=False, collect=collect, drop_key=drop_key)
     ex.check_inputs()
     return zimg, ztxt, out
 

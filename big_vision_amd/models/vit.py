@@ -63,6 +63,16 @@ def _seed_of(rng) -> int:
   return int(s)
 
 
+def dropout_for(rate, train, rngs):
+  """engine.Dropout of an `apply(..., train=, rngs=)` call, None when the call is deterministic (flax: a module with
+  dropout > 0 applied with train=True and no "dropout" rng raises)."""
+  if not train or not rate:
+    return None
+  if not rngs or "dropout" not in rngs:
+    raise ValueError("train=True with dropout > 0 needs rngs={'dropout': key}")
+  return E.Dropout(rate, _seed_of(rngs["dropout"]))
+
+
 class VitExec:
   """Forward / backward of one image tower bound to a ParamStore at `prefix`."""
 
@@ -89,10 +99,14 @@ class VitExec:
       self.head = (E._W(store, f"{prefix}head/kernel"), E._W(store, f"{prefix}head/bias"))
 
   # -------------------------------------------------------------- forward --
-  def fwd(self, image, save=False, collect=False):
+  def fwd(self, image, save=False, collect=False, drop=None):
+    """drop (engine.Dropout, train mode with the model's dropout > 0): vit.py:228 behind the position embedding
+    (+ cls) and the encoder blocks' sites; None = deterministic."""
     m = self.m
     D = m.width
     out = {}
+    if drop is not None and not (drop.rate > 0.0):
+      drop = None
     image = image.to(F32).contiguous()
     n = image.shape[0]
     patches, (h, w) = ops.patchify(image, m.patch_size[0])
@@ -111,10 +125,14 @@ class VitExec:
       x = ops.concat_cls(self.cls.f32, x, n, L0, D)
       L = L0 + 1
     enc_out = {} if collect else None
-    xL, saved = self.enc.fwd(x, n, L, save, enc_out)
+    k_pos = None
+    if drop is not None:
+      k_pos = (drop.rate, drop.key(E.DROP_POSEMB))
+      x = ops.dropout_f32(x, k_pos[1], drop.rate, out=x)       # vit.py:228
+    xL, saved = self.enc.fwd(x, n, L, save, enc_out, drop=drop)
     if collect:
       out["encoder"] = enc_out
-    ctx = dict(n=n, L=L, L0=L0, patches=patches, enc=saved, xL=xL)
+    ctx = dict(n=n, L=L, L0=L0, patches=patches, enc=saved, xL=xL, k_pos=k_pos)
     T = n * L
     if m.pool_type == "map":
       y, _, mean, rstd = self.enc.norm.fwd(xL, T, D)
@@ -199,16 +217,18 @@ class VitExec:
     dxL_bf = torch.empty((T, D), device=xL.device, dtype=BF16)
     if m.pool_type == "map":
       dy = self.map.bwd(ctx["map"], dz, n, L)
-      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+      dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
     elif m.pool_type == "gap":
       dyf = ops.pool_gap_bwd(dz, n, L, D)
-      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
+      dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
     else:
       dxL = torch.zeros((T, D), device=xL.device, dtype=F32)
       dxL_bf.zero_()
       self.enc.norm.bwd(dz, xL, mean, rstd, n, D, dx=dxL, dx_bf16=dxL_bf, row_stride=L, row_offset=0,
-                        dx_colsum=self.enc.last_b2_grad())
-    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=True, on_block=on_block)
+                        dx_colsum=self.enc.last_b2_grad(ctx["enc"]))
+    dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, L, b2_done=not self.enc.dropped(ctx["enc"]), on_block=on_block)
+    if ctx.get("k_pos") is not None:    # backward of the dropout behind the position embedding: the same keep bits
+      ops.dropout_f32(dx0, ctx["k_pos"][1], ctx["k_pos"][0], out=dx0, out_bf16=dx0_bf)
     if m.pool_type == "tok":
       if self.cls.grad is not None:
         ops.colsum(dx0.view(n, L * D)[:, :D], self.cls.grad.view(-1))
@@ -240,8 +260,9 @@ class _Model:
       raise ValueError(f"Unknown posemb type: {posemb}")
     if pool_type not in ("map", "gap", "0", "tok", "none"):
       raise ValueError(f"Unknown pool type: '{pool_type}'")
-    if dropout:
-      raise NotImplementedError("dropout > 0 is not on the accelerated path (all in-scope configs use 0)")
+    if not 0.0 <= float(dropout) < 1.0:
+      raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+    self.dropout = float(dropout)
     if width % num_heads or (width // num_heads) % 8 or width // num_heads > 128:
       raise NotImplementedError(f"attention kernels need a head_dim that is a multiple of 8 and <= 128 (64 is the "
                                 f"fast path), got {width}/{num_heads}")
@@ -307,11 +328,13 @@ class _Model:
                        lambda: ParamStore(self.entries("", hw), dev, scan_prefixes=self.scan_prefixes())), ""
 
   def apply(self, variables, image, *, train=False, rngs=None, collect=True, **kw):
-    del rngs, train, kw
+    """train=True with dropout > 0 needs rngs={"dropout": key} (vit.py:228, train.py:298), as in the reference."""
+    del kw
     hw = self.grid(tuple(image.shape))
     store, prefix = self._store_for(variables["params"], hw)
     store.refresh_shadow()
-    x, out, _ = self.executor(store, prefix, hw).fwd(image, save=False, collect=collect)
+    x, out, _ = self.executor(store, prefix, hw).fwd(image, save=False, collect=collect,
+                                                     drop=dropout_for(self.dropout, train, rngs))
     return x, out
 
   __call__ = None  # Flax-style direct calls are not supported; use .apply

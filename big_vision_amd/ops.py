@@ -565,6 +565,44 @@ def mixup(x, a):
   return out
 
 
+def dropout_f32(x, key, rate, addend=None, out=None, out_bf16=None):
+  """addend (or 0) + keep x / (1 - rate) on fp32 `x` (models/vit.py:100,109,228); the keep bits are a function of
+  (key, element index) only - see bv_dropout_f32.  Writes `out` (fp32; may be x or addend) and / or `out_bf16`;
+  with neither given a new fp32 tensor is returned."""
+  _chk(x, F32, "dropout.x")
+  assert x.is_contiguous()
+  if addend is not None:
+    _chk(addend, F32, "dropout.addend")
+    assert addend.is_contiguous() and addend.numel() == x.numel()
+  if out is None and out_bf16 is None:
+    out = torch.empty_like(x)
+  for o, dt in ((out, F32), (out_bf16, BF16)):
+    if o is not None:
+      _chk(o, dt, "dropout.out")
+      assert o.is_contiguous() and o.numel() == x.numel()
+  _lib.call("bv_dropout_f32", _p(x), _p(addend), _p(out), _p(out_bf16), x.numel(), int(key) & (2 ** 64 - 1), float(rate), _stream())
+  return out if out is not None else out_bf16
+
+
+def dropout_bf16_(a, key, rate, b=None):
+  """a (and b) *= keep / (1 - rate) in place, bf16, the same bits on both (models/vit.py:76: the dropout behind the
+  GELU, applied to gelu(h) and to the stored gelu'(h) alike so that the backward's product carries the mask)."""
+  _chk(a, BF16, "dropout.a")
+  assert a.is_contiguous()
+  if b is not None:
+    _chk(b, BF16, "dropout.b")
+    assert b.is_contiguous() and b.numel() == a.numel()
+  _lib.call("bv_dropout_bf16", _p(a), _p(b), a.numel(), int(key) & (2 ** 64 - 1), float(rate), _stream())
+  return a
+
+
+def dropout_mask(shape, key, rate, device):
+  """The keep bits (bool tensor of `shape`) the dropout kernels derive from `key` (tests / diagnostics)."""
+  out = torch.empty(shape, device=device, dtype=torch.uint8)
+  _lib.call("bv_dropout_mask", _p(out), out.numel(), int(key) & (2 ** 64 - 1), float(rate), _stream())
+  return out.bool()
+
+
 def sqnorm_(x, out):
   """out (f64[1]) += sum(x^2)."""
   _chk(x, F32, "sqnorm.x")

@@ -118,7 +118,13 @@ def make_update_fn(model, config, comm=None):
       images, labels = ops.mixup(images, a), ops.mixup(labels, a)
     n = images.shape[0]
     ex = model.executor(store, "", model.grid(tuple(images.shape)))
-    logits, _, ctx = ex.fwd(images, save=True)
+    # dropout (vit.py:228,100,109,76; train.py:298 rngs={"dropout": rng_model}): one key per step and rank
+    drop = None
+    if float(getattr(model, "dropout", 0.0) or 0.0) > 0.0:
+      if rng is None:
+        raise ValueError("the model has dropout > 0: update_fn needs an rng")
+      drop = E.Dropout(model.dropout, _seed_of(rng)).fold("step", int(bv_optax.get_count(opt)), "rank", int(comm.rank))
+    logits, _, ctx = ex.fwd(images, save=True, drop=drop)
     acc = torch.zeros(1, device=images.device, dtype=torch.float64)
     dlogits = loss_kernel(logits.contiguous(), labels, acc, want_grad=True, n_global=n * comm.size)
     # ("fsdp" placement: every range is summed onto its owner only, dp.GradShardSync)

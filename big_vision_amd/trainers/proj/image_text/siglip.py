@@ -109,10 +109,22 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
   if comm.active and config.get("overlap_grad_sync", True):
     dp.warn_if_overlap_is_uncapped()   # the persistent GEMMs leave dp.RESERVED_CUS CUs to RCCL: cap its channels
 
+  towers_drop = any(float(getattr(t, "dropout", 0.0) or 0.0) > 0.0
+                    for t in (getattr(model, "image_tower", None), getattr(model, "text_tower", None)))
+
   def update_fn(train_state, rng, batch):
-    del rng  # dropout is 0 on this path; kept for signature parity
     images, labels = batch["image"], batch["labels"]
     params, opt = train_state["params"], train_state["opt"]
+    # dropout (towers configured with dropout > 0; siglip.py:281-290: the step's key is `rng` folded with the step
+    # count, the model draws from rngs={"dropout": rng_model}): one 64-bit key per step, rank and micro-batch; the
+    # kernels derive the keep bits of every site from it, so a re-run micro-batch forward repeats its masks
+    step_key = None
+    if towers_drop:
+      if rng is None:
+        raise ValueError("the model has dropout > 0: update_fn needs an rng")
+      from big_vision_amd.models import vit as _vit
+      step_key = E.Dropout(0.0, _vit._seed_of(rng)).key("step", int(opt.count), "rank", int(comm.rank))
+    drop_key = lambda s: None if step_key is None else E.Dropout(0.0, step_key).key("microbatch", int(s))
     store = params.store
     store.want_grads = True
     # a checkpoint loaded with store.load_tree() / an in-place edit of the master weights only
@@ -172,7 +184,8 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         per_ctx = state_cache["per_ctx"].get(mode)
         keep = len(kept) < keep_max and (per_ctx is None or keep_cfg == "all" or fits(per_ctx, 1))
         before = torch.cuda.memory_allocated(dev)
-        a, b, o_, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=(mode if keep else False))
+        a, b, o_, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=(mode if keep else False),
+                             drop_key=drop_key(s))
         norms.append((o_.get("img/norm"), o_.get("txt/norm")))
         if keep and per_ctx is None:
           per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
@@ -187,7 +200,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
               del c
               state_cache["light"] = mode = trial
               before = torch.cuda.memory_allocated(dev)
-              a, b, _, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=mode)
+              a, b, _, c = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro], save=mode, drop_key=drop_key(s))
               per_ctx = state_cache["per_ctx"][mode] = max(1, torch.cuda.memory_allocated(dev) - before)
         if keep:
           kept[s] = c
@@ -203,7 +216,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
         ctx = kept.pop(s, None)
         if ctx is None:
           _, _, _, ctx = ex.fwd(_img_slice(images, s, s + micro), labels[s:s + micro],
-                                save=mode_of(state_cache["light"]))
+                                save=mode_of(state_cache["light"]), drop_key=drop_key(s))
         with dp.reserve_cus_for_collectives(comm if (sync is not None and s == starts[-1]) else None):
           ex.bwd(ctx, None if img_frozen else dzimg[s:s + micro].contiguous(),
                  None if txt_frozen else dztxt[s:s + micro].contiguous(),
@@ -215,7 +228,7 @@ def make_update_fn(model, config, comm=None, loss_fwd_bwd=None, measure=None):
       # gelu(h) only) - a memory knob that changes no result
       light_cfg = config.get("microbatch_light", "auto")
       save = "light" if light_cfg in (True, "light") else ("g" if light_cfg == "g" else True)
-      zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=save)
+      zimg, ztxt, o_, ctx = ex.fwd(images, labels, save=save, drop_key=drop_key(0))
       norms = [(o_.get("img/norm"), o_.get("txt/norm"))]
       stats, dzimg, dztxt, *lx = loss_fwd_bwd(zimg, ztxt, t_param, b_param, comm)
       with dp.reserve_cus_for_collectives(comm if sync is not None else None):

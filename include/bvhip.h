@@ -369,6 +369,23 @@ int bv_sigmoid_xent(const float* logits, const float* labels, double* loss_sum, 
 int bv_tanh_fwd(const float* x, float* y, long count, void* stream);
 int bv_tanh_bwd(const float* y, const float* dy, float* dx, long count, void* stream);
 
+/* Dropout of the encoder (models/vit.py:76 after the GELU, :100 / :109 on the two residual branches, :228 behind the
+ * position embedding; `nn.Dropout(rate)(x, deterministic)`): y = keep x / (1 - rate), keep ~ Bernoulli(1 - rate).
+ * The keep bits are a pure function of (key, element index): Philox-4x32-10 keyed by the caller's 64-bit site key,
+ * counter = index of a group of four consecutive elements, element j of the group keeps iff output word j <
+ * floor((1 - rate) 2^32).  Nothing is stored: the backward (and a re-run forward) passes the same key.
+ *   bv_dropout_f32:  out = addend (NULL: 0) + keep x / (1 - rate), fp32 in; writes out_f32 and / or out_bf16 (either
+ *                    may be NULL; out_f32 may alias x or addend).  Forward of a residual branch: x = branch output,
+ *                    addend = the stream; backward: x = the stream's gradient, out_bf16 = the branch's GEMM operand.
+ *   bv_dropout_bf16: a (and b, may be NULL) *= keep / (1 - rate) in place, bf16, the SAME bits on both (gelu(h) and the
+ *                    stored gelu'(h): the backward's product then carries the mask).
+ *   bv_dropout_mask: keep_u8[i] = the bit of element i (parity tests hand the masks to the oracle).
+ * count: elements, a multiple of 4. */
+int bv_dropout_f32(const float* x, const float* addend, float* out_f32, void* out_bf16, long count,
+                   unsigned long long key, float rate, void* stream);
+int bv_dropout_bf16(void* a, void* b, long count, unsigned long long key, float rate, void* stream);
+int bv_dropout_mask(void* keep_u8, long count, unsigned long long key, float rate, void* stream);
+
 /* Mixup (utils.py:1146-1154): out[i] = a x[i] + (1 - a) x[(i - 1) mod n] over n rows of
  * row_elems floats (jnp.roll(x, shift=1, axis=0)); used for images and soft labels alike. */
 int bv_mixup(const float* x, float* out, float a, int n, long row_elems, void* stream);

@@ -183,35 +183,93 @@ def mha(xq, xkv, p, num_heads, mask=None):
   return contract("nlhk,hkd->nld", o, p["out"]["kernel"]) + p["out"]["bias"]
 
 
-def mlp_block(x, p):
-  """models/vit.py:57-78 (MlpBlock)."""
-  return dense(gelu_tanh(dense(x, p["Dense_0"])), p["Dense_1"])
+class DropMasks:
+  """Dropout in train mode (flax nn.Dropout(rate)(x, deterministic=False): x * keep / (1 - rate), keep ~
+  Bernoulli(1 - rate)) with the keep masks GIVEN: JAX's random stream cannot be reproduced, so the parity tests draw
+  the masks once (from the product's own generator, ops.dropout_mask) and hand the same bits to both sides.
+  `masks`: {site name: bool tensor of the activation's shape}; site names are `<prefix>posemb` (vit.py:228) and
+  `<prefix>block<i>/{sa, gelu, mlp}` (vit.py:100, :76, :109).  `used` records the sites that were applied."""
+
+  def __init__(self, rate, masks, prefix=""):
+    self.rate, self.masks, self.prefix, self.used = float(rate), masks, prefix, []
+
+  def sub(self, name):
+    d = DropMasks(self.rate, self.masks, self.prefix + name)
+    d.used = self.used
+    return d
+
+  def __call__(self, site, x):
+    name = self.prefix + site
+    m = self.masks[name]
+    self.used.append(name)
+    return x * (m.reshape(x.shape).to(x.dtype) / (1.0 - self.rate))
 
 
-def encoder_block(x, p, num_heads, mask=None):
-  """models/vit.py:81-112 (Encoder1DBlock), dropout=0; mask [n, q, k] as naflex_vit.py:92-94."""
+def philox4x32_10(counter, key):
+  """Philox-4x32 with 10 rounds (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11;
+  Random123), vectorised over a leading axis: counter uint32 [..., 4], key uint32 [..., 2] -> uint32 [..., 4].
+  The product's dropout kernels (csrc/dropout.hip) draw their keep bits from it; pinned by Random123's published
+  known-answer vectors in tests/test_dropout_cpu.py."""
+  import numpy as np
+  c = [np.asarray(counter[..., i], np.uint64) for i in range(4)]
+  k0, k1 = np.asarray(key[..., 0], np.uint64), np.asarray(key[..., 1], np.uint64)
+  M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+  for _ in range(10):
+    p0, p1 = M0 * c[0], M1 * c[2]
+    c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK, p1 & MASK, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK, p0 & MASK]
+    k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+  return np.stack(c, -1).astype(np.uint32)
+
+
+def dropout_keep_mask(key, count, rate):
+  """The keep bits bv_dropout_* derive from a 64-bit site key (include/bvhip.h): element 4 g + j keeps iff word j of
+  philox4x32_10(counter = (g mod 2^32, g >> 32, 0, 0), key = (key mod 2^32, key >> 32)) < floor((1 - rate) 2^32)."""
+  import numpy as np
+  assert count % 4 == 0
+  g = np.arange(count // 4, dtype=np.uint64)
+  ctr = np.stack([g & np.uint64(0xFFFFFFFF), g >> np.uint64(32), 0 * g, 0 * g], -1).astype(np.uint32)
+  k = np.broadcast_to(np.array([key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF], np.uint32), (len(g), 2))
+  thr = min(int((1.0 - float(np.float32(rate))) * 4294967296.0), 4294967296)
+  return (philox4x32_10(ctr, k).astype(np.uint64) < np.uint64(thr)).reshape(-1)
+
+
+def _drop(drop, site, x):
+  return x if drop is None else drop(site, x)
+
+
+def mlp_block(x, p, drop=None):
+  """models/vit.py:57-78 (MlpBlock); drop: the dropout behind the GELU (:76)."""
+  return dense(_drop(drop, "gelu", gelu_tanh(dense(x, p["Dense_0"]))), p["Dense_1"])
+
+
+def encoder_block(x, p, num_heads, mask=None, drop=None):
+  """models/vit.py:81-112 (Encoder1DBlock); mask [n, q, k] as naflex_vit.py:92-94; drop (DropMasks of this block,
+  train mode with dropout > 0): the branch dropouts of :100 and :109 and the MlpBlock's."""
   out = {}
   y = layernorm(x, p["LayerNorm_0"])
   y = out["sa"] = mha(y, y, p["MultiHeadDotProductAttention_0"], num_heads,
                       mask=None if mask is None else mask[:, None])
+  y = _drop(drop, "sa", y)
   x = out["+sa"] = _stream(x + y)
   y = layernorm(x, p["LayerNorm_1"])
-  y = out["mlp"] = mlp_block(y, p["MlpBlock_0"])
+  y = out["mlp"] = mlp_block(y, p["MlpBlock_0"], drop)
+  y = _drop(drop, "mlp", y)
   x = out["+mlp"] = _stream(x + y)
   return x, out
 
 
-def encoder(x, p, depth, num_heads, mask=None):
+def encoder(x, p, depth, num_heads, mask=None, drop=None):
   """models/vit.py:115-160 (Encoder); accepts loop and scan param layouts."""
   out = {}
   x = _stream(x)
+  sub = lambda lyr: None if drop is None else drop.sub(f"block{lyr}/")
   if "encoderblock" in p:  # scan layout: leading depth axis (vit.py:129-148)
     for lyr in range(depth):
       pl = tree_map(lambda t, l=lyr: t[l], p["encoderblock"])
-      x, out[f"block{lyr:02d}"] = encoder_block(x, pl, num_heads, mask)
+      x, out[f"block{lyr:02d}"] = encoder_block(x, pl, num_heads, mask, sub(lyr))
   else:
     for lyr in range(depth):
-      x, out[f"block{lyr:02d}"] = encoder_block(x, p[f"encoderblock_{lyr}"], num_heads, mask)
+      x, out[f"block{lyr:02d}"] = encoder_block(x, p[f"encoderblock_{lyr}"], num_heads, mask, sub(lyr))
     out["pre_ln"] = x
   return layernorm(x, p["encoder_norm"]), out
 
@@ -330,8 +388,8 @@ def extract_patches(image, patch):
 # -----------------------------------------------------------------------------
 def vit_forward(params, image, *, num_classes=None, patch_size=(16, 16), width=768,
                 depth=12, mlp_dim=None, num_heads=12, posemb="learn",
-                rep_size=False, pool_type="gap", **_unused):
-  """models/vit.py:206-276 (_Model.__call__)."""
+                rep_size=False, pool_type="gap", drop=None, **_unused):
+  """models/vit.py:206-276 (_Model.__call__); drop (DropMasks): train mode with dropout > 0."""
   out = {}
   patches, (h, w) = extract_patches(image, patch_size)
   kern = params["embedding"]["kernel"]
@@ -350,7 +408,8 @@ def vit_forward(params, image, *, num_classes=None, patch_size=(16, 16), width=7
   n = x.shape[0]
   if pool_type == "tok":
     x = torch.cat([params["cls"].expand(n, -1, -1), x], dim=1)
-  x, out["encoder"] = encoder(x, params["Transformer"], depth, num_heads)
+  x = _drop(drop, "posemb", x)    # vit.py:228
+  x, out["encoder"] = encoder(x, params["Transformer"], depth, num_heads, drop=drop)
   encoded = out["encoded"] = x
   if pool_type == "map":
     x = out["head_input"] = map_head(x, params["MAPHead_0"], num_heads)
@@ -378,13 +437,13 @@ def vit_forward(params, image, *, num_classes=None, patch_size=(16, 16), width=7
 
 
 def text_forward(params, text, *, num_classes, width=512, depth=12, mlp_dim=2048,
-                 num_heads=8, vocab_size=32_000, pool_type="last", **_unused):
-  """models/proj/image_text/text_transformer.py:55-99."""
+                 num_heads=8, vocab_size=32_000, pool_type="last", drop=None, **_unused):
+  """models/proj/image_text/text_transformer.py:55-99; drop (DropMasks): train mode with dropout > 0 (:72-75)."""
   out = {}
   emb = params["Embed_0"]["embedding"]
   x = out["embedded"] = emb[text]
   x = x + params["pos_embedding"]
-  x, enc_out = encoder(x, params["Encoder_0"], depth, num_heads)
+  x, enc_out = encoder(x, params["Encoder_0"], depth, num_heads, drop=drop)
   out.update({"transformed": x, **enc_out})
   out["vocab_logits"] = x @ emb.T
   if pool_type == "last":
@@ -492,9 +551,11 @@ def init_bert(gen, *, config, num_classes=None, head_zeroinit=True, dtype=torch.
   return p
 
 
-def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None,
+def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None, drop=None,
                        **_unused):
-  """models/proj/image_text/two_towers.py:39-90."""
+  """models/proj/image_text/two_towers.py:39-90; drop: {"img": DropMasks, "txt": DropMasks} (either may be missing) for
+  a train-mode pass of towers configured with dropout > 0 (:56, :69 hand `train` down to both towers)."""
+  drop = drop or {}
   out = {}
   out_dims = (out_dim, out_dim) if isinstance(out_dim, int) else tuple(out_dim)
   zimg = ztxt = None
@@ -504,14 +565,14 @@ def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, tex
     else:
       kw = {**decode_variant(text_cfg.get("variant")),
             **{k: v for k, v in text_cfg.items() if k != "variant"}}
-      ztxt, o = text_forward(params["txt"], text, num_classes=out_dims[1], **kw)
+      ztxt, o = text_forward(params["txt"], text, num_classes=out_dims[1], **{**kw, "drop": drop.get("txt")})
     out.update({f"txt/{k}": v for k, v in o.items()})
     out["txt/norm"] = torch.linalg.norm(ztxt, dim=1, keepdim=True)
     out["txt/normalized"] = ztxt = ztxt / (out["txt/norm"] + 1e-8)
   if image is not None:
     kw = {**decode_variant(image_cfg.get("variant")),
           **{k: v for k, v in image_cfg.items() if k != "variant"}}
-    zimg, o = vit_forward(params["img"], image, num_classes=out_dims[0], **kw)
+    zimg, o = vit_forward(params["img"], image, num_classes=out_dims[0], **{**kw, "drop": drop.get("img")})
     out.update({f"img/{k}": v for k, v in o.items()})
     out["img/norm"] = torch.linalg.norm(zimg, dim=1, keepdim=True)
     out["img/normalized"] = zimg = zimg / (out["img/norm"] + 1e-8)
@@ -1087,9 +1148,10 @@ def synthetic_batch(seed, n, res, seq_len, vocab_size=32_000, dtype=torch.float3
   return image.to(dtype), text.to(torch.int32)
 
 
-def siglip_step_loss(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None):
-  """siglip.py:287-308 loss_fn: model.apply -> global sigmoid loss."""
+def siglip_step_loss(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None, drop=None):
+  """siglip.py:287-308 loss_fn: model.apply -> global sigmoid loss (drop: see two_towers_forward)."""
   zimg, ztxt, out = two_towers_forward(
-      params, image, text.long(), image_cfg=image_cfg, text_cfg=text_cfg, out_dim=out_dim, text_model=text_model)
+      params, image, text.long(), image_cfg=image_cfg, text_cfg=text_cfg, out_dim=out_dim, text_model=text_model,
+      drop=drop)
   loss, logits = siglip_loss_global(zimg, ztxt, out["t"], out["b"])
   return loss, (zimg, ztxt, logits, out)

@@ -7,7 +7,8 @@ RESTATED here (from upstream knowledge of Flax; pinned by HuggingF
     twice shares its parameters; `self.param(name, init, *args)` creates or reads `<path>/<name>`;
   * `init(rng, *args, **kw)` -> {"params": tree}; `apply({"params": tree}, *args, **kw)`;
   * the layers' arithmetic (Dense, DenseGeneral, Conv VALID-strided, LayerNorm eps 1e-6 with the fast variance,
-    MultiHeadDotProductAttention, Embed, Dropout as the identity at rate 0 / deterministic, gelu tanh form);
+    MultiHeadDotProductAttention, Embed, Dropout (identity at rate 0 / deterministic; in train mode a recorded
+    Bernoulli mask from the run's "dropout" rng), gelu tanh form);
   * `scan` over a leading parameter axis with a carried first argument, `remat` as the identity.
 Everything computes in numpy float64."""
 import numpy as np
@@ -19,6 +20,7 @@ _MISSING = object()
 _stack = []          # modules whose compact method is executing (innermost last)
 _run = None          # the active init / apply run: {"mode", "params", "key"}
 _scan = []           # active scans: [index, length]
+last_dropout_masks = []   # the train-mode Dropout masks of the most recent init / apply run (see Dropout)
 
 broadcast = "broadcast"
 
@@ -128,12 +130,14 @@ class Module:
   def _run_root(self, mode, params, key, args, kw):
     global _run
     assert _run is None and not _stack, "nested init / apply"
-    kw.pop("rngs", None)
+    rngs = kw.pop("rngs", None) or {}
     kw.pop("mutable", None)
-    _run = {"mode": mode, "params": params, "key": key}
+    global last_dropout_masks
+    _run = {"mode": mode, "params": params, "key": key, "rngs": rngs, "dropout_masks": []}
     try:
       return self(*args, **kw)
     finally:
+      last_dropout_masks = _run["dropout_masks"]     # [(module path incl. a scan index, keep mask)] of this run, in call order
       _run = None
 
   def init(self, rng, *args, **kw):
@@ -247,7 +251,16 @@ class Dropout(Module):
     det = self.deterministic if deterministic is None else deterministic
     if self.rate == 0.0 or det:
       return x
-    raise NotImplementedError("dropout > 0 in train mode is not restated (no in-scope config uses it)")
+    # train mode: keep ~ Bernoulli(1 - rate) drawn from the run's "dropout" rng folded with the module path (flax:
+    # make_rng("dropout") per module), x * keep / (1 - rate).  The masks are recorded so that a caller can hand the
+    # same bits to another implementation (JAX's own stream is not reproduced: only the PLACEMENT and the arithmetic
+    # of the reference's dropout are executed here).
+    if "dropout" not in _run["rngs"]:
+      raise ValueError("Dropout in train mode needs rngs={'dropout': key}")
+    path = "/".join(self._path) + (f"#{_scan[-1][0]}" if _scan else "")
+    keep = _run["rngs"]["dropout"].fold(path).generator().random(np.shape(x)) < (1.0 - self.rate)
+    _run["dropout_masks"].append((path, keep))
+    return np.where(keep, np.asarray(x, np.float64) / (1.0 - self.rate), 0.0)
 
 
 class Embed(Module):

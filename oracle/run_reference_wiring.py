@@ -50,6 +50,9 @@ CASES = {
     "vit_rep16": ("vit", dict(num_classes=10, **ONE_IMG, pool_type="gap", rep_size=16)),
     "vit_variant_mu16": ("vit", dict(num_classes=5, variant="mu/16", pool_type="map")),
     "vit_scan": ("vit", dict(num_classes=12, **TINY_IMG, pool_type="map", scan=True)),
+    # --- train mode with dropout > 0 (vit.py:76,100,109,228): the masks the stand-in Dropout drew are stored (`mask/<path>`)
+    "vit_dropout_tok": ("vit", dict(num_classes=10, **TINY_IMG, pool_type="tok", dropout=0.25), dict(train=True)),
+    "vit_dropout_scan": ("vit", dict(num_classes=None, **TINY_IMG, pool_type="map", dropout=0.1, scan=True), dict(train=True)),
     # --- models/proj/image_text/text_transformer.py:55-99: every pool_type
     "txt_last": ("txt", dict(num_classes=16, **TINY_TXT, pool_type="last")),
     "txt_first": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="first")),
@@ -58,6 +61,7 @@ CASES = {
     "txt_map": ("txt", dict(num_classes=16, **ONE_TXT, pool_type="map")),
     "txt_nohead": ("txt", dict(num_classes=0, **ONE_TXT, pool_type="last")),
     "txt_scan": ("txt", dict(num_classes=16, **TINY_TXT, pool_type="last", scan=True)),
+    "txt_dropout": ("txt", dict(num_classes=16, **TINY_TXT, pool_type="last", dropout=0.2), dict(train=True)),
     # --- models/proj/image_text/two_towers.py:28-90
     "two_map_last_bias": ("two", dict(image=dict(**TINY_IMG, pool_type="map"), text=dict(**TINY_TXT), out_dim=(None, 32),
                                       temperature_init=10.0, bias_init=-10.0)),
@@ -69,6 +73,8 @@ CASES = {
                                   temperature_init=10.0, bias_init=-2.71), dict(image=False)),
     "two_scan": ("two", dict(image=dict(**TINY_IMG, pool_type="map", scan=True), text=dict(**TINY_TXT, scan=True),
                              out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0)),
+    "two_dropout": ("two", dict(image=dict(**TINY_IMG, pool_type="map", dropout=0.1), text=dict(**TINY_TXT, dropout=0.3),
+                                out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0), dict(train=True)),
 }
 
 
@@ -99,8 +105,10 @@ def run_case(name, out_dir):
   import jax
   import numpy as np
   kind, cfg, *rest = CASES[name]
-  use = dict(image=True, text=True)
+  use = dict(image=True, text=True, train=False)
   use.update(rest[0] if rest else {})
+  train = use.pop("train")
+  tkw = dict(train=True, rngs={"dropout": jax.random.PRNGKey(5)}) if train else dict(train=False)
   g = np.random.default_rng([11, zlib.crc32(name.encode())])
   res = 32
   image = g.uniform(-1.0, 1.0, (2, res, res, 3))
@@ -112,14 +120,14 @@ def run_case(name, out_dir):
     model = vit.Model(**cfg)
     params = model.init(jax.random.PRNGKey(0), image)["params"]
     _jitter(params, np)
-    y, out = model.apply({"params": params}, image, train=False)
+    y, out = model.apply({"params": params}, image, **tkw)
     arrays.update({"in/image": image, "y": y})
   elif kind == "txt":
     from big_vision.models.proj.image_text import text_transformer
     model = text_transformer.Model(**cfg)
     params = model.init(jax.random.PRNGKey(0), text)["params"]
     _jitter(params, np)
-    y, out = model.apply({"params": params}, text, train=False)
+    y, out = model.apply({"params": params}, text, **tkw)
     arrays.update({"in/text": text, "y": y})
   else:
     from big_vision.models.proj.image_text import two_towers
@@ -128,12 +136,16 @@ def run_case(name, out_dir):
     _jitter(params, np)
     im = image if use["image"] else None
     tx = text if use["text"] else None
-    zimg, ztxt, out = model.apply({"params": params}, im, tx)
+    zimg, ztxt, out = model.apply({"params": params}, im, tx, **(tkw if train else {}))
     if im is not None:
       arrays.update({"in/image": image, "z/img": zimg})
     if tx is not None:
       arrays.update({"in/text": text, "z/txt": ztxt})
     meta["inputs"] = use
+  if train:
+    import flax.linen as nn
+    meta["dropout_sites"] = [p for p, _ in nn.last_dropout_masks]          # module paths in call order (`#i`: scan index)
+    arrays.update({f"mask/{p}": np.asarray(k, np.uint8) for p, k in nn.last_dropout_masks})
   flat_p, flat_o = _flatten(params), _flatten(out)
   meta["param_names"] = [n for n, _ in flat_p]
   meta["param_shapes"] = {n: list(np.shape(v)) for n, v in flat_p}

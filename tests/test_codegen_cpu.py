@@ -38,7 +38,7 @@ def _resources(src, tmp_path):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src", ["gemm256.hip", "attention3.hip", "attention_dh.hip", "layernorm.hip", "gemm_bf16.hip", "attention.hip",
-                                 "elementwise.hip", "loss_optim.hip"])
+                                 "elementwise.hip", "loss_optim.hip", "dropout.hip"])
 def test_no_spills_no_scratch(src, tmp_path):
   res = _resources(src, tmp_path)
   assert res, "no kernels found in the compiler remarks"

@@ -85,8 +85,44 @@ def _flat_out(tree, prefix=""):
   return out
 
 
-def _oracle_run(z, meta):
+def reference_site_to_oracle(path):
+  """Module path of a reference Dropout (`[img/|txt/]...`, flax auto-names, `#i` = scan index) -> (tower prefix, site
+  name of bv_oracle.DropMasks).  vit.py:228 is the tower's own `Dropout_0`; inside an Encoder1DBlock `Dropout_0` follows
+  the attention (:100), `Dropout_1` the MLP (:109), `MlpBlock_0/Dropout_0` the GELU (:76)."""
+  tower = ""
+  for t in ("img/", "txt/"):
+    if path.startswith(t):
+      tower, path = t, path[len(t):]
+  scan = None
+  if "#" in path:
+    path, scan = path.split("#")
+  parts = path.split("/")
+  if parts == ["Dropout_0"]:
+    return tower, "posemb"
+  blk = parts[1]
+  i = int(scan) if blk == "encoderblock" else int(blk.split("_")[-1])
+  site = {("Dropout_0",): "sa", ("Dropout_1",): "mlp", ("MlpBlock_0", "Dropout_0"): "gelu"}[tuple(parts[2:])]
+  return tower, f"block{i}/{site}"
+
+
+def oracle_drop(z, meta, mutate=None):
+  """{tower prefix: bv_oracle.DropMasks} from the masks the executed reference drew (None for deterministic cases)."""
+  if "dropout_sites" not in meta:
+    return None
+  cfg = meta["config"]
+  rates = {"": cfg.get("dropout"), "img/": cfg.get("image", {}).get("dropout"), "txt/": cfg.get("text", {}).get("dropout")}
+  masks = {}
+  for path in meta["dropout_sites"]:
+    tower, site = reference_site_to_oracle(path)
+    masks.setdefault(tower, {})[site] = torch.from_numpy(np.asarray(z[f"mask/{path}"])).bool()
+  if mutate:
+    mutate(masks)
+  return {t: O.DropMasks(rates[t], m) for t, m in masks.items()}
+
+
+def _oracle_run(z, meta, mutate=None):
   cfg, kind = meta["config"], meta["kind"]
+  drop = oracle_drop(z, meta, mutate)
   params = _nest({k[len("param/"):]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith("param/")})
   params = _unstack_scan(params)
   image = torch.from_numpy(z["in/image"]) if "in/image" in z.files else None
@@ -94,14 +130,15 @@ def _oracle_run(z, meta):
   if kind == "vit":
     kw = {**O.decode_variant(cfg.get("variant")), **{k: v for k, v in cfg.items() if k != "variant"}}
     kw["patch_size"] = tuple(kw["patch_size"])
-    y, out = O.vit_forward(params, image, **kw)
+    y, out = O.vit_forward(params, image, **kw, drop=drop[""] if drop else None)
     return {"y": y}, out
   if kind == "txt":
-    y, out = O.text_forward(params, text, **cfg)
+    y, out = O.text_forward(params, text, **cfg, drop=drop[""] if drop else None)
     return {"y": y}, out
   image_cfg = dict(cfg["image"], patch_size=tuple(cfg["image"]["patch_size"]))
   out_dim = cfg["out_dim"] if isinstance(cfg["out_dim"], int) else tuple(cfg["out_dim"])
-  zi, zt, out = O.two_towers_forward(params, image, text, image_cfg=image_cfg, text_cfg=cfg["text"], out_dim=out_dim)
+  zi, zt, out = O.two_towers_forward(params, image, text, image_cfg=image_cfg, text_cfg=cfg["text"], out_dim=out_dim,
+                                     drop=None if not drop else {"img": drop.get("img/"), "txt": drop.get("txt/")})
   return {k: v for k, v in (("z/img", zi), ("z/txt", zt)) if v is not None}, out
 
 
@@ -125,6 +162,25 @@ def test_oracle_reproduces_the_executed_reference(name):
     v = got[k].numpy()
     assert v.shape == ref.shape, (k, v.shape, ref.shape)
     assert np.max(np.abs(v - ref)) <= TOL * max(1.0, np.max(np.abs(ref))), k
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if "dropout" in c])
+def test_dropout_cases_bite(name):
+  """Every dropout site of the executed reference is consumed by the oracle, and moving a mask to a neighbouring site
+  (attention branch <-> MLP branch of block 0) breaks the agreement: the comparison above pins the PLACEMENT."""
+  z, meta = load_case(name)
+  drop = oracle_drop(z, meta)
+  _oracle_run(z, meta)   # (populates nothing here: used lists belong to the objects built inside) - run again below with ours
+  cfg, kind = meta["config"], meta["kind"]
+  n_sites = len(meta["dropout_sites"])
+  assert n_sites == sum(len(d.masks) for d in drop.values())
+
+  def swap(masks):
+    m = masks["img/" if "img/" in masks else ""]
+    m["block0/sa"], m["block0/mlp"] = m["block0/mlp"], m["block0/sa"]
+  ys, _ = _oracle_run(z, meta, mutate=swap)
+  k = next(iter(ys))
+  assert np.max(np.abs(ys[k].numpy() - z[k])) > 1e-6, "swapping two dropout sites changed nothing"
 
 
 def _product_tree(meta):

@@ -51,7 +51,13 @@ def _close(got, ref, what, rel=3e-2, floor=1e-3):
   assert err <= rel * scale + floor, (what, err, scale)
 
 
-@pytest.mark.parametrize("name", sorted(RW.CASES))
+# the train-mode dropout cases hold the masks the stand-in Dropout drew; the product derives its own bits (Philox), so
+# those cases pin the oracle's dropout PLACEMENT (tests/test_reference_wiring_cpu.py) and the product is compared with
+# the oracle GIVEN ITS OWN masks in tests/test_dropout_gpu.py
+DETERMINISTIC = sorted(c for c in RW.CASES if not (len(RW.CASES[c]) > 2 and RW.CASES[c][2].get("train")))
+
+
+@pytest.mark.parametrize("name", DETERMINISTIC)
 def test_product_matches_the_executed_reference(name):
   from big_vision_amd.models import vit
   from big_vision_amd.models.proj.image_text import text_transformer, two_towers
