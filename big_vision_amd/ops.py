@@ -23,6 +23,18 @@ def _p(t):
   return None if t is None else t.data_ptr()
 
 
+class ShiftedBase:
+  """A device buffer that holds elements [shift, shift + numel) of a larger index space: `data_ptr()` is the address
+  element 0 of that space WOULD have.  For kernels that address operands through a table of absolute offsets
+  (bv_adafactor_step) when a rank holds its own run of the buffer only; the caller's table must stay inside the run."""
+
+  def __init__(self, t, shift):
+    self.t, self.shift, self.dtype = t, int(shift), t.dtype
+
+  def data_ptr(self):
+    return self.t.data_ptr() - self.shift * self.t.element_size()
+
+
 def _chk(t, dtype, name):
   if not t.is_cuda:
     raise RuntimeError(f"{name}: expected a GPU tensor (libbvhip has no CPU path)")

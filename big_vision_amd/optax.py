@@ -159,6 +159,13 @@ class Optimizer:
       _refuse_per_example_clip(config)
       self.lr = float(config["lr"])
       self._init_adafactor(okw, lr_mult, wd, sched_idx_of_leaf)
+      # "fsdp": the PARAMETERS are sharded too, as under Adam - by OWNERSHIP of whole tensors here (the factored
+      # statistics are per tensor): the store keeps the fp32 master of this rank's run of entries plus the replicated
+      # non-kernel entries; the momentum exists for the own run only (`_af_base` hands the kernel base pointers
+      # shifted by -lo, its leaf table addresses the flat index space)
+      if self.sharded and config.get("fsdp_shard_params", True) and not store.master_sharded:
+        store.refresh_shadow()
+        store.shard_master_(self.lo, self.hi, 0, self.comm, bounds=self.bounds)
       return
     else:
       raise NotImplementedError(f"optax_name={self.name!r}: scale_by_adam and big_vision.scale_by_adafactor "
@@ -333,7 +340,9 @@ class Optimizer:
         cur["rows"], cur["cols"], cur["b"] = max(cur["rows"], rows), max(cur["cols"], cols), max(cur["b"], b)
       cur["total"] = max(cur["total"], total)
     self.af_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev).view(-1, AF_LEAF.itemsize)
-    self.mu = torch.zeros(st.trainable_count, device=dev, dtype=mom_dtype) if self.af["momentum"] > 0 else None
+    # (sharded: the momentum of the OWN run of tensors only - elements [lo, hi) of the flat index space)
+    n_mu = max(4, self.hi - self.lo) if self.sharded else st.trainable_count
+    self.mu = torch.zeros(n_mu, device=dev, dtype=mom_dtype) if self.af["momentum"] > 0 else None
     self.nu = None
     self.count = 0
     self.gsq = torch.zeros(1, device=dev, dtype=torch.float64)
@@ -357,19 +366,29 @@ class Optimizer:
     if self.sharded:
       self.comm.all_reduce_scalars_(self.gsq)
     self.stats.zero_()
+    # sharded: this rank's leaves live in [lo, hi) of the flat index space; the buffers that exist for that run only
+    # (fp32 master when the parameters are sharded, momentum) go in as base pointers shifted by -lo
+    master = ops.ShiftedBase(st.master_own, lo) if st.master_sharded else st.master
+    mu = ops.ShiftedBase(self.mu, lo) if (self.sharded and self.mu is not None) else self.mu
     for c in self.af_classes:     # one call per size class of the leaf table (four launches each, three for unfactored)
-      ops.adafactor_step_(st.master, st.grad, self.mu, st.shadow, self.af_table[c["first"]:c["first"] + c["n"]], c["n"],
+      ops.adafactor_step_(master, st.grad, mu, st.shadow, self.af_table[c["first"]:c["first"] + c["n"]], c["n"],
                           c["rows"], c["cols"], c["b"], c["total"], self.af_state, self.gsq, self.clip_norm, decay,
                           af["eps"], af["momentum"], sched, self.stats, block_rms_clip=af["block_rms_clip"],
                           block_usq=self._af_usq(c["n"]) if af["block_rms_clip"] > 0 else None)
     if self.sharded:
       comm, n_tr = self.comm, st.trainable_count
       comm.all_reduce_scalars_(self.stats)
-      comm.broadcast_ranges_(st.master[:n_tr], self.bounds)
-      if comm.active:
-        for a, b in ((0, lo), (hi, n_tr)):
-          if b > a:
-            ops.cast_bf16(st.master[a:b], st.shadow[a:b])
+      if st.master_sharded:
+        # sharded PARAMETERS: every rank needs the bf16 compute copy of the others' tensors (the kernel wrote the own
+        # run's) and the fp32 of the replicated entries - half the bytes of the fp32 exchange below
+        comm.broadcast_ranges_(st.shadow[:n_tr], self.bounds)
+        st.exchange_small_()
+      else:
+        comm.broadcast_ranges_(st.master[:n_tr], self.bounds)
+        if comm.active:
+          for a, b in ((0, lo), (hi, n_tr)):
+            if b > a:
+              ops.cast_bf16(st.master[a:b], st.shadow[a:b])
     self.count = k + 1
     st.shadow_version += 1
     return {"l2_grads": torch.sqrt(self.gsq[0]),
@@ -396,8 +415,22 @@ class Optimizer:
     for r in range(1, len(sb)):
       sb[r] = max(sb[r], sb[r - 1])
     self.comm.broadcast_ranges_(self.af_state, sb)
-    if self.mu is not None:
-      self.comm.broadcast_ranges_(self.mu[:self.bounds[-1]], self.bounds)
+
+  def _full_mu(self):
+    """The momentum over the whole flat index space (what a replicated optimizer holds): under the "fsdp" placement a
+    TEMPORARY tensor assembled from the owners' runs - a COLLECTIVE on N > 1 ranks, like _gather_af_state."""
+    if self.mu is None or not self.sharded:
+      return self.mu
+    n_tr = self.store.trainable_count
+    full = torch.zeros(n_tr, device=self.mu.device, dtype=self.mu.dtype)
+    full[self.lo:self.hi] = self.mu[:self.hi - self.lo]
+    self.comm.broadcast_ranges_(full, self.bounds)
+    return full
+
+  def _set_own_mu(self, full):
+    """Inverse of _full_mu: keep the own run of a whole momentum buffer."""
+    self.mu.zero_()
+    self.mu[:self.hi - self.lo].copy_(full[self.lo:self.hi].to(self.mu.dtype))
 
   def adafactor_state_numel(self):
     """Elements of the optax FactoredState (count, v_row, v_col, v) this optimizer stands for - the
@@ -625,7 +658,7 @@ class Optimizer:
     rt = lambda d: u.recover_tree(list(d.keys()), list(d.values()))
     out = {"0": {"0": cnt, "1": rt(trees[0]), "2": rt(trees[1]), "3": rt(trees[2])}}
     if self.mu is not None:
-      out["2"] = {"0": cnt, "1": self._moment_tree(self.mu)}
+      out["2"] = {"0": cnt, "1": self._moment_tree(self._full_mu())}
     return out
 
   def _af_assign(self, leaf, v_row, v_col, v):
@@ -709,7 +742,12 @@ class Optimizer:
         pick = lambda t, real: t[i] if (stacked and real) else t
         self._af_assign(leaf, pick(vr, factored), pick(vc, factored), pick(vv, not factored))
     if self.mu is not None:
-      self._assign_moment(self.mu, flat, pre + "2/1/")
+      if self.sharded:      # the checkpoint holds the whole momentum: lay it out in a full buffer, keep the own run
+        full = torch.zeros(st.trainable_count, device=self.mu.device, dtype=self.mu.dtype)
+        self._assign_moment(full, flat, pre + "2/1/")
+        self._set_own_mu(full)
+      else:
+        self._assign_moment(self.mu, flat, pre + "2/1/")
 
   def state_dict(self):
     """The raw state buffers.  Under the "fsdp" placement this is a COLLECTIVE like state_tree() (every rank must
@@ -718,7 +756,7 @@ class Optimizer:
     what load_state_dict of a replicated or sharded optimizer takes back."""
     if self.name in ADAFACTOR_NAMES:
       self._gather_af_state()
-      return {"mu": self.mu, "af_state": self.af_state, "count": self.count}
+      return {"mu": self._full_mu(), "af_state": self.af_state, "count": self.count}
     # always moments of exactly `trainable_count` elements, whatever the placement (advisor r5: a sharded
     # optimizer on an inactive one-rank group used to hand out its padded own-slice buffers)
     if self.sharded:
@@ -728,7 +766,13 @@ class Optimizer:
   def load_state_dict(self, d):
     if self.name in ADAFACTOR_NAMES:
       if self.mu is not None:
-        self.mu.copy_(d["mu"].to(self.mu.dtype))
+        if d["mu"].numel() != self.store.trainable_count:
+          raise ValueError(f"Adafactor momentum of {d['mu'].numel()} elements does not fit this model's "
+                           f"{self.store.trainable_count} trainable parameters (state_dict() holds the whole momentum)")
+        if self.sharded:
+          self._set_own_mu(d["mu"].to(self.mu.device))
+        else:
+          self.mu.copy_(d["mu"].to(self.mu.dtype))
       self.af_state.copy_(d["af_state"]); self.count = int(d["count"])
       return
     mu, nu = d["mu"], d["nu"]

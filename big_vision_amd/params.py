@@ -246,16 +246,19 @@ class ParamStore:
     return _nest(flat, self, buf)
 
   # ------------------------------------------------- sharded fp32 master --
-  def shard_master_(self, lo: int, hi: int, S: int, comm):
+  def shard_master_(self, lo: int, hi: int, S: int, comm, bounds=None):
     """"fsdp" placement (reference sharding.py:104-139: parameters AND optimizer state 1/N per device): from here on
     this rank keeps the fp32 master of its slice [lo, hi) of the flat trainable buffer only (`master_own`), plus
     `master_small`: every entry a kernel reads in fp32 (everything that is not a `.../kernel`: biases, LayerNorm,
     position / token embeddings, cls, t, b) and every frozen tensor, replicated.  The full flat master is released.
     Matmul kernels reach the GEMMs through the replicated bf16 shadow, which the sharded optimizer step all-gathers
     (optax.Optimizer._sharded_adam_step); `exchange_small_` carries the updated fp32 of the replicated entries.
-    slices are S apart (a whole number of 1024-element chunks)."""
+    slices are S apart (a whole number of 1024-element chunks) - or, with `bounds` (rank r owns [bounds[r],
+    bounds[r + 1]): the sharded Adafactor cuts the flat buffer at TENSOR boundaries, its statistics are per tensor),
+    of unequal length and exchanged by one broadcast per owner instead of an all-gather."""
     assert self.master is not None and not self.master_sharded
-    self.own, self.own_S, self._comm = (int(lo), int(hi)), int(S), comm
+    self.own, self.own_S, self._comm = (int(lo), int(hi)), int(S or 0), comm
+    self.own_bounds = None if bounds is None else [int(b) for b in bounds]
     self.master_own = self.master[lo:hi].clone()
     small = [e for e in self.entries.values() if e.name in self.frozen or not e.name.endswith("/kernel")]
     small.sort(key=lambda e: (e.name in self.frozen, e.offset))      # trainable ones first: only they are exchanged
@@ -304,6 +307,15 @@ class ParamStore:
     comm.all_reduce_sum_(tmp)
     self.master_small[:n].copy_(tmp)
 
+  def _gather_slices_(self, flat: torch.Tensor):
+    """In place on a flat tensor over the trainable prefix (any dtype): every rank's own range reaches every rank."""
+    if self._comm is None:
+      return
+    if self.own_bounds is not None:
+      self._comm.broadcast_ranges_(flat, self.own_bounds)
+    else:
+      self._comm.all_gather_flat_(flat, self.own[0], self.own[1], self.own_S)
+
   def gather_master(self) -> torch.Tensor:
     """The whole flat fp32 master as a TEMPORARY tensor.  A COLLECTIVE on N > 1 ranks (checkpointing, tests)."""
     if not self.master_sharded:
@@ -311,8 +323,7 @@ class ParamStore:
     lo, hi = self.own
     full = torch.zeros(self.count, device=self.device, dtype=torch.float32)
     full[lo:hi] = self.master_own
-    if self._comm is not None:
-      self._comm.all_gather_flat_(full[:self.trainable_count], lo, hi, self.own_S)
+    self._gather_slices_(full[:self.trainable_count])
     for name, o in self.small_off.items():      # replicated entries (the frozen ones exist nowhere else)
       e = self.entries[name]
       full[e.offset:e.offset + e.numel] = self.master_small[o:o + e.numel]
@@ -348,14 +359,14 @@ class ParamStore:
 
   def load_tree(self, tree, strict: bool = True):
     if self.master_sharded:      # materialise the flat master (collective), load into it, shard again
-      (lo, hi), S, comm = self.own, self.own_S, self._comm
+      (lo, hi), S, comm, bounds = self.own, self.own_S, self._comm, self.own_bounds
       self.master = self.gather_master()
       self.master_sharded, self.master_own, self.master_small = False, None, None
       try:
         self.load_tree(tree, strict)
         self.refresh_shadow()
       finally:
-        self.shard_master_(lo, hi, S, comm)
+        self.shard_master_(lo, hi, S, comm, bounds=bounds)
       return
     flat = flatten_tree(tree)
     # accept the presented layout (stacked for scanned encoders) and the per-block one
@@ -385,8 +396,7 @@ class ParamStore:
       lo, hi = self.own
       if hi > lo:
         ops.cast_bf16(self.master_own, self.shadow[lo:hi])
-      if self._comm is not None:
-        self._comm.all_gather_flat_(self.shadow[:self.trainable_count], lo, hi, self.own_S)
+      self._gather_slices_(self.shadow[:self.trainable_count])
       for name, o in self.small_off.items():
         e = self.entries[name]
         n8 = (e.numel + ALIGN - 1) // ALIGN * ALIGN

@@ -32,7 +32,8 @@ RCCL all-reduce (big_vision_amd/dp.py).  Two placements exist:
              the bytes of the fp32 exchange it replaces) where XLA would re-gather per use; the updated fp32 of
              the replicated entries travels in one all-reduce.  `store.tree()` stays complete and live (bf16
              views for sharded kernels), `store.full_tree()` / `u.save_train_state` gather the fp32 slices.
-             `config.fsdp_shard_params = False` keeps the round-4 form; Adafactor always does.
+             `config.fsdp_shard_params = False` keeps the round-4 form.  Adafactor: the same with runs of whole
+             tensors (fp32 master and momentum of the own run only; one broadcast of the bf16 copy per owner).
 `shard_dim` and `logical_partitioning` raise NotImplementedError naming the parameter - instead of silently
 running replicated under a config that asked for something else.
 A spec is a tuple with one entry per array axis (None = not sharded), like the reference's

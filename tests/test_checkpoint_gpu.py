@@ -155,3 +155,65 @@ def test_train_state_of_a_parameter_sharded_run_resumes(dev, tmp_path):
     assert torch.equal(v, saved[k]), k
   state_s, m2s = fn_s(state_s, None, batch)
   assert m2["training_loss"].item() == m2s["training_loss"].item()
+
+
+def test_train_state_of_a_parameter_sharded_adafactor_run_resumes(dev, tmp_path):
+  """The same under BigVision Adafactor (optax.py:187-216): the sharded optimizer owns runs of WHOLE tensors, holds the
+  fp32 master and the momentum of its run only (base pointers shifted by -lo into the kernel's flat index space) and
+  the factored statistics; a checkpoint holds whole parameters / momentum / statistics and resumes either placement."""
+  import bv_oracle as O
+  from big_vision_amd import utils as u
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  base = dict(lr=1e-3, wd=1e-2, optax_name="big_vision.scale_by_adafactor", total_steps=10, grad_clip_norm=1.0,
+              schedule=dict(decay_type="cosine", warmup_steps=2))
+  c_rep = ConfigDict(base)
+  c_fsdp = ConfigDict(dict(base, sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)")]))
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  batch = {"image": image.to(dev), "labels": text.to(dev)}
+
+  def fresh(c, rng):
+    model = two_towers.Model(image=IMG, text=TXT, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+    state, _ = siglip.make_train_state(model, c, tuple(image.shape), tuple(text.shape), rng=rng, total_steps=10)
+    return state, siglip.make_update_fn(model, c)
+
+  state, fn = fresh(c_fsdp, 0)
+  store, opt = state["params"].store, state["opt"]
+  assert store.master_sharded and store.master is None and opt.sharded
+  state, _ = fn(state, None, batch)
+  f = str(tmp_path / "state.npz")
+  u.save_train_state(f, state)
+  saved = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(store.full_tree())[0]}
+  sd = opt.state_dict()
+  assert sd["mu"].numel() == store.trainable_count
+  saved_mu = sd["mu"].clone()
+  saved_tree = {k: torch.as_tensor(v).detach().clone() for k, v in u.tree_flatten_with_names(opt.state_tree())[0]}
+  assert saved_mu.float().abs().sum().item() > 0
+  state, m2 = fn(state, None, batch)
+  after = {k: v.detach().clone() for k, v in u.tree_flatten_with_names(store.full_tree())[0]}
+  # (a) a replicated state of another seed takes the file bit for bit and makes the same next step
+  state_r, fn_r = fresh(c_rep, 5)
+  u.load_train_state(f, state_r)
+  for k, v in u.tree_flatten_with_names(state_r["params"])[0]:
+    assert torch.equal(v, saved[k]), k
+  assert state_r["opt"].count == 1 and torch.equal(state_r["opt"].mu, saved_mu)
+  for k, v in u.tree_flatten_with_names(state_r["opt"].state_tree())[0]:       # v_row / v_col / v / ema of every leaf
+    assert torch.equal(torch.as_tensor(v).to(saved_tree[k].device), saved_tree[k]), k
+  state_r, m2r = fn_r(state_r, None, batch)
+  assert m2["training_loss"].item() == m2r["training_loss"].item()
+  # (the gradients of two runs differ in their last bits: one update moves a weight by at most lr (1 - momentum) here)
+  worst = max((v - after[k]).abs().max().item() for k, v in u.tree_flatten_with_names(state_r["params"])[0])
+  assert worst <= 2 * 2.2e-4 + 1e-6, worst
+  # (b) a sharded state of another seed
+  state_s, fn_s = fresh(c_fsdp, 7)
+  u.load_train_state(f, state_s)
+  assert state_s["params"].store.master_sharded
+  for k, v in u.tree_flatten_with_names(state_s["params"].store.full_tree())[0]:
+    assert torch.equal(v, saved[k]), k
+  assert torch.equal(state_s["opt"].state_dict()["mu"], saved_mu)
+  state_s, m2s = fn_s(state_s, None, batch)
+  assert m2["training_loss"].item() == m2s["training_loss"].item()
+  # and state_dict() -> load_state_dict() between the placements
+  state_r["opt"].load_state_dict(state_s["opt"].state_dict())
+  assert torch.equal(state_r["opt"].mu, state_s["opt"].state_dict()["mu"])

@@ -28,6 +28,13 @@ class _FakeComm:
       if b > a:
         flat[a:b] = st.master_own[:b - a]
 
+  def broadcast_ranges_(self, flat, bounds):
+    for r, st in enumerate(self.peers):
+      a, b = bounds[r], bounds[r + 1]
+      assert (a, b) == st.own
+      if b > a:
+        flat[a:b] = st.master_own[:b - a].to(flat.dtype)
+
   def all_reduce_sum_(self, t):
     raise AssertionError("exchanged through _exchange_all below")
 
@@ -76,6 +83,31 @@ def test_sharded_master_round_trips(world):
   full = dict(u.tree_flatten_with_names(dict(stores[0].full_tree()))[0])
   e = stores[0].entries["txt/head/kernel"]
   assert torch.equal(full["txt/head/kernel"], ref[e.offset:e.offset + e.numel].view(e.shape))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_master_cut_at_tensor_boundaries_round_trips(world):
+  """The sharded Adafactor owns whole tensors (optax.Optimizer._init_adafactor): unequal runs, exchanged by one
+  broadcast per owner (`bounds`) instead of the equal-slice all-gather."""
+  stores = _stores(world)
+  ref = stores[0].master.clone()
+  st0 = stores[0]
+  n_tr = st0.trainable_count
+  share = (n_tr + world - 1) // world
+  starts = sorted(e.offset for e in st0.entries.values() if e.name not in st0.frozen)
+  bounds = [0] + [next((o for o in starts if o >= r * share), n_tr) for r in range(1, world)] + [n_tr]
+  assert len(set(b1 - b0 for b0, b1 in zip(bounds, bounds[1:]))) > 1, "the toy model happens to cut evenly"
+  comm = _FakeComm(world)
+  comm.peers = stores
+  for r, st in enumerate(stores):
+    st.shard_master_(bounds[r], bounds[r + 1], 0, comm, bounds=bounds)
+    assert st.master is None and st.master_sharded and st.master_own.numel() == bounds[r + 1] - bounds[r]
+  for st in stores:
+    assert torch.equal(st.gather_master(), ref)
+  # every entry lies inside exactly one owner's run
+  for e in st0.entries.values():
+    if e.name not in st0.frozen:
+      assert sum(b0 <= e.offset and e.offset + e.numel <= b1 for b0, b1 in zip(bounds, bounds[1:])) == 1, e.name
 
 
 def test_exchange_of_the_replicated_entries_is_exact():
