@@ -418,16 +418,19 @@ class MLP:
     self.w2 = _W(store, f"{prefix}/Dense_1/kernel"); self.b2 = _W(store, f"{prefix}/Dense_1/bias")
     self.M = M
 
-  def fwd_drop(self, y_bf, resid, rate, k_gelu, k_out):
-    """resid + drop(fc2(drop(gelu(fc1(y))))) (models/vit.py:72-77,109) on the fp32 stream; returns (out, hd, g) in
-    the form of full contexts: g = drop(gelu(h)) is fc2's operand and hd = gelu'(h) scaled by the SAME keep bits, so the
-    unchanged backward (dW2 = g^T dout, dH = (dout W2^T) o hd, BV_EPI_MUL) differentiates the dropped activation."""
+  def fwd_drop(self, y_bf, resid, rate, k_gelu, k_out, keep_branch=False):
+    """resid + drop(fc2(drop(gelu(fc1(y))))) (models/vit.py:72-77,109) on the fp32 stream; returns (out, hd, g, branch)
+    in the form of full contexts: g = drop(gelu(h)) is fc2's operand and hd = gelu'(h) scaled by the SAME keep bits, so
+    the unchanged backward (dW2 = g^T dout, dH = (dout W2^T) o hd, BV_EPI_MUL) differentiates the dropped activation.
+    branch: the MLP output BEFORE its dropout (the reference's out["mlp"], vit.py:108) when keep_branch, else None."""
     g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
     hd = torch.empty_like(g)
     linear_fwd(y_bf, self.w1, self.b1, out=g, epilogue=ops.EPI_GELU_GD, out2=hd)
     ops.dropout_bf16_(g, k_gelu, rate, b=hd)
     branch = linear_fwd(g, self.w2, self.b2, out_dtype=F32)
-    return ops.dropout_f32(branch, k_out, rate, addend=resid, out=branch), hd, g
+    if keep_branch:
+      return ops.dropout_f32(branch, k_out, rate, addend=resid), hd, g, branch
+    return ops.dropout_f32(branch, k_out, rate, addend=resid, out=branch), hd, g, None
 
   def fwd(self, y_bf, resid, keep_g=True):
     """resid + fc2(gelu(fc1(y))) ; returns (out, hd bf16, g bf16 or None).
@@ -484,7 +487,7 @@ class Block:
     self.bo = _W(store, f"{A}/out/bias")
     self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
 
-  def fwd(self, x, n, L, light=False, kv_len=None, drop=None):
+  def fwd(self, x, n, L, light=False, kv_len=None, drop=None, collect=False):
     """kv_len (int32 [n], optional): key-padding length per sample (NaFlex, naflex_vit.py:84-113).
     drop (Dropout of THIS block, rate > 0): the dropout sites of vit.py:100,109 and :76, see _fwd_drop.
     light (True, or "g" = only the second item): the saved context drops what the backward can re-derive cheaply - the two
@@ -492,7 +495,7 @@ class Block:
     GEMM) - one third of the block's activation bytes."""
     T, D, H = n * L, self.D, self.H
     if drop is not None and drop.rate > 0.0:
-      return self._fwd_drop(x, n, L, kv_len, drop)
+      return self._fwd_drop(x, n, L, kv_len, drop, collect)
     y0, _, mean0, rstd0 = self.ln0.fwd(x, T, D)
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
     o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
@@ -503,11 +506,13 @@ class Block:
       y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
 
-  def _fwd_drop(self, x, n, L, kv_len, drop):
+  def _fwd_drop(self, x, n, L, kv_len, drop, collect=False):
     """Encoder1DBlock in train mode with dropout > 0 (vit.py:90-111): x1 = x + drop(attention branch), x2 = x1 +
     drop(MLP branch), drop(gelu(h)) inside the MLP.  fp32 stream, full contexts.  The residual adds cannot ride in
     the GEMM epilogues here: each branch GEMM writes fp32 and ONE element-wise kernel applies the mask and adds the
-    stream (bv_dropout_f32).  The context carries the three site keys as a 14th entry."""
+    stream (bv_dropout_f32).  The context carries the site keys as a 14th entry (rate, k_sa, k_mlp, pre); pre = the
+    two branch outputs BEFORE their dropout when `collect` (the reference publishes those as out["sa"] / out["mlp"],
+    vit.py:98,108), which Encoder.fwd takes out of the context again."""
     if x.dtype != F32:
       raise NotImplementedError("dropout > 0 runs on the float32 residual stream only")
     T, D, H = n * L, self.D, self.H
@@ -516,17 +521,18 @@ class Block:
     qkv = linear_fwd(y0, self.wqkv, self.bqkv, out_dtype=BF16)
     o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
     branch = linear_fwd(o, self.wo, self.bo, out_dtype=F32)
-    x1 = ops.dropout_f32(branch, k_sa, drop.rate, addend=x, out=branch)
+    x1 = ops.dropout_f32(branch, k_sa, drop.rate, addend=x, out=None if collect else branch)
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
-    x2, hd, g = self.mlp.fwd_drop(y1, x1, drop.rate, k_gelu, k_mlp)
-    return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (drop.rate, k_sa, k_mlp))
+    x2, hd, g, mlp_pre = self.mlp.fwd_drop(y1, x1, drop.rate, k_gelu, k_mlp, keep_branch=collect)
+    pre = (branch, mlp_pre) if collect else None
+    return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (drop.rate, k_sa, k_mlp, pre))
 
   def _bwd_drop(self, saved, dx2, n, L, kv_len):
     """Backward of _fwd_drop.  The gradient of a dropped branch is the stream's gradient under the branch's mask:
     the bf16 operand of the branch's dX / dW GEMMs is written by the dropout kernel (instead of the LayerNorm
     backward's plain bf16 copy) and the branch biases take ITS column sums (the fused column sums of the LayerNorm
     backward would be those of the unmasked stream)."""
-    x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (rate, k_sa, k_mlp) = saved
+    x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, hd, g, (rate, k_sa, k_mlp, _) = saved
     T, D, H = n * L, self.D, self.H
     dmlp_bf = ops.dropout_f32(dx2, k_mlp, rate, out_bf16=torch.empty((T, D), device=dx2.device, dtype=BF16))
     dy1 = self.mlp.bwd(None, dmlp_bf, y1, hd, g, bias2_done=False)
@@ -615,13 +621,17 @@ class Encoder:
     for i, blk in enumerate(self.blocks):
       x_in = x
       x, s = blk.fwd(x, n, L, light=(True if save == "light" else ("g" if save == "g" else False)), kv_len=kv_len,
-                     drop=(drop.fold("block", i) if dropping else None))
+                     drop=(drop.fold("block", i) if dropping else None), collect=out is not None)
+      pre = None
+      if dropping and out is not None:       # the branch outputs before their dropout leave the context again
+        pre, s = s[13][3], s[:13] + (s[13][:3] + (None,),)
       if save:
         saved.append(s)
       if out is not None:
         x1 = s[7]
         v = lambda t: t.view(n, L, -1)   # the reference's activations are [n, L, D]
-        out[f"block{i:02d}"] = {"sa": v(x1 - x_in), "+sa": v(x1), "mlp": v(x - x1), "+mlp": v(x)}
+        sa, mlp = pre if pre is not None else (x1 - x_in, x - x1)     # (vit.py:98,108: published BEFORE the dropout)
+        out[f"block{i:02d}"] = {"sa": v(sa), "+sa": v(x1), "mlp": v(mlp), "+mlp": v(x)}
     if out is not None and not self.scan:   # (the reference's scan branch publishes no `pre_ln` alias, vit.py:129-157)
       out["pre_ln"] = x.view(n, L, -1)
     return x, saved

@@ -128,7 +128,7 @@ class VitExec:
     k_pos = None
     if drop is not None:
       k_pos = (drop.rate, drop.key(E.DROP_POSEMB))
-      x = ops.dropout_f32(x, k_pos[1], drop.rate, out=x)       # vit.py:228
+      x = ops.dropout_f32(x, k_pos[1], drop.rate, out=None if collect else x)   # vit.py:228 (out["with_posemb"] is the input)
     xL, saved = self.enc.fwd(x, n, L, save, enc_out, drop=drop)
     if collect:
       out["encoder"] = enc_out

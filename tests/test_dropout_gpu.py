@@ -117,8 +117,22 @@ def test_vit_tower_with_dropout_matches_the_oracle(dev, pool, scan):
                              for k, v in u.tree_flatten_with_names(store.tree())[0]])
   dm = O.DropMasks(cfg["dropout"], masks)
   okw = {k: v for k, v in cfg.items() if k not in ("scan", "head_zeroinit")}
-  y_ref, _ = O.vit_forward(params64, image.double(), **okw, drop=dm)
+  y_ref, out_ref = O.vit_forward(params64, image.double(), **okw, drop=dm)
   assert sorted(dm.used) == sorted(masks), "the oracle did not consume every mask"
+  # the `out` dict of a train-mode pass (8b contract): "sa" / "mlp" are the branch outputs BEFORE their dropout
+  # (vit.py:98,108), "with_posemb" the input of the dropout behind the position embedding (:220,228) - and collecting
+  # them changes nothing downstream
+  logits_c, out_c, _ = ex.fwd(image.to(dev), save=False, collect=True, drop=E.Dropout(cfg["dropout"], 0xABCDEF))
+  assert torch.equal(logits_c, logits)
+  def close(a, b, what, rel=6e-2, floor=2e-3):
+    a, b = a.detach().double().cpu().reshape(b.shape), b.detach().double()
+    assert (a - b).abs().max().item() <= rel * b.pow(2).mean().sqrt().item() + floor, what
+  close(out_c["with_posemb"], out_ref["with_posemb"], "with_posemb")
+  for i in range(cfg["depth"]):
+    for k in ("sa", "+sa", "mlp", "+mlp"):
+      close(out_c["encoder"][f"block{i:02d}"][k], out_ref["encoder"][f"block{i:02d}"][k], f"block{i:02d}/{k}")
+  # (the dropped branch is NOT what is published: about a quarter of its elements are zero)
+  assert (out_c["encoder"]["block00"]["sa"] == 0).float().mean().item() < 0.01
   assert (logits.cpu().double() - y_ref.detach()).abs().max() <= 5e-2 * max(1.0, y_ref.abs().max().item())
   (y_ref * w.cpu().double()).sum().backward()
   gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0] if v.grad is not None}
