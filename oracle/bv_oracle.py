@@ -959,7 +959,7 @@ class OptaxOracle:
         u = mu_hat / (torch.sqrt(nu_hat) + eps)
       elif self.name in ("big_vision.scale_by_adafactor", "scale_by_adafactor"):
         u = self._adafactor(n, u, step)
-      elif self.name == "identity":
+      elif self.name in ("identity", "big_vision.sgd"):      # optax.py:227: big_vision.sgd = optax.identity
         pass
       else:
         raise NotImplementedError(self.name)

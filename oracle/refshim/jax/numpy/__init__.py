@@ -3,7 +3,8 @@ for (../README.md: dtype promotion is not pinned here; the comparison against th
 import numpy as _np
 from numpy import (arange, roll, eye, diag, dot, clip, not_equal, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
                    linalg, maximum, minimum, where, stack, transpose, zeros_like, ones_like, tanh, abs, max, min,
-                   argmin, argmax, take, expand_dims, squeeze, ndarray, pi, newaxis, inf, int32, int64, uint32, bool_)
+                   argmin, argmax, take, expand_dims, squeeze, ndarray, pi, newaxis, inf, int32, int64, uint32, bool_, searchsorted,
+                   square, delete, argsort)
 
 float32 = _np.float32
 float64 = _np.float64
