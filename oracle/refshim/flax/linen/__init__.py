@@ -41,6 +41,23 @@ def with_logical_constraint(x, names):
   return x
 
 
+class Partitioned:
+  """flax.linen.Partitioned / LogicallyPartitioned boxes: no model on this path creates one; big_vision/sharding.py only
+  tests for them (`is_leaf`, `isinstance`)."""
+
+
+class LogicallyPartitioned(Partitioned):
+  pass
+
+
+def unbox(tree):
+  return tree
+
+
+def logical_to_mesh_axes(names):
+  raise NotImplementedError("logical partitioning is out of scope (DESIGN.md 4.5)")
+
+
 def compact(fn):
   def wrapped(self, *a, **kw):
     self._autonames, self._children = {}, set()

@@ -1,7 +1,7 @@
 """jax stand-in (see ../README.md): enough of the top-level namespace for the reference's model files to import and
 for their `__call__` bodies to run on numpy float64."""
 from . import numpy  # noqa: F401  (jax.numpy)
-from . import tree, tree_util, random, nn, lax, scipy  # noqa: F401
+from . import tree, tree_util, random, nn, lax, scipy, sharding  # noqa: F401
 
 Array = object
 
