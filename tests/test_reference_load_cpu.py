@@ -1,0 +1,94 @@
+"""The reference's OWN checkpoint loaders, executed (oracle/run_reference_load.py: models/vit.py `load` + fix-ups + scan
+conversion + `resample_posemb` through the real scipy, text_transformer.py `load`, two_towers.py `load`, models/common.py
+`merge_params`, utils.py `load_params`, all imported unmodified; host code on numpy arrays, nothing restated) vs the PRODUCT's
+loaders on the SAME checkpoint files: 29 scenarios - same layout, `dont_load`, the three generations of old position-embedding
+layouts, the combined cls + posemb, an inlined MAP head, loop <-> scan conversion both ways, up- and down-sampled position
+grids, the `params` / `opt/target` wrappers, `file.npz:subkey`, mismatches that raise (with the reference's message, which
+callers grep for ` - ` / ` + ` lines) or are covered by `dont_load`, the text tower's doubled posemb, two_towers from one
+file / a dict of files / with a mistyped key, `merge_params` directly.  SURVEY.md 8f rank 1."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import run_reference_load as RL  # noqa: E402  (scenario builders only: numpy, nothing of the reference)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "refload.npz")
+
+
+@pytest.fixture(scope="module")
+def golden():
+  z = np.load(GOLDEN)
+  return z, json.loads(bytes(z["meta"]).decode())
+
+
+def _config_of(d):
+  from big_vision_amd.compat.ml_collections import ConfigDict
+  return ConfigDict(d)
+
+
+def _product(sc):
+  from big_vision_amd.models import common, vit
+  from big_vision_amd.models.proj.image_text import text_transformer, two_towers
+  return RL.call(sc, vit, text_transformer, two_towers, common, _config_of)
+
+
+@pytest.mark.parametrize("name", RL.SCENARIOS)
+def test_product_loader_returns_what_the_reference_returns(golden, tmp_path, name):
+  z, meta = golden
+  want = meta[name]
+  sc = RL.build(name, str(tmp_path))
+  if "error" in want:
+    with pytest.raises((ValueError, AssertionError)) as ei:
+      _product(sc)
+    assert type(ei.value).__name__ == want["error"]
+    assert RL.scrub(str(ei.value), str(tmp_path)) == want["message"]
+    return
+  got = RL._flatten(_product(sc))
+  assert list(got) == want["leaves"] or sorted(got) == sorted(want["leaves"]), (sorted(set(got) ^ set(want["leaves"])))
+  resampled = "posemb_" in name and name.startswith("vit_posemb")
+  for k in want["leaves"]:
+    ref = z[f"{name}/{k}"]
+    v = np.asarray(got[k])
+    assert v.shape == ref.shape, (k, v.shape, ref.shape)
+    if resampled and k == "pos_embedding":      # bilinear zoom: the product's own implementation of scipy.ndimage.zoom(order=1)
+      assert np.max(np.abs(v.astype(np.float64) - ref)) <= 1e-6 * max(1.0, float(np.max(np.abs(ref)))), k
+    else:
+      assert np.array_equal(v, ref), k
+
+
+def test_the_fixture_covers_the_fixups(golden):
+  """The scenarios really went through the branches they are named after (in the REFERENCE's run)."""
+  z, meta = golden
+  ck = RL.vit_tree(1)
+  same = lambda a, b: np.array_equal(a, b)
+  assert same(z["vit_old_posemb_in_transformer/pos_embedding"], ck["pos_embedding"])
+  assert "Transformer/pos_embedding" not in meta["vit_old_posemb_in_transformer"]["leaves"]
+  assert same(z["vit_very_old_posembed_input/pos_embedding"], ck["pos_embedding"])
+  tok = RL.vit_tree(3, pool="tok")
+  assert z["vit_combined_cls_posemb/pos_embedding"].shape == (1, 16, RL.D) and not same(z["vit_combined_cls_posemb/cls"], tok["cls"])
+  assert same(z["vit_inlined_map_head/MAPHead_0/probe"], ck["MAPHead_0"]["probe"])
+  assert z["vit_loop_ckpt_into_scan_model/Transformer/encoderblock/LayerNorm_0/scale"].shape == (2, RL.D)
+  assert "Transformer/encoderblock_1/LayerNorm_0/scale" in meta["vit_scan_ckpt_into_loop_model"]["leaves"]
+  assert z["vit_posemb_upsample/pos_embedding"].shape == (1, 36, RL.D) and z["vit_posemb_downsample/pos_embedding"].shape == (1, 9, RL.D)
+  assert same(z["vit_dont_load_head/head/bias"], RL.vit_tree(2)["head"]["bias"]) and same(z["vit_dont_load_head/embedding/bias"], ck["embedding"]["bias"])
+  assert not same(z["txt_posemb_added_twice/pos_embedding"], RL.txt_tree(1)["pos_embedding"])
+  assert same(z["two_single_file_without_bias/b"], RL._r(RL._gen("b0"), 1)) and same(z["two_single_file_with_bias/b"], RL._r(RL._gen("b"), 1))
+  assert " - MAPHead_0/probe" in meta["vit_missing_leaf_raises"]["message"] and " + extra/kernel" in meta["vit_extra_leaf_raises"]["message"]
+  assert sum("error" in m for m in meta.values()) == 4
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(RL.REFERENCE, "big_vision")), reason="the reference tree is not on this host")
+def test_committed_fixture_is_what_the_reference_produces_now(tmp_path):
+  r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "run_reference_load.py"), str(tmp_path)],
+                     capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stderr[-2000:]
+  a, b = np.load(tmp_path / "refload.npz"), np.load(GOLDEN)
+  assert sorted(a.files) == sorted(b.files)
+  for k in a.files:
+    assert np.array_equal(a[k], b[k]), k
