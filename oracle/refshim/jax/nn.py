@@ -17,3 +17,9 @@ def log_sigmoid(x):
   """-softplus(-x), the stable form."""
   x = np.asarray(x, np.float64)
   return np.minimum(x, 0.0) - np.log1p(np.exp(-np.abs(x)))
+
+
+def log_softmax(x, axis=-1):
+  x = np.asarray(x, np.float64)
+  m = np.max(x, axis=axis, keepdims=True)
+  return x - m - np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True))

@@ -1,7 +1,7 @@
 """jax.numpy stand-in = numpy, with ONE policy: every floating-point array is float64, whatever float dtype is asked
 for (../README.md: dtype promotion is not pinned here; the comparison against the fp64 oracle needs full precision)."""
 import numpy as _np
-from numpy import (arange, roll, eye, diag, dot, clip, not_equal, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
+from numpy import (arange, roll, eye, diag, dot, not_equal, logical_not, logical_or, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
                    linalg, maximum, minimum, where, stack, transpose, zeros_like, ones_like, tanh, abs, max, min,
                    argmin, argmax, take, expand_dims, squeeze, ndarray, pi, newaxis, inf, int32, int64, uint32, bool_, searchsorted,
                    square, delete, argsort)
@@ -50,3 +50,15 @@ def concatenate(arrays, axis=0):
     assert axis == 0 and arrays.ndim >= 2
     return arrays.reshape((arrays.shape[0] * arrays.shape[1],) + arrays.shape[2:])
   return _np.concatenate(arrays, axis)
+
+
+def clip(x, a_min=None, a_max=None, *, min=None, max=None):  # pylint: disable=redefined-builtin
+  """jnp.clip: either bound may be missing (utils.py:280 clips from below only)."""
+  lo = a_min if a_min is not None else min
+  hi = a_max if a_max is not None else max
+  x = _np.asarray(x)
+  if lo is not None:
+    x = _np.maximum(x, lo)
+  if hi is not None:
+    x = _np.minimum(x, hi)
+  return x

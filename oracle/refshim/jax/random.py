@@ -28,3 +28,10 @@ def split(k, num=2):
 
 def fold_in(k, data):
   return k.fold(f"fold{data}")
+
+
+def beta(k, a, b, shape=None, dtype=None):
+  """A Beta(a, b) draw from the stand-in generator of this key (utils.py:1149: the mixup coefficient).  The STREAM is not
+  JAX's; what runs downstream of the draw is."""
+  del dtype
+  return k.generator().beta(a, b, size=shape)
