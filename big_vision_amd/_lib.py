@@ -65,6 +65,7 @@ PROTOTYPES = {
     "bv_pool_gap_fwd": [P, P, c_int, c_int, c_int, P],
     "bv_pool_gap_bwd": [P, P, c_int, c_int, c_int, P],
     "bv_pool_max_fwd": [P, P, P, c_int, c_int, c_int, P],
+    "bv_pool_max_masked_fwd": [P, P, P, P, c_int, c_int, c_int, P],
     "bv_pool_max_bwd": [P, P, P, c_int, c_int, c_int, P],
     "bv_l2norm_fwd": [P, P, P, c_int, c_int, c_float, P],
     "bv_l2norm_bwd": [P, P, P, P, c_int, c_int, c_float, P],

@@ -272,15 +272,19 @@ __global__ __launch_bounds__(256) void pool_gap_bwd_kernel(const float* __restri
 // pool_type "max" / "gmp" of the text tower (text_transformer.py:89-90): y[b][c] = max_l x[b][l][c]; the index of the
 // (first) maximum is kept for the backward, which routes dy[b][c] to that one position (ties have measure zero in
 // float activations; jnp.max's VJP would split the cotangent between exact ties).
+// len (nullable): only the first len[b] positions of sample b take part (NaFlex, naflex_vit.py:267-271: padded positions
+// count as finfo.min; a sample without any valid token yields -FLT_MAX at position 0)
 __global__ __launch_bounds__(256) void pool_max_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                           int* __restrict__ arg, int n, int L, int D) {
+                                                           int* __restrict__ arg, const int* __restrict__ len, int n, int L,
+                                                           int D) {
   const long total = (long)n * D;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long b = i / D;
     const int c = (int)(i - b * D);
-    float best = x[(b * L) * D + c];
+    const int Lb = len ? min(max(len[b], 0), L) : L;
+    float best = Lb > 0 ? x[(b * L) * D + c] : -3.402823466e+38f;
     int at = 0;
-    for (int l = 1; l < L; ++l) {
+    for (int l = 1; l < Lb; ++l) {
       const float v = x[(b * L + l) * D + c];
       // a NaN takes the maximum and keeps it (x.max(axis=1) propagates NaN: a diverged tower must stay visible to
       // the trainer's finiteness check); `best == best` stops later values from replacing a NaN already held
@@ -643,8 +647,14 @@ extern "C" int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, 
 extern "C" int bv_pool_max_fwd(const float* x, float* y, int* argmax, int n, int L, int D, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && D > 0 && argmax != nullptr, "bv_pool_max_fwd: bad arguments");
   hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(grid_for((long)n * D, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y,
-                     argmax, n, L, D);
+                     argmax, (const int*)nullptr, n, L, D);
   return bv_check_launch("bv_pool_max_fwd");
+}
+extern "C" int bv_pool_max_masked_fwd(const float* x, float* y, int* argmax, const int* len, int n, int L, int D, void* stream) {
+  BV_REQUIRE(n > 0 && L > 0 && D > 0 && argmax != nullptr && len != nullptr, "bv_pool_max_masked_fwd: bad arguments");
+  hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(grid_for((long)n * D, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     argmax, len, n, L, D);
+  return bv_check_launch("bv_pool_max_masked_fwd");
 }
 extern "C" int bv_pool_max_bwd(const float* dy, const int* argmax, float* dx, int n, int L, int D, void* stream) {
   BV_REQUIRE(n > 0 && L > 0 && D > 0 && argmax != nullptr, "bv_pool_max_bwd: bad arguments");

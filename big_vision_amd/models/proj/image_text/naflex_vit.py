@@ -144,6 +144,12 @@ class NaflexExec:
       ctx.update(norm=(mean, rstd))
       if collect:
         out["encoded"] = yf.view(n, N, D)
+    elif m.pool_type == "max":        # naflex_vit.py:267-271: padded tokens never win the maximum
+      _, yf, mean, rstd = self.enc.norm.fwd(xL, T, D, want_bf16=False, want_f32=True)
+      z, argmax = ops.pool_max_fwd(yf, n, N, D, lens=lens)
+      ctx.update(norm=(mean, rstd), argmax=argmax)
+      if collect:
+        out["encoded"] = yf.view(n, N, D)
     elif m.pool_type == "none":
       if save:
         raise NotImplementedError("pool_type='none' is forward-only on the accelerated path")
@@ -153,21 +159,20 @@ class NaflexExec:
         out["encoded"] = yf.view(n, N, D)
     else:
       raise NotImplementedError(f"pool_type '{m.pool_type}' (naflex_vit.py:267-271) is not implemented")
-    if m.pool_type != "none":
-      out["head_input"] = z
+    out["head_input"] = z.view(n, N, D) if m.pool_type == "none" else z      # (naflex_vit.py:276: set for every pool_type)
     if self.pre is not None:
       zb0 = ops.cast_bf16(z)
       z = ops.tanh_fwd(E.linear_fwd(zb0, self.pre[0], self.pre[1], out_dtype=F32))
       ctx["pre"] = (zb0, z)
-    out["pre_logits"] = z
+    per_token = (lambda t: t.view(n, N, -1)) if m.pool_type == "none" else (lambda t: t)     # [n, N, .] like the reference's
+    out["pre_logits"] = per_token(z)
     x = z
     if self.head is not None:
       zb = ops.cast_bf16(z)
       x = E.linear_fwd(zb, self.head[0], self.head[1], out_dtype=F32)
-      out["logits"] = x
+      out["logits"] = per_token(x)
       ctx["head_in"] = zb
-    if m.pool_type == "none":
-      x = x.view(n, N, -1)
+    x = per_token(x)
     if perm is not None and collect:   # per-token diagnostics back in the caller's token order
       inv = torch.argsort(perm, dim=1)
 
@@ -203,7 +208,7 @@ class NaflexExec:
       dy = self.map.bwd(ctx["map"], dz, n, N)          # works from the saved (masked) probabilities
       dxL = self.enc.norm.bwd(dy, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     else:
-      dyf = ops.pool_gap_bwd(dz, n, N, D, lens=lens)
+      dyf = ops.pool_max_bwd(dz, ctx["argmax"], n, N, D) if m.pool_type == "max" else ops.pool_gap_bwd(dz, n, N, D, lens=lens)
       dxL = self.enc.norm.bwd(dyf, xL, mean, rstd, T, D, dx_bf16=dxL_bf, dx_colsum=self.enc.last_b2_grad())
     dx0, dx0_bf = self.enc.bwd(ctx["enc"], dxL, dxL_bf, n, N, b2_done=True, on_block=on_block, kv_len=lens)
     # x = stem (+ patchln_post) + W . pos : d pos = W^T d x

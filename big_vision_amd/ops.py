@@ -460,12 +460,16 @@ def pool_gap_bwd(dy, n, L, D, lens=None):
   return dx
 
 
-def pool_max_fwd(x, n, L, D):
-  """max over the L positions (text pool_type "max" / "gmp"); returns (pooled [n, D], argmax int32 [n, D])."""
+def pool_max_fwd(x, n, L, D, lens=None):
+  """max over the L positions (text pool_type "max" / "gmp"); returns (pooled [n, D], argmax int32 [n, D]).
+  lens (int32 [n], optional): over the first lens[b] positions only (NaFlex pool_type "max")."""
   _chk(x, F32, "pool_max.x")
   y = torch.empty((n, D), device=x.device, dtype=F32)
   arg = torch.empty((n, D), device=x.device, dtype=torch.int32)
-  _lib.call("bv_pool_max_fwd", _p(x), _p(y), _p(arg), n, L, D, _stream())
+  if lens is not None:
+    _lib.call("bv_pool_max_masked_fwd", _p(x), _p(y), _p(arg), _p(lens), n, L, D, _stream())
+  else:
+    _lib.call("bv_pool_max_fwd", _p(x), _p(y), _p(arg), n, L, D, _stream())
   return y, arg
 
 

@@ -317,6 +317,9 @@ int bv_pool_gap_bwd(const float* dy, float* dx, int n, int L, int D, void* strea
  * the backward writes dy[i][c] there and 0 to the other L - 1 positions; fp32. */
 int bv_pool_max_fwd(const float* x, float* y, int* argmax, int n, int L, int D, void* stream);
 int bv_pool_max_bwd(const float* dy, const int* argmax, float* dx, int n, int L, int D, void* stream);
+/* The same over the first len[i] positions of sample i only (NaFlex pool_type "max", naflex_vit.py:267-271: padded tokens
+ * enter the maximum as finfo.min, i.e. never win); the backward is bv_pool_max_bwd (argmax lies inside the valid range). */
+int bv_pool_max_masked_fwd(const float* x, float* y, int* argmax, const int* len, int n, int L, int D, void* stream);
 
 /* ------------------------------------------------------------ L2 normalise --
  * zn = z / (||z||_2 + eps), eps = 1e-8 (models/proj/image_text/two_towers.py:60-61,

@@ -171,6 +171,29 @@ class Module:
     return self._run_root("apply", variables["params"], None, args, kw)
 
 
+class _JArray(np.ndarray):
+  """A numpy array with jax's VALUE semantics for augmented assignment: `x += y` rebinds x to a new array instead of
+  writing into the buffer other names still refer to (naflex_vit.py:243 does `x += posemb` on the tensor it has just
+  published as out["stem"]; under plain numpy that entry would silently become the sum).  Layer outputs are handed out
+  as this type; it propagates through numpy arithmetic."""
+
+  def __iadd__(self, other):
+    return np.add(self, other)
+
+  def __isub__(self, other):
+    return np.subtract(self, other)
+
+  def __imul__(self, other):
+    return np.multiply(self, other)
+
+  def __itruediv__(self, other):
+    return np.true_divide(self, other)
+
+
+def _value(x):
+  return np.asarray(x).view(_JArray)
+
+
 # ------------------------------------------------------------------------ layers --
 class Dense(Module):
   features: int
@@ -186,7 +209,7 @@ class Dense(Module):
     y = x @ kernel
     if self.use_bias:
       y = y + self.param("bias", binit, (self.features,), np.float32)
-    return y
+    return _value(y)
 
 
 class DenseGeneral(Module):
@@ -257,7 +280,7 @@ class LayerNorm(Module):
       y = y * self.param("scale", initializers.ones, (x.shape[-1],), np.float32)
     if self.use_bias:
       y = y + self.param("bias", initializers.zeros, (x.shape[-1],), np.float32)
-    return y
+    return _value(y)
 
 
 class Dropout(Module):

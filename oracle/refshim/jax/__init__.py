@@ -1,7 +1,7 @@
 """jax stand-in (see ../README.md): enough of the top-level namespace for the reference's model files to import and
 for their `__call__` bodies to run on numpy float64."""
 from . import numpy  # noqa: F401  (jax.numpy)
-from . import tree, tree_util, random, nn, lax, scipy, sharding  # noqa: F401
+from . import tree, tree_util, random, nn, lax, scipy, sharding, image  # noqa: F401
 
 Array = object
 
@@ -40,3 +40,15 @@ config = _Config()
 
 def process_index():
   return 0
+
+
+def vmap(fn, in_axes=0, out_axes=0):
+  """jax.vmap over the leading axis of every argument (in_axes all 0): a Python loop, results stacked."""
+  import numpy as _np
+  assert out_axes == 0 and (in_axes == 0 or all(a == 0 for a in in_axes)), (in_axes, out_axes)
+
+  def mapped(*args):
+    n = len(args[0])
+    return _np.stack([fn(*[a[i] for a in args]) for i in range(n)])
+
+  return mapped

@@ -72,3 +72,23 @@ def psum(x, axis_name):
 
 def pmean(x, axis_name):
   return _tree(lambda v: np.mean(np.stack(_tls.group.exchange(_tls.rank, np.asarray(v, np.float64))), axis=0), x)
+
+
+class GatherDimensionNumbers:
+  def __init__(self, offset_dims, collapsed_slice_dims, start_index_map, **_kw):
+    self.offset_dims, self.collapsed_slice_dims, self.start_index_map = tuple(offset_dims), tuple(collapsed_slice_dims), tuple(start_index_map)
+
+
+def gather(operand, start_indices, dimension_numbers, slice_sizes, mode=None, **_kw):
+  """jax.lax.gather for the ONE pattern naflex_vit.py:69-79 uses: operand [A, B, C], indices [L, 3] = (a, b, 0), slices
+  [1, 1, C] with the first two dims collapsed -> [L, C] = operand[a, b, :]; mode="fill": an index outside the operand
+  yields NaN (the documented failure mode of grids beyond the resize canvas)."""
+  dn = dimension_numbers
+  assert dn.offset_dims == (1,) and dn.collapsed_slice_dims == (0, 1) and dn.start_index_map == (0, 1, 2), vars(dn)
+  operand, idx = np.asarray(operand), np.asarray(start_indices)
+  assert list(slice_sizes) == [1, 1, operand.shape[-1]] and mode == "fill" and idx.shape[-1] == 3
+  a, b = idx[:, 0], idx[:, 1]
+  ok = (a >= 0) & (a < operand.shape[0]) & (b >= 0) & (b < operand.shape[1]) & (idx[:, 2] == 0)
+  out = operand[np.clip(a, 0, operand.shape[0] - 1), np.clip(b, 0, operand.shape[1] - 1), :].astype(np.float64)
+  out[~ok] = np.nan
+  return out

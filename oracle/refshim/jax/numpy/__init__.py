@@ -1,7 +1,7 @@
 """jax.numpy stand-in = numpy, with ONE policy: every floating-point array is float64, whatever float dtype is asked
 for (../README.md: dtype promotion is not pinned here; the comparison against the fp64 oracle needs full precision)."""
 import numpy as _np
-from numpy import (arange, roll, eye, diag, dot, not_equal, logical_not, logical_or, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
+from numpy import (arange, roll, eye, diag, dot, not_equal, logical_not, logical_or, logical_and, pad, finfo, equal, cos, einsum, exp, log, mean, mgrid, prod, reshape, sin, sqrt, sum, tile,  # noqa: F401
                    linalg, maximum, minimum, where, stack, transpose, zeros_like, ones_like, tanh, abs, max, min,
                    argmin, argmax, take, expand_dims, squeeze, ndarray, pi, newaxis, inf, int32, int64, uint32, bool_, searchsorted,
                    square, delete, argsort)

@@ -36,6 +36,7 @@ def _isolate_imports():
 
 TINY_IMG = dict(width=32, depth=2, mlp_dim=64, num_heads=2, patch_size=(8, 8))
 TINY_TXT = dict(width=32, depth=2, mlp_dim=64, num_heads=2, vocab_size=50)
+TINY_NAFLEX = dict(width=32, depth=2, mlp_dim=64, num_heads=2, nposemb=4, posemb="learn_2d(8)")
 ONE_IMG, ONE_TXT = dict(TINY_IMG, depth=1), dict(TINY_TXT, depth=1)     # branch variants: one block keeps the fixtures small
 
 CASES = {
@@ -73,6 +74,13 @@ CASES = {
                                   temperature_init=10.0, bias_init=-2.71), dict(image=False)),
     "two_scan": ("two", dict(image=dict(**TINY_IMG, pool_type="map", scan=True), text=dict(**TINY_TXT, scan=True),
                              out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0)),
+    # --- models/proj/image_text/naflex_vit.py:196-285: pre-patchified ragged inputs (patches, ptype, yabs, xabs), the
+    # learned position grid resized per example, key-padding masks, masked pooling
+    "naflex_gap": ("naflex", dict(num_classes=7, **TINY_NAFLEX, pool_type="gap")),
+    "naflex_map_patchln": ("naflex", dict(num_classes=None, **TINY_NAFLEX, pool_type="map", patchln_pre=True, patchln_post=True)),
+    "naflex_max_rep": ("naflex", dict(num_classes=5, **TINY_NAFLEX, pool_type="max", rep_size=16)),
+    "naflex_none_scan": ("naflex", dict(num_classes=None, **TINY_NAFLEX, pool_type="none", scan=True)),
+    "naflex_gap_holes": ("naflex", dict(num_classes=7, **TINY_NAFLEX, pool_type="gap"), dict(holes=True)),
     "two_dropout": ("two", dict(image=dict(**TINY_IMG, pool_type="map", dropout=0.1), text=dict(**TINY_TXT, dropout=0.3),
                                 out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0), dict(train=True)),
 }
@@ -101,13 +109,30 @@ def _jitter(params, np):
   walk(params, "")
 
 
+def naflex_inputs(g, holes=False):
+  """(patches, ptype, yabs, xabs) of two examples with 12 token slots: a 3 x 4 grid that fills them and a 2 x 3 grid with
+  six padding slots (ptype 0, coordinates 0) - at the end, or (holes) scattered between the patches."""
+  import numpy as np
+  n, L, pd = 2, 12, 48
+  patches = g.uniform(-1.0, 1.0, (n, L, pd))
+  ptype = np.zeros((n, L), np.int32)
+  yabs = np.zeros((n, L), np.int32)
+  xabs = np.zeros((n, L), np.int32)
+  slots = [list(range(12)), [0, 2, 3, 6, 9, 11] if holes else list(range(6))]
+  for i, (gh, gw) in enumerate(((3, 4), (2, 3))):
+    for t, s_ in enumerate(slots[i]):
+      ptype[i, s_], yabs[i, s_], xabs[i, s_] = 1, t // gw, t % gw
+  patches[ptype == 0] = 0.0
+  return patches, ptype, yabs, xabs
+
+
 def run_case(name, out_dir):
   import jax
   import numpy as np
   kind, cfg, *rest = CASES[name]
-  use = dict(image=True, text=True, train=False)
+  use = dict(image=True, text=True, train=False, holes=False)
   use.update(rest[0] if rest else {})
-  train = use.pop("train")
+  train, holes = use.pop("train"), use.pop("holes")
   tkw = dict(train=True, rngs={"dropout": jax.random.PRNGKey(5)}) if train else dict(train=False)
   g = np.random.default_rng([11, zlib.crc32(name.encode())])
   res = 32
@@ -122,6 +147,14 @@ def run_case(name, out_dir):
     _jitter(params, np)
     y, out = model.apply({"params": params}, image, **tkw)
     arrays.update({"in/image": image, "y": y})
+  elif kind == "naflex":
+    from big_vision.models.proj.image_text import naflex_vit
+    nf = naflex_inputs(g, holes)
+    model = naflex_vit.Model(**cfg)
+    params = model.init(jax.random.PRNGKey(0), nf)["params"]
+    _jitter(params, np)
+    y, out = model.apply({"params": params}, nf, **tkw)
+    arrays.update({"in/patches": nf[0], "in/ptype": nf[1], "in/yabs": nf[2], "in/xabs": nf[3], "y": y})
   elif kind == "txt":
     from big_vision.models.proj.image_text import text_transformer
     model = text_transformer.Model(**cfg)

@@ -31,7 +31,7 @@ def _batch(seed, grids=GRIDS, N=36):
   return patches, ptype, yabs, xabs
 
 
-def _case(dev, cfg, case, shuffle=False):
+def _case(dev, cfg, case, shuffle=False, **bounds):
   import bv_oracle as O
   import _parity
   from big_vision_amd import utils as u
@@ -77,7 +77,7 @@ def _case(dev, cfg, case, shuffle=False):
   gref = {k: v.grad for k, v in u.tree_flatten_with_names(params64)[0]}
   gours = {k: v.detach().cpu().double() for k, v in u.tree_flatten_with_names(store.tree("grad"))[0]}
   fl = _parity.bf16_floor(lambda p: loss_of(p)[0], params64)
-  _parity.compare_grads(case, gref, gours, floor=fl)
+  _parity.compare_grads(case, gref, gours, floor=fl, **bounds)
   # the CONTENT of padding slots must not matter: garbage there, same pooled output
   junk = image[0].clone()
   junk[image[1] == 0] = 37.0
@@ -94,6 +94,30 @@ def test_naflex_gap_patchln_head(dev):
   _case(dev, dict(width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="gap", nposemb=8, posemb="learn_2d(16)",
                   patchln_pre=True, patchln_post=True, rep_size=True),
         "NaFlex tiny gap + patchln + pre_logits")
+
+
+def test_naflex_max_pooling(dev):
+  """pool_type="max" (naflex_vit.py:267-271): the maximum over the VALID tokens (bv_pool_max_masked_fwd), gradient routed
+  to the winning token; the junk-in-padding check of _case proves that padded tokens never win."""
+  _case(dev, dict(width=128, depth=1, mlp_dim=256, num_heads=2, pool_type="max", nposemb=8, posemb="learn_2d(16)", rep_size=True),
+        "NaFlex tiny max pooling + pre_logits", rel_max=6e-2, cos_min=0.998)
+  # (bounds: a maximum is discontinuous - bf16 operand rounding alone moves the winner of near-ties, the measured
+  # bf16-operand floor of this case is rel-L2 0.07-0.08 / cosine 0.9966, printed beside every tensor; the kernel itself is
+  # held to exact equality below)
+  from big_vision_amd import ops
+  g = torch.Generator().manual_seed(3)
+  n, L, D = 5, 12, 64
+  x = torch.randn((n, L, D), generator=g)
+  lens = torch.tensor([12, 7, 1, 3, 12], dtype=torch.int32)
+  x[1, 9] = 100.0      # larger than every valid entry, but padding
+  y, arg = ops.pool_max_fwd(x.to(dev).view(n * L, D).contiguous(), n, L, D, lens=lens.to(dev))
+  for b in range(n):
+    want = x[b, :lens[b]].max(dim=0)
+    assert torch.equal(y[b].cpu(), want.values) and torch.equal(arg[b].cpu().long(), want.indices), b
+  dy = torch.randn((n, D), generator=g)
+  dx = ops.pool_max_bwd(dy.to(dev), arg, n, L, D).cpu().view(n, L, D)
+  ref = torch.zeros((n, L, D)).scatter_(1, arg.cpu().long()[:, None, :], dy[:, None, :])
+  assert torch.equal(dx, ref)
 
 
 def test_naflex_mask_with_holes(dev):

@@ -135,6 +135,11 @@ def _oracle_run(z, meta, mutate=None):
   if kind == "txt":
     y, out = O.text_forward(params, text, **cfg, drop=drop[""] if drop else None)
     return {"y": y}, out
+  if kind == "naflex":
+    nf = (torch.from_numpy(z["in/patches"]), torch.from_numpy(z["in/ptype"]), torch.from_numpy(z["in/yabs"]).long(),
+          torch.from_numpy(z["in/xabs"]).long())
+    y, out = O.naflex_vit_forward(params, nf, **{k: v for k, v in cfg.items() if k != "scan"})
+    return {"y": y}, out
   image_cfg = dict(cfg["image"], patch_size=tuple(cfg["image"]["patch_size"]))
   out_dim = cfg["out_dim"] if isinstance(cfg["out_dim"], int) else tuple(cfg["out_dim"])
   zi, zt, out = O.two_towers_forward(params, image, text, image_cfg=image_cfg, text_cfg=cfg["text"], out_dim=out_dim,
@@ -195,6 +200,10 @@ def _product_tree(meta):
       cfg["patch_size"] = tuple(cfg["patch_size"])
     m = vit.Model(**cfg)
     st = ParamStore(m.entries("", m.grid((2, 32, 32, 3))), "cpu", scan_prefixes=m.scan_prefixes())
+  elif kind == "naflex":
+    from big_vision_amd.models.proj.image_text import naflex_vit
+    m = naflex_vit.Model(**cfg)
+    st = ParamStore(m.entries("", 48), "cpu", scan_prefixes=m.scan_prefixes())
   elif kind == "txt":
     m = text_transformer.Model(**cfg)
     st = ParamStore(m.entries("", 8), "cpu", scan_prefixes=m.scan_prefixes())
