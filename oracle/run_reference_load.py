@@ -232,6 +232,9 @@ SCENARIOS = [
 ]
 
 
+VARIANTS = [n + p for n in ("mu", "Ti", "S", "M", "B", "L", "So400m", "H", "g", "g-opt", "G", "G-opt", "e") for p in ("", "/16", "/14", "/32", "/8")]
+
+
 def call(sc, vit, text_transformer, two_towers, common, config_of):
   """Runs one scenario through a set of loader modules (the reference's here, the product's in the test)."""
   if sc["kind"] == "vit":
@@ -269,11 +272,14 @@ def main():
         meta[name] = {"leaves": list(flat), "dtypes": sorted({str(np.asarray(v).dtype) for v in flat.values()})}
       except Exception as e:     # recorded: the product must fail the same way
         meta[name] = {"error": type(e).__name__, "message": scrub(str(e), tmp)}
+  # the variant table (vit.py:284-303), every name x a few patch sizes, as the reference decodes them
+  meta["__variants__"] = {v: {k: (list(x) if isinstance(x, tuple) else x) for k, x in vit.decode_variant(v).items()}
+                          for v in VARIANTS}
   arrays["meta"] = np.frombuffer(json.dumps(meta, sort_keys=True).encode(), np.uint8)
   np.savez_compressed(os.path.join(out_dir, "refload.npz"), **arrays)
   print(len(SCENARIOS), "scenarios,", sum("error" in m for m in meta.values()), "raise")
   for n, m in meta.items():
-    if "error" in m:
+    if "error" in m and n != "__variants__":
       print(" ", n, m["error"], m["message"][:90].replace("\n", " | "))
 
 

@@ -80,7 +80,19 @@ def test_the_fixture_covers_the_fixups(golden):
   assert not same(z["txt_posemb_added_twice/pos_embedding"], RL.txt_tree(1)["pos_embedding"])
   assert same(z["two_single_file_without_bias/b"], RL._r(RL._gen("b0"), 1)) and same(z["two_single_file_with_bias/b"], RL._r(RL._gen("b"), 1))
   assert " - MAPHead_0/probe" in meta["vit_missing_leaf_raises"]["message"] and " + extra/kernel" in meta["vit_extra_leaf_raises"]["message"]
-  assert sum("error" in m for m in meta.values()) == 4
+  assert sum("error" in m for k, m in meta.items() if k != "__variants__") == 4
+
+
+def test_variant_table_equals_the_reference(golden):
+  """`decode_variant` (vit.py:284-303) for all 13 model names x {no patch, /16, /14, /32, /8}, as the REFERENCE decodes
+  them, vs the product's (the table the factory and `Model(variant=...)` read)."""
+  from big_vision_amd.models import vit
+  _, meta = golden
+  assert len(meta["__variants__"]) == len(RL.VARIANTS) == 65
+  for v, want in meta["__variants__"].items():
+    got = {k: (list(x) if isinstance(x, tuple) else x) for k, x in vit.decode_variant(v).items()}
+    assert got == want, (v, got, want)
+  assert vit.decode_variant(None) == {}
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(RL.REFERENCE, "big_vision")), reason="the reference tree is not on this host")
