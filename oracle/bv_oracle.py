@@ -551,7 +551,7 @@ def init_bert(gen, *, config, num_classes=None, head_zeroinit=True, dtype=torch.
   return p
 
 
-def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None, drop=None,
+def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, text_model=None, image_model=None, drop=None,
                        **_unused):
   """models/proj/image_text/two_towers.py:39-90; drop: {"img": DropMasks, "txt": DropMasks} (either may be missing) for
   a train-mode pass of towers configured with dropout > 0 (:56, :69 hand `train` down to both towers)."""
@@ -572,7 +572,10 @@ def two_towers_forward(params, image, text, *, image_cfg, text_cfg, out_dim, tex
   if image is not None:
     kw = {**decode_variant(image_cfg.get("variant")),
           **{k: v for k, v in image_cfg.items() if k != "variant"}}
-    zimg, o = vit_forward(params["img"], image, num_classes=out_dims[0], **{**kw, "drop": drop.get("img")})
+    if image_model == "proj.image_text.naflex_vit":     # two_towers.py:64-66: towers by module path
+      zimg, o = naflex_vit_forward(params["img"], image, num_classes=out_dims[0], **kw)
+    else:
+      zimg, o = vit_forward(params["img"], image, num_classes=out_dims[0], **{**kw, "drop": drop.get("img")})
     out.update({f"img/{k}": v for k, v in o.items()})
     out["img/norm"] = torch.linalg.norm(zimg, dim=1, keepdim=True)
     out["img/normalized"] = zimg = zimg / (out["img/norm"] + 1e-8)

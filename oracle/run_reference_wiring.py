@@ -81,6 +81,8 @@ CASES = {
     "naflex_max_rep": ("naflex", dict(num_classes=5, **TINY_NAFLEX, pool_type="max", rep_size=16)),
     "naflex_none_scan": ("naflex", dict(num_classes=None, **TINY_NAFLEX, pool_type="none", scan=True)),
     "naflex_gap_holes": ("naflex", dict(num_classes=7, **TINY_NAFLEX, pool_type="gap"), dict(holes=True)),
+    "two_naflex": ("two", dict(image=dict(**TINY_NAFLEX, pool_type="map"), text=dict(**TINY_TXT), image_model="proj.image_text.naflex_vit",
+                               out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0), dict(naflex=True)),
     "two_dropout": ("two", dict(image=dict(**TINY_IMG, pool_type="map", dropout=0.1), text=dict(**TINY_TXT, dropout=0.3),
                                 out_dim=(None, 32), temperature_init=10.0, bias_init=-10.0), dict(train=True)),
 }
@@ -130,9 +132,9 @@ def run_case(name, out_dir):
   import jax
   import numpy as np
   kind, cfg, *rest = CASES[name]
-  use = dict(image=True, text=True, train=False, holes=False)
+  use = dict(image=True, text=True, train=False, holes=False, naflex=False)
   use.update(rest[0] if rest else {})
-  train, holes = use.pop("train"), use.pop("holes")
+  train, holes, two_naflex = use.pop("train"), use.pop("holes"), use.pop("naflex")
   tkw = dict(train=True, rngs={"dropout": jax.random.PRNGKey(5)}) if train else dict(train=False)
   g = np.random.default_rng([11, zlib.crc32(name.encode())])
   res = 32
@@ -165,12 +167,16 @@ def run_case(name, out_dir):
   else:
     from big_vision.models.proj.image_text import two_towers
     model = two_towers.Model(**cfg)
+    if two_naflex:     # the image tower takes (patches, ptype, yabs, xabs)
+      image = naflex_inputs(g)
     params = model.init(jax.random.PRNGKey(0), image, text)["params"]      # both towers exist in the tree
     _jitter(params, np)
     im = image if use["image"] else None
     tx = text if use["text"] else None
     zimg, ztxt, out = model.apply({"params": params}, im, tx, **(tkw if train else {}))
-    if im is not None:
+    if im is not None and two_naflex:
+      arrays.update({"in/patches": im[0], "in/ptype": im[1], "in/yabs": im[2], "in/xabs": im[3], "z/img": zimg})
+    elif im is not None:
       arrays.update({"in/image": image, "z/img": zimg})
     if tx is not None:
       arrays.update({"in/text": text, "z/txt": ztxt})

@@ -140,9 +140,15 @@ def _oracle_run(z, meta, mutate=None):
           torch.from_numpy(z["in/xabs"]).long())
     y, out = O.naflex_vit_forward(params, nf, **{k: v for k, v in cfg.items() if k != "scan"})
     return {"y": y}, out
-  image_cfg = dict(cfg["image"], patch_size=tuple(cfg["image"]["patch_size"]))
+  image_cfg = dict(cfg["image"])
+  if "patch_size" in image_cfg:
+    image_cfg["patch_size"] = tuple(image_cfg["patch_size"])
+  if "in/patches" in z.files:      # the NaFlex image tower
+    image = (torch.from_numpy(z["in/patches"]), torch.from_numpy(z["in/ptype"]), torch.from_numpy(z["in/yabs"]).long(),
+             torch.from_numpy(z["in/xabs"]).long())
   out_dim = cfg["out_dim"] if isinstance(cfg["out_dim"], int) else tuple(cfg["out_dim"])
   zi, zt, out = O.two_towers_forward(params, image, text, image_cfg=image_cfg, text_cfg=cfg["text"], out_dim=out_dim,
+                                     image_model=cfg.get("image_model"),
                                      drop=None if not drop else {"img": drop.get("img/"), "txt": drop.get("txt/")})
   return {k: v for k, v in (("z/img", zi), ("z/txt", zt)) if v is not None}, out
 
@@ -208,11 +214,12 @@ def _product_tree(meta):
     m = text_transformer.Model(**cfg)
     st = ParamStore(m.entries("", 8), "cpu", scan_prefixes=m.scan_prefixes())
   else:
-    cfg["image"]["patch_size"] = tuple(cfg["image"]["patch_size"])
+    if "patch_size" in cfg["image"]:
+      cfg["image"]["patch_size"] = tuple(cfg["image"]["patch_size"])
     if not isinstance(cfg["out_dim"], int):
       cfg["out_dim"] = tuple(cfg["out_dim"])
     m = two_towers.Model(**cfg)
-    st = m.make_store((2, 32, 32, 3), (2, 8), device="cpu")
+    st = m.make_store((2, 12, 48) if cfg.get("image_model") else (2, 32, 32, 3), (2, 8), device="cpu")
   return {n: tuple(v.shape) for n, v in u.tree_flatten_with_names(dict(st.tree()))[0]}
 
 

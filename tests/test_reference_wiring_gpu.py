@@ -88,13 +88,17 @@ def test_product_matches_the_executed_reference(name):
     y, out = text_transformer.Model(**cfg).apply({"params": params}, text)
     ys = {"y": y}
   else:
-    cfg["image"]["patch_size"] = tuple(cfg["image"]["patch_size"])
+    if "patch_size" in cfg["image"]:
+      cfg["image"]["patch_size"] = tuple(cfg["image"]["patch_size"])
+    if "in/patches" in z.files:      # the NaFlex image tower takes (patches, ptype, yabs, xabs)
+      image = (torch.from_numpy(z["in/patches"].astype(np.float32)).to(dev), torch.from_numpy(z["in/ptype"].astype(np.int32)).to(dev),
+               torch.from_numpy(z["in/yabs"].astype(np.int32)).to(dev), torch.from_numpy(z["in/xabs"].astype(np.int32)).to(dev))
     if not isinstance(cfg["out_dim"], int):
       cfg["out_dim"] = tuple(cfg["out_dim"])
     zi, zt, out = two_towers.Model(**cfg).apply({"params": params}, image, text)
     ys = {k: v for k, v in (("z/img", zi), ("z/txt", zt)) if v is not None}
   torch.cuda.synchronize()
-  rows = (z["in/ptype"] == 1) if kind == "naflex" else None
+  rows = (z["in/ptype"] == 1) if "in/ptype" in z.files else None
   for k, v in ys.items():
     _close(v, z[k], k, rows=rows)
   got = _flat(out)
