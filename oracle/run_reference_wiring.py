@@ -272,6 +272,19 @@ def run_losses(out_dir):
   return keys
 
 
+def model_fields():
+  """The dataclass fields (name, default) of the reference's model classes, in definition order: the constructor surface a
+  config reaches through `Model(**config.model)` (8b contract)."""
+  import flax.linen as nn
+  from big_vision.models import vit
+  from big_vision.models.proj.image_text import naflex_vit, text_transformer, two_towers
+  out = {}
+  for key, cls in (("vit", vit._Model), ("proj.image_text.text_transformer", text_transformer._Model),
+                   ("proj.image_text.two_towers", two_towers.Model), ("proj.image_text.naflex_vit", naflex_vit._Model)):
+    out[key] = [[k, "<required>" if d is nn._MISSING else (list(d) if isinstance(d, tuple) else d)] for k, d in nn._fields_of(cls)]
+  return out
+
+
 def main():
   out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "tests", "golden")
   if not os.path.isdir(os.path.join(REFERENCE, "big_vision")):
@@ -289,6 +302,7 @@ def main():
   print("losses:", summary["losses"])
   summary["scan_roundtrip"] = scan_roundtrip(out_dir)
   print("scan round trip:", {k: v for k, v in summary["scan_roundtrip"].items() if k != "loop_names"})
+  summary["model_fields"] = model_fields()
   with open(os.path.join(out_dir, "refwiring_summary.json"), "w") as f:
     json.dump(summary, f, indent=1, sort_keys=True)
 

@@ -233,6 +233,24 @@ def test_product_parameter_tree_has_the_reference_names_and_shapes(name):
     assert got[n] == want[n], (n, got[n], want[n])
 
 
+def test_product_constructors_take_the_reference_fields():
+  """`Model(**config.model)`: every dataclass field of the reference's model classes (read off the executed classes) is a
+  keyword of the product's constructor with the same default, in the same order (positional use: `Model(num_classes, ...)`)."""
+  import inspect
+  from big_vision_amd.models import vit
+  from big_vision_amd.models.proj.image_text import naflex_vit, text_transformer, two_towers
+  want = json.load(open(os.path.join(GOLDEN, "refwiring_summary.json")))["model_fields"]
+  prod = {"vit": vit._Model, "proj.image_text.text_transformer": getattr(text_transformer, "_Model", None) or text_transformer.Model,
+          "proj.image_text.two_towers": two_towers.Model, "proj.image_text.naflex_vit": naflex_vit._Model}
+  assert set(want) == set(prod)
+  for key, fields in want.items():
+    params = [p for p in inspect.signature(prod[key].__init__).parameters.values() if p.name != "self"]
+    got = [[p.name, "<required>" if p.default is inspect.Parameter.empty else (list(p.default) if isinstance(p.default, tuple) else p.default)]
+           for p in params]
+    assert got[:len(fields)] == fields, (key, got[:len(fields)], fields)
+    assert all(p.default is not inspect.Parameter.empty for p in params[len(fields):]), key     # extras are optional (name=...)
+
+
 def test_reference_scan_and_loop_layouts_agree():
   s = json.load(open(os.path.join(GOLDEN, "refwiring_summary.json")))["scan_roundtrip"]
   assert s["max_abs_diff_scan_vs_loop"] <= 1e-12 and s["pyloop_to_scan_inverts"]
