@@ -68,10 +68,24 @@ def tree_unflatten(names_and_vals):
 
 
 def tree_map_with_names(f, tree, *rest):
+  """f(name, leaf, *leaves of `rest` at the same position) over the leaves; the result has the STRUCTURE of `tree`
+  (utils.py:676-696: `tree_def.unflatten`) - dicts stay dicts, lists / tuples keep their type, `None` stays `None`."""
   names_and_vals, _ = tree_flatten_with_names(tree)
   rest_vals = [[v for _, v in tree_flatten_with_names(t)[0]] for t in rest]
-  out = [f(n, v, *[rv[i] for rv in rest_vals]) for i, (n, v) in enumerate(names_and_vals)]
-  return recover_tree([n for n, _ in names_and_vals], out)
+  assert all(len(rv) == len(names_and_vals) for rv in rest_vals), "trees of different structure"
+  mapped = {n: f(n, v, *[rv[i] for rv in rest_vals]) for i, (n, v) in enumerate(names_and_vals)}
+
+  def rebuild(node, prefix):
+    if node is None:
+      return None
+    if isinstance(node, Mapping):
+      return {k: rebuild(node[k], prefix + (str(k),)) for k in node}
+    if isinstance(node, (list, tuple)):
+      items = [rebuild(v, prefix + (str(i),)) for i, v in enumerate(node)]
+      return type(node)(*items) if hasattr(node, "_fields") else type(node)(items)
+    return mapped["/".join(prefix)]
+
+  return rebuild(tree, ())
 
 
 def tree_map(f, tree, *rest):
