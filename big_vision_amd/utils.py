@@ -294,13 +294,20 @@ def get_mixup_coefficient(rng, step, p):
 
 
 def get_mixup(rng, p, step=0):
-  """Mirror of utils.get_mixup (utils.py:1146-1154): returns `_mixup(*things)` which gives back
-  (rng, mixed things); every thing is a [n, ...] fp32 GPU tensor, mixed with its roll by one
-  along dim 0 (bv_mixup kernel)."""
+  """Mirror of utils.get_mixup (utils.py:1146-1154): returns `_mixup(*things, **more_things)` which gives back
+  `(rng, things, more_things)` - a TUPLE of the mixed positional things and a DICT of the mixed keyword things, exactly the
+  shape train.py:285-289 unpacks (`rng, (images, labels), _ = ...`).  Every thing is a [n, ...] fp32 GPU tensor, mixed with
+  its roll by one along dim 0 (bv_mixup kernel) under one coefficient a = max(a, 1 - a), a ~ Beta(p, p)."""
   from big_vision_amd import ops
   a = get_mixup_coefficient(rng, step, p)
+  mix = lambda t: ops.mixup(t.contiguous(), a)
 
-  def _mixup(*things):
-    return (rng, *[ops.mixup(t.contiguous(), a) for t in things])
+  def _mixup(*things, **more_things):
+    return rng, tuple(mix(t) for t in things), {k: mix(t) for k, t in more_things.items()}
   _mixup.a = a
   return _mixup
+
+
+def mixup(rng, *things, p, **more_things):
+  """The legacy spelling (utils.py:1158-1159)."""
+  return get_mixup(rng, p)(*things, **more_things)

@@ -44,3 +44,18 @@ def test_mixup_kernel_equals_the_executed_reference(dev):
     x = torch.from_numpy(z[f"in/{k}"].astype(np.float32)).to(dev).contiguous()
     got = ops.mixup(x, a).cpu().double().numpy()
     assert np.max(np.abs(got - z[f"mixup/{k}"])) <= 3e-7 * max(1.0, float(np.max(np.abs(z[f"mixup/{k}"])))), k
+
+
+def test_get_mixup_has_the_reference_call_shape(dev):
+  """`rng, (images, labels), _ = u.get_mixup(rng, p)(images, labels)` (train.py:285-289) and the legacy keyword spelling
+  (utils.py:1158-1159) unpack as they do on the reference; the mixing itself is the kernel checked above."""
+  from big_vision_amd import ops, utils as u
+  z = np.load(GOLDEN)
+  images = torch.from_numpy(z["in/images"].astype(np.float32)).to(dev)
+  labels = torch.from_numpy(z["in/labels"].astype(np.float32)).to(dev)
+  fn = u.get_mixup(7, 0.2)
+  rng, (mi, ml), more = fn(images, labels)
+  assert rng == 7 and more == {} and 0.5 <= fn.a <= 1.0
+  assert torch.equal(mi, ops.mixup(images.contiguous(), fn.a)) and torch.equal(ml, ops.mixup(labels.contiguous(), fn.a))
+  rng2, things, kw = u.mixup(7, images, p=0.2, labels=labels)
+  assert len(things) == 1 and set(kw) == {"labels"} and torch.equal(things[0], mi) and torch.equal(kw["labels"], ml)
