@@ -789,6 +789,22 @@ class Optimizer:
     self.count = int(d["count"])
 
 
+def replace_frozen(schedule, pytree, replacement, log=None):
+  """Replaces the values of `pytree` whose parameter is frozen (a `None` entry of `schedule`) with `replacement`
+  (optax.py:44-51; trainers use it for `l2_grads`: the norm of the gradients that are applied, train.py:307)."""
+  del log
+  if not isinstance(schedule, (list, tuple)):
+    return pytree
+  patterns, scheds = zip(*schedule)
+  masks = u.make_mask_trees(pytree, patterns)
+  flat_masks = [dict(u.tree_flatten_with_names(m)[0]) for m in masks]
+  names = [n for n, _ in u.tree_flatten_with_names(pytree)[0]]
+  not_covered = [n for n in names if not any(m[n] for m in flat_masks)]
+  assert not not_covered, f"All params must be covered (use `None` for freezing): {not_covered}"
+  frozen = {n: any(m[n] for m, s_ in zip(flat_masks, scheds) if s_ is None) for n in names}
+  return u.tree_map_with_names(lambda n, v: replacement if frozen[n] else v, pytree)
+
+
 def make(config, store: ParamStore, *, sched_kw, comm=None, shard=False):
   """Returns (optimizer, schedule_fns) like bv_optax.make returns (tx, sched_fns).  comm / shard: see Optimizer."""
   opt = Optimizer(config, store, sched_kw=sched_kw, comm=comm, shard=shard)

@@ -176,6 +176,13 @@ def run_model_state_names(out_dir):
     tx, _ = bv_optax.make(_config(cfg), params, sched_kw=dict(SCHED_KW))
     flat = u.tree_flatten_with_names(tx.init(params))[0]
     out[name] = dict(fixture=fixture, config=cfg, state=[[k, list(np.shape(v))] for k, v in flat])
+  # replace_frozen (optax.py:44-51) on an integer-leaved tree with the schedules of the cases above
+  tree = _nest({k: i + 1 for i, k in enumerate(SHAPES)})
+  out["__replace_frozen__"] = {}
+  for cname in ("adam_frozen_mults", "adafactor_f32mom_frozen", "adam_clip_wd"):
+    sched = CASES[cname]["schedule"]
+    res = bv_optax.replace_frozen(sched, tree, 0)
+    out["__replace_frozen__"][cname] = {"schedule": sched, "result": [[k, int(v)] for k, v in u.tree_flatten_with_names(res)[0]]}
   with open(os.path.join(out_dir, "refoptax_state_names.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 

@@ -165,6 +165,21 @@ def dry(monkeypatch):
   return calls
 
 
+def test_product_replace_frozen_equals_the_executed_reference():
+  """optax.py:44-51 (what a trainer's `l2_grads` goes through, train.py:307)."""
+  from big_vision_amd import optax as bv_optax
+  from big_vision_amd import utils as u
+  want = json.load(open(os.path.join(GOLDEN, "refoptax_state_names.json")))["__replace_frozen__"]
+  tree = RO._nest({k: i + 1 for i, k in enumerate(RO.SHAPES)})
+  for cname, w in want.items():
+    sched = w["schedule"] if isinstance(w["schedule"], dict) else [tuple(x) for x in w["schedule"]]
+    got = [[k, int(v)] for k, v in u.tree_flatten_with_names(bv_optax.replace_frozen(sched, tree, 0))[0]]
+    assert got == w["result"], cname
+  assert any(v == 0 for _, v in want["adam_frozen_mults"]["result"]) and all(v for _, v in want["adam_clip_wd"]["result"])
+  with pytest.raises(AssertionError, match="All params must be covered"):
+    bv_optax.replace_frozen([("img/.*", None)], tree, 0)
+
+
 @pytest.mark.parametrize("case", sorted(RO.MODEL_STATE_CASES))
 def test_product_optimizer_state_has_the_reference_names_and_shapes(dry, case):
   """`Optimizer.state_tree()` of the product for a real two-tower parameter tree = the names and shapes of the state the
@@ -174,7 +189,7 @@ def test_product_optimizer_state_has_the_reference_names_and_shapes(dry, case):
   from big_vision_amd.compat.ml_collections import ConfigDict
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
-  want = json.load(open(os.path.join(GOLDEN, "refoptax_state_names.json")))[case]
+  want = json.load(open(os.path.join(GOLDEN, "refoptax_state_names.json")))[case]      # ("__replace_frozen__" is not a case)
   zf = np.load(os.path.join(GOLDEN, f"{want['fixture']}.npz"))
   mcfg = json.loads(bytes(zf["meta"]).decode())["config"]
   mcfg["image"]["patch_size"] = tuple(mcfg["image"]["patch_size"])
