@@ -312,6 +312,12 @@ class Optimizer:
                         ("lr_eff", np.float32), ("wd", np.float32)], align=True)
     assert AF_LEAF.itemsize == 88, AF_LEAF.itemsize
     own = [lf for lf in self.af_leaves if lf["own"]]   # the leaves this rank updates (all of them when replicated)
+    if self.sharded:
+      # the own-run buffers (fp32 master, momentum) reach the kernel as base pointers shifted by -lo (_adafactor_step):
+      # every row of this rank's table must address elements of [lo, hi) only
+      for lf in own:
+        e = st.entries[st.leaf_index[lf["leaf"]][0]]
+        assert self.lo <= e.offset and e.offset + e.numel <= self.hi, (lf["leaf"], e.offset, e.numel, self.lo, self.hi)
     self.af_nown = len(own)
     # bv_adafactor_step launches a 2-D grid (extent of the LARGEST leaf of the table) x (leaves), and a workgroup beyond
     # its own leaf's extent returns at once: with one table for the whole model the 300 biases / LayerNorm scales would
