@@ -15,7 +15,7 @@ by the reference's own known answers, optax_test.py:103-318, in tests/test_oracl
 Everything computes in numpy float64 (the policy of ../jax/numpy) with ONE exception: an accumulator dtype of bfloat16
 (`mu_dtype`, `ema(accumulator_dtype=...)`, `trace(...)`) rounds the STORED accumulator to bfloat16 - that rounding is
 part of the algorithm the product and the oracle implement (2^-9 relative), not a promotion detail."""
-from typing import Any, Callable, NamedTuple, Optional
+from typing import Any, Callable, NamedTuple
 
 import numpy as np
 
