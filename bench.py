@@ -308,7 +308,7 @@ def cpu_baseline(sample_pairs, samples=2):
   step(2)  # page in / thread-pool warm-up
   # two sample sizes ("n = 8 / 16 / 32 ... scales ~linearly in n"): half and one-and-a-half times the
   # requested sample, together the CPU work of two samples of it (~30-40 s); `value` is the larger one's rate
-  sizes = sorted({max(2, sample_pairs // 2), max(2, sample_pairs * 3 // 2)}) if samples > 1 else [sample_pairs]
+  sizes = sorted({max(2, sample_pairs // 2), max(2, sample_pairs * 3 // 2)}) if samples > 1 and sample_pairs > 2 else [max(2, sample_pairs)]   # (--cpu-sample 2: smoke runs, one sample)
   times = []
   for n in sizes:
     if times and times[-1] / sizes[len(times) - 1] * n > 90.0:

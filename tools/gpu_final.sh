@@ -12,7 +12,7 @@ O=gpurun_out/final
 mkdir -p $O
 if [[ " $* " == *" tests "* ]]; then
   rm -f gpurun_out/parity_report.jsonl
-  timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/pytest.txt; cat $O/pytest.txt
+  BV_PARITY_FLOOR=1 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/pytest.txt; cat $O/pytest.txt
   cp gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null
 fi
 if [[ " $* " == *" bench "* ]]; then
