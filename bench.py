@@ -41,6 +41,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
+# Kernel arguments in device memory (read by the HIP runtime when it initialises, i.e. at the first GPU call): a step is
+# ~1600 launches; measured -0.5 % at the 512-pair rank shape (86.6 -> 86.2 ms, profiles/r06_kernarg_ab.txt), nothing on the
+# headline.  A deployment sets it in its own environment; an explicit value is left alone.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch  # noqa: E402
 
 GLOBAL_BATCH = 4096
