@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import importlib
 import math
+import os
 
 import torch
 
@@ -52,7 +53,9 @@ class TwoTowersExec:
     contexts when the backward runs on one stream) are `record_stream(main)`-ed where they cross."""
     main = torch.cuda.current_stream()
     if self._side is None:
-      self._side = torch.cuda.Stream(device=self.store.device)
+      # BV_SIDE_STREAM_PRIORITY (A/B knob, tools/stream_priority_ab.py): HIP priority of the text tower's stream
+      # (-1 = high, 0 = the default); within the noise: 512 pairs +-0.2 %, headline -0.4 +- 0.4 % (profiles/r06_stream_priority_ab.txt)
+      self._side = torch.cuda.Stream(device=self.store.device, priority=int(os.environ.get("BV_SIDE_STREAM_PRIORITY", "0")))
     E.refresh_twins(self.store)
     mc = ops.ctx()
     with torch.cuda.stream(self._side):
