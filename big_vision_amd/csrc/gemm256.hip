@@ -96,8 +96,17 @@ __device__ __forceinline__ s16x4 lds_read_tr64(uint32_t addr) {
   return v;
 }
 
+// Cache policy of the operand DMA (the instruction's aux field: 1 = sc0, 2 = nt, 16 = sc1), per operand.  0 / 0 ships;
+// tools/gemm_cachepolicy_ab.py builds the other combinations (-DBV_GLDS_AUX_A=.. -DBV_GLDS_AUX_B=..) and times them.
+#ifndef BV_GLDS_AUX_A
+#define BV_GLDS_AUX_A 0
+#endif
+#ifndef BV_GLDS_AUX_B
+#define BV_GLDS_AUX_B 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const bf16* src, char* dst_wave_base) {
-  __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst_wave_base, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gl_void*)src, (lds_void*)dst_wave_base, 16, 0, AUX);
 }
 
 // 16-byte global stores / loads with an optional streaming (nontemporal) hint: the outputs of
@@ -280,15 +289,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
     if (BV_PROBE(3) && probe_no_dma) return;
     char* d = ldsA + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcA + c.offA + (long)c.t * stepA + (h ? hA : 0);
-    glds16(s, d);
-    glds16(s + gA, d + 8192);
+    glds16<BV_GLDS_AUX_A>(s, d);
+    glds16<BV_GLDS_AUX_A>(s + gA, d + 8192);
   };
   auto issueB = [&](const Cursor& c, int slot, int h) {
     if (BV_PROBE(3) && probe_no_dma) return;
     char* d = ldsB + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcB + c.offB + (long)c.t * stepB + (h ? hB : 0);
-    glds16(s, d);
-    glds16(s + gB, d + 8192);
+    glds16<BV_GLDS_AUX_B>(s, d);
+    glds16<BV_GLDS_AUX_B>(s + gB, d + 8192);
   };
 
 #ifdef BV_GEMM256_PROBES
@@ -999,14 +1008,14 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(G256Params p) {
   auto issueA = [&](const Cursor& c, int slot, int h) {
     char* d = ldsA + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcA + c.offA + (long)c.t * 64 + (h ? hA : 0);
-    glds16(s, d);
-    glds16(s + gA, d + 8192);
+    glds16<BV_GLDS_AUX_A>(s, d);
+    glds16<BV_GLDS_AUX_A>(s + gA, d + 8192);
   };
   auto issueB = [&](const Cursor& c, int slot, int h) {
     char* d = ldsB + (slot * 2 + h) * HALF + wave_off;
     const bf16* s = srcB + c.offB + (long)c.t * 64 + (h ? hB : 0);
-    glds16(s, d);
-    glds16(s + gB, d + 8192);
+    glds16<BV_GLDS_AUX_B>(s, d);
+    glds16<BV_GLDS_AUX_B>(s + gB, d + 8192);
   };
 
   // ---- per-lane LDS read addresses (relative to the stage base), as gemm256_kernel<true>
