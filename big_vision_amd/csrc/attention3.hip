@@ -39,6 +39,15 @@
 #ifndef A3_PIPE
 #define A3_PIPE 1   // 1: software-pipelined S / P V loops of the 3-workgroups-per-CU forward (0: the plain loops, A/B)
 #endif
+#ifndef A3_PIPE_LONG
+#define A3_PIPE_LONG 0   // 1: the same software pipeline in the one-workgroup-per-CU forward of the long sequences (28 / 36 key
+#endif                   //    fragments, 2 waves per SIMD: 256 VGPRs hold the two operand sets); A/B: tools/attn_fwd_long_ab.py
+#ifndef A3_DQ_PIPE
+#define A3_DQ_PIPE 0     // 1: the one-sweep dQ kernel of the long sequences (28 / 36 key fragments, 2 waves per SIMD) requests the
+#endif                   //    K / V rows of the next PAIR of key fragments before the current pair is computed; A/B: tools/attn_fwd_long_ab.py
+#ifndef A4_DKV_PIPE
+#define A4_DKV_PIPE 0    // 1: the 32-key-block dK / dV kernel requests the Q / dO rows of the NEXT query fragment before the current
+#endif                   //    fragment's MFMAs / exponentials (two row sets, the transposed products cover the second request)
 #ifndef A3_SB_S
 #define A3_SB_S 4
 #endif
@@ -112,7 +121,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
   // instantiation that runs this path (6, 14, 18), so the last group of an iteration works from register set 1 and
   // set 0 is free for the next iteration's first group
   constexpr int NG = KF / 2;
-  static_assert(!(A3_PIPE && WPS == 3) || (NG % 2 == 0 && NG >= 2), "attn3_fwd: the K prefetch ping-pong needs an even group count");
+  constexpr bool PIPE = A3_PIPE && (WPS == 3 || (A3_PIPE_LONG && KF >= 28));        // the S loop
+  constexpr bool PIPE_PV = A3_PIPE && (WPS == 3 || (A3_PIPE_LONG == 2 && KF >= 28));   // the P V loop too (A3_PIPE_LONG = 2 spills: 256 VGPRs)
+  static_assert(!PIPE || (NG % 2 == 0 && NG >= 2), "attn3_fwd: the K prefetch ping-pong needs an even group count");
   bf16x8 kk[2][3][2];
   auto ldk = [&](int f, bf16x8 (&k)[2]) __attribute__((always_inline)) {
     k[0] = t64_row(Kt, f * 16 + lr, lg);
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
     ldk(2 * g + 1, k[1]);
     if ((KF & 1) && g == NG - 1) ldk(KF - 1, k[2]);
   };
-  if constexpr (A3_PIPE && WPS == 3) ldg(0, kk[0]);
+  if constexpr (PIPE) ldg(0, kk[0]);
 
   for (; qf * 16 < L; qf += NW, ++it_) {
     A3_STAMP(2 + it_ * 5);
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
 #pragma unroll
       for (int d = 0; d < 4; ++d) v[d] = t64_trpair(Vt, (2 * fp) * 16 + 4 * lg, (2 * fp + 1) * 16 + 4 * lg, d, lr);
     };
-    if constexpr (A3_PIPE && WPS == 3) {
+    if constexpr (PIPE) {
       // software pipeline over PAIRS of key fragments: the K rows of the next pair are requested from the LDS before the
       // MFMAs of the current pair are issued (two register sets, ping-pong; 3 workgroups per CU leave 168 VGPRs).  In
       // the plain loop below every group of MFMAs waits for its own operands' LDS round trip with only the two other
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
           ldg(g + 1, kk[c_ ^ 1]);
         } else {               // last group (set 1): the NEXT iteration's first group into set 0, and this
           ldg(0, kk[0]);       // iteration's first V operands
-          ldv(0, vv[0]);
+          if constexpr (PIPE_PV) ldv(0, vv[0]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
     A3_STAMP(4 + it_ * 5);
 #pragma unroll
     for (int d = 0; d < 4; ++d) oa[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (A3_PIPE && WPS == 3) {
+    if constexpr (PIPE_PV) {
       // the same for the P V products: the transposed V operands of the next pair of key fragments are in flight
       // while the current pair's four MFMAs issue
 #pragma unroll
@@ -477,10 +488,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq1_kernel(const bf16*
     f32x2 eps2 = f32x2{0.f, 0.f};
 
     // P^T and dS~^T of key fragment f for this query fragment (MASK: keys >= Lk get p = 0)
-    auto pds = [&](int f, auto maskc, f32x4& p, f32x4& ds) {
+    // (the K / V rows of fragment f: rows[0..1] = K halves, rows[2..3] = V halves)
+    auto ldrows = [&](int f, bf16x8 (&rows)[4]) __attribute__((always_inline)) {
+      rows[0] = t64_row(Kt, f * 16 + lr, lg); rows[1] = t64_row(Kt, f * 16 + lr, 4 + lg);
+      rows[2] = t64_row(Vt, f * 16 + lr, lg); rows[3] = t64_row(Vt, f * 16 + lr, 4 + lg);
+    };
+    auto pds_of = [&](int f, bf16x8 k0, bf16x8 k1, bf16x8 v0, bf16x8 v1, auto maskc, f32x4& p, f32x4& ds) __attribute__((always_inline)) {
       constexpr bool MASK = decltype(maskc)::value;
-      const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg), k1 = t64_row(Kt, f * 16 + lr, 4 + lg);
-      const bf16x8 v0 = t64_row(Vt, f * 16 + lr, lg), v1 = t64_row(Vt, f * 16 + lr, 4 + lg);
       f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
       st = mfma16(k0, q0, st);
       st = mfma16(k1, q1, st);
@@ -510,10 +524,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq1_kernel(const bf16*
       dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
       bq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto pair = [&](int fp, auto mask_hi) {
-      f32x4 p[2], ds[2];
-      pds(2 * fp, NoMask{}, p[0], ds[0]);
-      pds(2 * fp + 1, mask_hi, p[1], ds[1]);
+    // (plain path: a fragment's rows are read right in front of its MFMAs, as before the operands became arguments)
+    auto pds = [&](int f, auto maskc, f32x4& p, f32x4& ds) __attribute__((always_inline)) {
+      const bf16x8 k0 = t64_row(Kt, f * 16 + lr, lg), k1 = t64_row(Kt, f * 16 + lr, 4 + lg);
+      const bf16x8 v0 = t64_row(Vt, f * 16 + lr, lg), v1 = t64_row(Vt, f * 16 + lr, 4 + lg);
+      pds_of(f, k0, k1, v0, v1, maskc, p, ds);
+    };
+    auto pair_tail = [&](int fp, f32x4 (&p)[2], f32x4 (&ds)[2]) __attribute__((always_inline)) {
       const bf16x8 dsf = pack8(ds[0], ds[1]), pf = pack8(p[0], p[1]);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -522,10 +539,49 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_bwd_dq1_kernel(const bf16*
         bq[d] = mfma16(kt, pf, bq[d]);
       }
     };
+    auto pair_of = [&](int fp, const bf16x8 (&ra)[4], const bf16x8 (&rb)[4], auto mask_hi) __attribute__((always_inline)) {
+      f32x4 p[2], ds[2];
+      pds_of(2 * fp, ra[0], ra[1], ra[2], ra[3], NoMask{}, p[0], ds[0]);
+      pds_of(2 * fp + 1, rb[0], rb[1], rb[2], rb[3], mask_hi, p[1], ds[1]);
+      pair_tail(fp, p, ds);
+    };
+    auto pair = [&](int fp, auto mask_hi) __attribute__((always_inline)) {
+      f32x4 p[2], ds[2];
+      pds(2 * fp, NoMask{}, p[0], ds[0]);
+      pds(2 * fp + 1, mask_hi, p[1], ds[1]);
+      pair_tail(fp, p, ds);
+    };
     constexpr int NPAIR = KF / 2, NLOOP = (KF & 1) ? NPAIR : NPAIR - 1;   // even KF: the last pair holds the tail
+    // Long sequences (one workgroup per CU, 2 waves per SIMD, 256 VGPRs): two operand sets, ping-pong - the rows of the next
+    // pair are requested from the LDS before the current pair's MFMAs / exponentials, which then cover the round trip (in the
+    // plain loop every pair waits for its own operands with ONE other wave on the SIMD to fill the gap).
+    constexpr bool DQ_PIPE = A3_DQ_PIPE && WPS == 2 && KF >= 28 && !(KF & 1) && (NLOOP & 1);
+    if constexpr (DQ_PIPE) {
+      bf16x8 a0[4], a1[4], b0[4], b1[4];
+      ldrows(0, a0); ldrows(1, a1);
+#pragma unroll 1
+      for (int fp = 0; fp + 1 < NLOOP; fp += 2) {
+        ldrows(2 * fp + 2, b0); ldrows(2 * fp + 3, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_of(fp, a0, a1, NoMask{});
+        __builtin_amdgcn_sched_barrier(0);
+        ldrows(2 * fp + 4, a0); ldrows(2 * fp + 5, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_of(fp + 1, b0, b1, NoMask{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (NLOOP odd: set a holds pair NLOOP - 1; the masked last pair follows)
+      ldrows(2 * NPAIR - 2, b0); ldrows(2 * NPAIR - 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      pair_of(NLOOP - 1, a0, a1, NoMask{});
+      __builtin_amdgcn_sched_barrier(0);
+      pair_of(NPAIR - 1, b0, b1, Mask{});
+    } else {
 #pragma unroll 1
     for (int fp = 0; fp < NLOOP; ++fp) pair(fp, NoMask{});
-    if constexpr (KF & 1) {
+    }
+    if constexpr (DQ_PIPE) {
+    } else if constexpr (KF & 1) {
       f32x4 p, ds;
       pds(KF - 1, Mask{}, p, ds);
       const s16x4 dsf = pack4(ds), pf = pack4(p);
@@ -761,9 +817,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* _
   const float c = scale * LOG2E;
 
   // P and dS of query fragment f against this wave's two key fragments: p[e][r] = P[q = 4lg+r][key = lr of fragment e]
-  auto pds = [&](int f, f32x4 (&p)[2], f32x4 (&ds)[2]) {
-    const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
-    const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
+  auto ldrows = [&](int f, bf16x8 (&rows)[4]) __attribute__((always_inline)) {
+    rows[0] = t64_row(Qt, f * 16 + lr, lg); rows[1] = t64_row(Qt, f * 16 + lr, 4 + lg);
+    rows[2] = t64_row(Gt, f * 16 + lr, lg); rows[3] = t64_row(Gt, f * 16 + lr, 4 + lg);
+  };
+  auto pds_of = [&](int f, bf16x8 q0, bf16x8 q1, bf16x8 g0, bf16x8 g1, f32x4 (&p)[2], f32x4 (&ds)[2]) __attribute__((always_inline)) {
     const float4 l4 = *reinterpret_cast<const float4*>(lse_s + f * 16 + lg * 4);
     const float4 d4 = *reinterpret_cast<const float4*>(del_s + f * 16 + lg * 4);
     const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
@@ -781,6 +839,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* _
       }
     }
   };
+  auto pds = [&](int f, f32x4 (&p)[2], f32x4 (&ds)[2]) __attribute__((always_inline)) {
+    const bf16x8 q0 = t64_row(Qt, f * 16 + lr, lg), q1 = t64_row(Qt, f * 16 + lr, 4 + lg);
+    const bf16x8 g0 = t64_row(Gt, f * 16 + lr, lg), g1 = t64_row(Gt, f * 16 + lr, 4 + lg);
+    pds_of(f, q0, q1, g0, g1, p, ds);
+  };
+  constexpr bool DKV_PIPE = A4_DKV_PIPE && QN >= 28 && !(QN & 1);
 
   for (; kb < NB; kb += NW) {
     f32x4 dk[2][4], dv[2][4];
@@ -791,12 +855,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn4_bwd_dkv_kernel(const bf16* _
         dk[e][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         dv[e][d] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+    bf16x8 r0[4], r1[4];
+    if constexpr (DKV_PIPE) ldrows(0, r0);
 #pragma unroll 1
     for (int ip = 0; ip < QN / 2; ++ip) {
       f32x4 pa[2], dsa[2], pb[2], dsb[2];
+      if constexpr (DKV_PIPE) {
+        // 7 waves per CU hide little: the rows of fragment 2 ip + 1 are requested before fragment 2 ip is computed, those
+        // of the next pair's first fragment before 2 ip + 1 (the transposed products below cover that round trip)
+        ldrows(2 * ip + 1, r1);
+        __builtin_amdgcn_sched_barrier(0);
+        pds_of(2 * ip, r0[0], r0[1], r0[2], r0[3], pa, dsa);
+        __builtin_amdgcn_sched_barrier(0);
+        ldrows(min(2 * ip + 2, QN - 1), r0);
+        __builtin_amdgcn_sched_barrier(0);
+        pds_of(2 * ip + 1, r1[0], r1[1], r1[2], r1[3], pb, dsb);
+      } else {
       pds(2 * ip, pa, dsa);
       __builtin_amdgcn_sched_barrier(0);   // one query fragment's operand reads at a time (register pressure)
       pds(2 * ip + 1, pb, dsb);
+      }
       bf16x8 pf[2], dsf[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
