@@ -40,14 +40,16 @@
 #define A3_PIPE 1   // 1: software-pipelined S / P V loops of the 3-workgroups-per-CU forward (0: the plain loops, A/B)
 #endif
 #ifndef A3_PIPE_LONG
-#define A3_PIPE_LONG 0   // 1: the same software pipeline in the one-workgroup-per-CU forward of the long sequences (28 / 36 key
-#endif                   //    fragments, 2 waves per SIMD: 256 VGPRs hold the two operand sets); A/B: tools/attn_fwd_long_ab.py
+#define A3_PIPE_LONG 1   // 1 (ships since round 6): the K-row prefetch of that pipeline also in the one-workgroup-per-CU forward of the
+#endif                   //    long sequences (28 / 36 key fragments, 2 waves per SIMD): bit-identical, L = 441: 441 -> 425 us at n = 256,
+                         //    L = 576: 678 -> 657 (profiles/r06_attn_long_prefetch_ab.txt); 2 = the P V loop too (spills at 256 VGPRs)
 #ifndef A3_DQ_PIPE
-#define A3_DQ_PIPE 0     // 1: the one-sweep dQ kernel of the long sequences (28 / 36 key fragments, 2 waves per SIMD) requests the
-#endif                   //    K / V rows of the next PAIR of key fragments before the current pair is computed; A/B: tools/attn_fwd_long_ab.py
+#define A3_DQ_PIPE 0     // 1: the one-sweep dQ kernel of the long sequences requests the K / V rows of the next PAIR of key fragments
+#endif                   //    before the current pair is computed: backward -2.4 % at L = 441, +0.9 % at L = 576 (same file), 72 of 10.8 M
+                         //    gradient elements move by one bf16 ulp (contraction of the delta sum) - not adopted
 #ifndef A4_DKV_PIPE
 #define A4_DKV_PIPE 0    // 1: the 32-key-block dK / dV kernel requests the Q / dO rows of the NEXT query fragment before the current
-#endif                   //    fragment's MFMAs / exponentials (two row sets, the transposed products cover the second request)
+#endif                   //    fragment's MFMAs / exponentials: bit-identical, +0.5..1 % SLOWER (same file) - not adopted
 #ifndef A3_SB_S
 #define A3_SB_S 4
 #endif

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "probes", "build")
 
 
-VARIANTS = {"base": [], "fwd": ["-DA3_PIPE_LONG=1"], "dq": ["-DA3_DQ_PIPE=1"], "dkv": ["-DA4_DKV_PIPE=1"],
+VARIANTS = {"base": ["-DA3_PIPE_LONG=0"], "fwd": ["-DA3_PIPE_LONG=1"], "dq": ["-DA3_PIPE_LONG=0", "-DA3_DQ_PIPE=1"], "dkv": ["-DA3_PIPE_LONG=0", "-DA4_DKV_PIPE=1"],
             "all": ["-DA3_PIPE_LONG=1", "-DA3_DQ_PIPE=1", "-DA4_DKV_PIPE=1"]}
 
 
@@ -88,7 +88,7 @@ def main():
         continue
       for k, d in json.loads(line[0][7:]).items():
         rows.setdefault(k, {}).setdefault(v, []).append(d)
-  print("# us per launch, three interleaved repetitions; variants: " + ", ".join(f"{v} ({' '.join(f) or 'what ships'})" for v, f in VARIANTS.items()))
+  print("# us per launch, three interleaved repetitions; variants: " + ", ".join(f"{v} ({' '.join(f)})" for v, f in VARIANTS.items()))
   for k, r in rows.items():
     base = r.get("base", [{}])[0]
     for v in VARIANTS:
