@@ -50,6 +50,12 @@
 #ifndef A4_DKV_PIPE
 #define A4_DKV_PIPE 0    // 1: the 32-key-block dK / dV kernel requests the Q / dO rows of the NEXT query fragment before the current
 #endif                   //    fragment's MFMAs / exponentials: bit-identical, +0.5..1 % SLOWER (same file) - not adopted
+#ifndef A3_FWD_LONG_NW
+#define A3_FWD_LONG_NW 8   // waves of the 28-fragment forward's workgroup: 8 (2 per SIMD, K-row prefetch) or 12 (3 per SIMD, plain loops,
+#endif                     // 166 VGPRs): 12 is bit-identical and 2 % faster (433 vs 442 us, r06_attn_long_prefetch_ab.txt) - inside the spread, off
+#ifndef A3_DQ_LONG_NW
+#define A3_DQ_LONG_NW 16   // waves of the UNMASKED 28-fragment one-sweep dQ kernel: 16 (4 per SIMD: its 126 VGPRs fit the 128 line) ships since
+#endif                     // round 6 - bit-identical, backward at L = 441 1424-1430 -> 1384-1400 us (same file); 8 = the former 2 per SIMD
 #ifndef A3_SB_S
 #define A3_SB_S 4
 #endif
@@ -123,8 +129,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn3_fwd_kernel(const bf16* __r
   // instantiation that runs this path (6, 14, 18), so the last group of an iteration works from register set 1 and
   // set 0 is free for the next iteration's first group
   constexpr int NG = KF / 2;
-  constexpr bool PIPE = A3_PIPE && (WPS == 3 || (A3_PIPE_LONG && KF >= 28));        // the S loop
-  constexpr bool PIPE_PV = A3_PIPE && (WPS == 3 || (A3_PIPE_LONG == 2 && KF >= 28));   // the P V loop too (A3_PIPE_LONG = 2 spills: 256 VGPRs)
+  constexpr bool PIPE = A3_PIPE && ((WPS == 3 && KF <= 17) || (A3_PIPE_LONG && KF >= 28 && WPS == 2));        // the S loop
+  constexpr bool PIPE_PV = A3_PIPE && ((WPS == 3 && KF <= 17) || (A3_PIPE_LONG == 2 && KF >= 28 && WPS == 2));   // the P V loop too (A3_PIPE_LONG = 2 spills: 256 VGPRs)
   static_assert(!PIPE || (NG % 2 == 0 && NG >= 2), "attn3_fwd: the K prefetch ping-pong needs an even group count");
   bf16x8 kk[2][3][2];
   auto ldk = [&](int f, bf16x8 (&k)[2]) __attribute__((always_inline)) {
@@ -1006,8 +1012,10 @@ int launch_bwd3(const void* qkv, const void* o, const void* d_o, const float* ls
   const size_t sh1 = (size_t)KF * 4096 + (size_t)NW * 64 * 4;
   if (o && g_a3_one_sweep) {
     if (!kv_len && L > (KF - 1) * 16) {
-      set_lds(attn3_bwd_dq1_kernel<KF, NW, WPS, true>, sh1);
-      hipLaunchKernelGGL((attn3_bwd_dq1_kernel<KF, NW, WPS, true>), dim3(n * H), dim3(NW * 64), sh1, s,
+      constexpr int NWT = (KF == 28 && A3_DQ_LONG_NW == 16) ? 16 : NW, WPST = (KF == 28 && A3_DQ_LONG_NW == 16) ? 4 : WPS;
+      const size_t sh1 = (size_t)KF * 4096 + (size_t)NWT * 64 * 4;
+      set_lds(attn3_bwd_dq1_kernel<KF, NWT, WPST, true>, sh1);
+      hipLaunchKernelGGL((attn3_bwd_dq1_kernel<KF, NWT, WPST, true>), dim3(n * H), dim3(NWT * 64), sh1, s,
                          (const bf16*)qkv, (const bf16*)o, (const bf16*)d_o, lse, delta, (bf16*)dqkv, dbias, kv_len,
                          L, H, 0.125f);
     } else {
@@ -1063,7 +1071,7 @@ int bv_attn3_fwd(const void* qkv, void* o, float* lse, const int* kv_len, int n,
   if (L <= 208 && cfg.fwd8) return launch_fwd3<13, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 208) return launch_fwd3<13, 4, 3>(qkv, o, lse, kv_len, n, L, H, s);
   if (L <= 272) return launch_fwd3<17, 8, 4>(qkv, o, lse, kv_len, n, L, H, s);
-  if (L <= 448) return launch_fwd3<28, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
+  if (L <= 448) return launch_fwd3<28, A3_FWD_LONG_NW, A3_FWD_LONG_NW == 12 ? 3 : 2>(qkv, o, lse, kv_len, n, L, H, s);
   return launch_fwd3<36, 8, 2>(qkv, o, lse, kv_len, n, L, H, s);
 }
 

@@ -17,8 +17,9 @@ sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tools", "probes", "build")
 
 
-VARIANTS = {"base": ["-DA3_PIPE_LONG=0"], "fwd": ["-DA3_PIPE_LONG=1"], "dq": ["-DA3_PIPE_LONG=0", "-DA3_DQ_PIPE=1"], "dkv": ["-DA3_PIPE_LONG=0", "-DA4_DKV_PIPE=1"],
-            "all": ["-DA3_PIPE_LONG=1", "-DA3_DQ_PIPE=1", "-DA4_DKV_PIPE=1"]}
+VARIANTS = {"base": [], "nopipe": ["-DA3_PIPE_LONG=0"], "fwd12": ["-DA3_FWD_LONG_NW=12"], "dq8": ["-DA3_DQ_LONG_NW=8"]}
+if os.environ.get("BV_AB_ALL"):   # the measured-and-shelved prefetch variants too
+  VARIANTS.update({"dq": ["-DA3_DQ_PIPE=1"], "dkv": ["-DA4_DKV_PIPE=1"]})
 
 
 def lib_of(v):
@@ -88,7 +89,7 @@ def main():
         continue
       for k, d in json.loads(line[0][7:]).items():
         rows.setdefault(k, {}).setdefault(v, []).append(d)
-  print("# us per launch, three interleaved repetitions; variants: " + ", ".join(f"{v} ({' '.join(f)})" for v, f in VARIANTS.items()))
+  print("# us per launch, three interleaved repetitions; variants: " + ", ".join(f"{v} ({' '.join(f) or 'what ships'})" for v, f in VARIANTS.items()))
   for k, r in rows.items():
     base = r.get("base", [{}])[0]
     for v in VARIANTS:
