@@ -650,7 +650,8 @@ def main():
   comm = dp.init_from_env(overlap_channels=dp.RESERVED_CUS)   # gradient all-reduces overlap the backward's GEMMs
   world = comm.size
   assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-  local = int(os.environ.get("LOCAL_RANK", "0"))
+  # (BV_BENCH_SHARE_GPU=1: every rank on GPU 0 also under a launcher that numbers LOCAL_RANK itself - torchrun on a one-GPU box)
+  local = 0 if os.environ.get("BV_BENCH_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
   assert args.global_batch % world == 0
