@@ -192,3 +192,29 @@ def test_bench_line_of_two_ranks_sharing_one_gpu():
   assert d["roofline"]["bound"] == "mfma" and d["roofline"]["launches"] > 0 and "measured_on" in d["roofline"]
   assert "shared_gpu" in d["config"] and d["value"] > 0 and math.isfinite(d["config"]["final_loss"])
 
+
+def test_bench_line_under_torchrun_sharing_one_gpu():
+  """The driver's own N > 1 launch command - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+  127.0.0.1 --master-port P bench.py --gpus 2 ...` - on a one-GPU box: the launcher numbers LOCAL_RANK 0 / 1, BV_BENCH_SHARE_GPU
+  pins both ranks to GPU 0 (gloo).  Exactly one line on stdout, complete, rc 0."""
+  import json
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ, BV_BENCH_SHARE_GPU="1", BV_DP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+  for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                      "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--global-batch",
+                      "64", "--steps", "2", "--warmup", "1", "--cpu-sample", "2"], env=env, capture_output=True, text=True,
+                     timeout=900)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.strip()]
+  assert len(lines) == 1, r.stdout[-1000:]
+  d = json.loads(lines[0])
+  assert d["n_gpus"] == 2 and d["config"]["per_gpu_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+  assert d["rccl"]["ranks"] == 2 and d["rccl"]["allreduce_of_ones"] == 2.0
+  assert d["cpu_baseline"]["value"] > 0 and d["roofline"]["launches"] > 0 and "shared_gpu" in d["config"]
+  assert d["value"] > 0 and math.isfinite(d["config"]["final_loss"])
