@@ -69,8 +69,7 @@ class TwoTowersExec:
 
   def _backward_will_fork(self):
     """False when one of the towers takes no gradient (LiT / a frozen tower: `bwd` then runs the other tower alone on
-    the main stream).  A saving forward does not fork in that case either: contexts allocated from the side stream's
-    pool and freed on the main stream would only raise peak HBM for an overlap the backward cannot use."""
+    the main stream)."""
     if self._will_fork is None:     # (the frozen set of a store is fixed at construction)
       frozen = self.store.frozen
       self._will_fork = all(any(n.startswith(f"{self.prefix}{tower}") and n not in frozen for n in self.store.entries)
@@ -91,7 +90,11 @@ class TwoTowersExec:
     zimg = ztxt = None
     tkw = self._drop_kw(self.m.text_tower, "txt", drop_key)
     ikw = self._drop_kw(self.m.image_tower, "img", drop_key)
-    if self._two_streams(image, text, collect) and (not save or self._backward_will_fork()):
+    # (a saving forward forks even when its backward will not - LiT / a frozen tower: the FORWARD overlap alone is worth
+    #  1.1-1.9 % of the LiT steps, profiles/r06_lit_forward_fork_ab.txt; the one-stream backward then record_stream()s the
+    #  text contexts it consumes, see bwd.  BV_FORK_FWD_TRAINABLE_ONLY=1 restores the former rule for an A/B.)
+    if self._two_streams(image, text, collect) and (not save or self._backward_will_fork()
+                                                    or os.environ.get("BV_FORK_FWD_TRAINABLE_ONLY") != "1"):
       main, side = self._fork()
       with torch.cuda.stream(side):
         z, o, c = self.txt.fwd(text, save, collect, **tkw)

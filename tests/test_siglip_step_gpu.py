@@ -386,11 +386,13 @@ def test_l16_336_siglip_step_n16(dev):
             case="siglip L/16@336 depth2 n=16")
 
 
-@pytest.mark.parametrize("micro", [0, 4])
-def test_towers_on_two_streams_change_nothing(dev, micro):
+@pytest.mark.parametrize("micro,frozen", [(0, None), (4, None), (0, "img"), (4, "img"), (0, "txt")])
+def test_towers_on_two_streams_change_nothing(dev, micro, frozen):
   """config.tower_streams = 2 (the default since round 6; 1 = both towers on the caller's stream): the text tower runs on a side stream beside the image tower, forward and
   backward, with and without micro-batches.  Same kernels on the same inputs: loss, gradient norm and every gradient
-  agree with the one-stream step (LayerNorm scale / bias gradients are fp32 atomics: summation order only)."""
+  agree with the one-stream step (LayerNorm scale / bias gradients are fp32 atomics: summation order only).
+  frozen = "img" (LiT) / "txt": the forward still forks, the backward of the one trainable tower runs on the caller's stream
+  and consumes text contexts that were allocated on the side stream."""
   import bv_oracle as O
   from big_vision_amd.models.proj.image_text import two_towers
   from big_vision_amd.trainers.proj.image_text import siglip
@@ -402,8 +404,12 @@ def test_towers_on_two_streams_change_nothing(dev, micro):
   for streams in (1, 2):
     model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
     config = _cfg(tower_streams=streams, microbatch=micro, microbatch_keep="all")
+    if frozen:
+      config.schedule = [(f"{frozen}/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))]
     state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, total_steps=config.total_steps)
     fn = siglip.make_update_fn(model, config)
+    if frozen:
+      assert state["params"].store.frozen and all(n.startswith(f"{frozen}/") for n in state["params"].store.frozen)
     for _ in range(2):     # two steps: the second one re-transposes the weight images before the fork
       state, meas = fn(state, None, batch)
     torch.cuda.synchronize()
