@@ -582,19 +582,22 @@ def configs_object(dev, steps=3):
   """The `configs` object of the N = 1 line: every entry is measured here, after the headline, on the same device."""
   import gc
   out = {}
-  for key, fn in (("c2", lambda: workload_c2(dev, steps)), ("c4_rank", lambda: workload_c4(dev, steps)),
-                  ("c5b", lambda: workload_c5b(dev, steps)), ("rank512", lambda: workload_rank_shape(dev, steps, 512)),
-                  ("rank1024", lambda: workload_rank_shape(dev, steps, 1024)),
-                  ("rank512_rccl", lambda: workload_rank_shape_rccl(dev, steps, 512)),
-                  ("rank512_one_stream", lambda: workload_rank_shape(dev, steps, 512, tower_streams=1)),
-                  ("rank1024_one_stream", lambda: workload_rank_shape(dev, steps, 1024, tower_streams=1))):
+  # the short steps (36-170 ms) are timed over at least 8 of them: three steps of the 512-pair shape with the one-rank RCCL
+  # group read 85.9 ms on one box and 92.9 on the next, ten steps 86.4 +- 0.1 on both (profiles/NOTES_r06.md)
+  few, more = steps, max(steps, 8)
+  for key, k, fn in (("c2", more, lambda: workload_c2(dev, more)), ("c4_rank", few, lambda: workload_c4(dev, few)),
+                     ("c5b", more, lambda: workload_c5b(dev, more)), ("rank512", more, lambda: workload_rank_shape(dev, more, 512)),
+                     ("rank1024", more, lambda: workload_rank_shape(dev, more, 1024)),
+                     ("rank512_rccl", more, lambda: workload_rank_shape_rccl(dev, more, 512)),
+                     ("rank512_one_stream", more, lambda: workload_rank_shape(dev, more, 512, tower_streams=1)),
+                     ("rank1024_one_stream", more, lambda: workload_rank_shape(dev, more, 1024, tower_streams=1))):
     gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
     try:
       r = fn()
       out[key] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                  "steps": steps, "roofline_frac": r["roofline"]["frac"], "step_frac": r.get("step_frac"),
+                  "steps": k, "roofline_frac": r["roofline"]["frac"], "step_frac": r.get("step_frac"),
                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                   "final_loss": r["config"].get("final_loss")}
       if "rccl" in r:
