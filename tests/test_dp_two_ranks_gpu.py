@@ -117,11 +117,16 @@ FSDP = dict(sharding_strategy=[(".*", "fsdp(axis='data', min_size_to_shard_mb=0)
 FSDP_AF = dict(FSDP, optax_name="big_vision.scale_by_adafactor")
 
 
+# LiT: the image tower frozen - the forward still forks (text tower on the side stream), the one-stream backward of the text tower
+# hands its blocks to the overlapped gradient sync
+LIT = dict(schedule=[("img/.*", None), (".*", dict(decay_type="cosine", warmup_steps=2))])
+
+
 @pytest.mark.parametrize("world,kw", [(2, dict()), (2, dict(overlap_grad_sync=False)), (2, dict(microbatch=2)),
                                       (2, dict(loss_fn="softmax")), (2, dict(loss_fn="sigmoid")), (2, FSDP), (2, FSDP_AF),
-                                      (4, dict()), (4, FSDP), (2, dict(tower_streams=1))],
+                                      (4, dict()), (4, FSDP), (2, dict(tower_streams=1)), (2, LIT)],
                          ids=["w2-plain", "w2-no_overlap", "w2-microbatch", "w2-softmax", "w2-sigmoid", "w2-fsdp",
-                              "w2-fsdp_adafactor", "w4-plain", "w4-fsdp", "w2-one_stream"])
+                              "w2-fsdp_adafactor", "w4-plain", "w4-fsdp", "w2-one_stream", "w2-lit"])
 def test_two_ranks_match_single_process(dev, world, kw):
   import torch.multiprocessing as mp
   sys.path.insert(0, os.path.join(ROOT, "oracle"))
