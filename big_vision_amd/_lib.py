@@ -107,7 +107,7 @@ OPTS = {"fast_path": 0, "gemm_nt": 1, "gemm_skew_mode": 2, "gemm_skew_pct": 3, "
         "gemm_group_n": 6, "gemm_reserve_cus": 7, "attn_cfg": 8, "sgemm_mfma": 9,
         "gemm256_calls": 100, "gemm256_multi": 101, "gemm256_fused": 102}
 
-EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL = range(9)
+EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD, EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL, EPI_GELU_G = range(10)
 
 _lib = None
 

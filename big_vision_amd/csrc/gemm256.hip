@@ -808,6 +808,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(G256Params p) {
                 // g = gelu(h) of the bf16-ROUNDED pre-activation h that is stored (and that the
                 // backward differentiates / can recompute g from): forward and backward agree.
                 if constexpr (EPI == BV_EPI_GELU) gw[e] = bf2_pack(gelu_tanh_pk(bf2_unpack(cw[e])));
+                if constexpr (EPI == BV_EPI_GELU_G) cw[e] = bf2_pack(gelu_tanh_pk(bf2_unpack(cw[e])));   // the only output
               }
             }
             st16(c + vc[hh * 2], u32x4{cw[0], cw[1], cw[2], cw[3]}, nts);
@@ -1506,6 +1507,7 @@ int bv_gemm256_try(int a_kmajor, int b_kmajor, const void* A, long lda, const vo
   else if (epilogue == BV_EPI_RESIDUAL) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_RESIDUAL, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_POS) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_POS, true>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU, false>), grid, block, 0, s, p);
+  else if (epilogue == BV_EPI_GELU_G) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_G, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_BWD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_BWD_EMIT) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_BWD_EMIT, false>), grid, block, 0, s, p);
   else if (epilogue == BV_EPI_GELU_GD) hipLaunchKernelGGL((gemm256_kernel<true, 0, BV_EPI_GELU_GD, false>), grid, block, 0, s, p);

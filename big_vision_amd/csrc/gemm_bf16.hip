@@ -267,6 +267,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams p) {
         uint2 o;
         o.x = pack_bf2(v[0], v[1]);
         o.y = pack_bf2(v[2], v[3]);
+        if (epi == BV_EPI_GELU_G) {   // only gelu of the bf16-rounded pre-activation leaves the kernel
+          o.x = pack_bf2(gelu_tanh_f(bflo(o.x)), gelu_tanh_f(bfhi(o.x)));
+          o.y = pack_bf2(gelu_tanh_f(bflo(o.y)), gelu_tanh_f(bfhi(o.y)));
+        }
         *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n) = o;
         if (epi == BV_EPI_GELU) {   // gelu of the bf16-rounded pre-activation that is stored
           uint2 g;
@@ -313,7 +317,7 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
              "bv_gemm_bf16: B contiguous dim / ldb must be multiples of 8 (N=%d K=%d ldb=%ld)", N, K, ldb);
   BV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0),
              "bv_gemm_bf16: operand pointers must be 16-byte aligned");
-  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_MUL, "bv_gemm_bf16: bad epilogue %d", epilogue);
+  BV_REQUIRE(epilogue >= BV_EPI_NONE && epilogue <= BV_EPI_GELU_G, "bv_gemm_bf16: bad epilogue %d", epilogue);
   BV_REQUIRE(ldc % 4 == 0, "bv_gemm_bf16: ldc=%ld must be a multiple of 4", ldc);
   if (epilogue == BV_EPI_RESIDUAL || epilogue == BV_EPI_POS || epilogue == BV_EPI_GELU_BWD ||
       epilogue == BV_EPI_GELU_BWD_EMIT || epilogue == BV_EPI_MUL)
@@ -323,7 +327,7 @@ extern "C" int bv_gemm_bf16_colsum(int a_kmajor, int b_kmajor, const void* A, lo
     BV_REQUIRE(C2 != nullptr && !out_f32, "bv_gemm_bf16: epilogue %d needs bf16 C and C2", epilogue);
   if (epilogue == BV_EPI_POS || epilogue == BV_EPI_ATOMIC)   // RESIDUAL: aux and C share one dtype (fp32 or bf16)
     BV_REQUIRE(out_f32, "bv_gemm_bf16: epilogue %d writes fp32", epilogue);
-  if (epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_MUL)
+  if (epilogue == BV_EPI_GELU_BWD || epilogue == BV_EPI_MUL || epilogue == BV_EPI_GELU_G)
     BV_REQUIRE(!out_f32, "bv_gemm_bf16: epilogue %d writes bf16 (out_f32 must be 0)", epilogue);
   if (epilogue == BV_EPI_ATOMIC) BV_REQUIRE(bias == nullptr, "bv_gemm_bf16: ATOMIC epilogue takes no bias");
   if (colsum)

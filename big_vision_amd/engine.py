@@ -432,8 +432,11 @@ class MLP:
       return ops.dropout_f32(branch, k_out, rate, addend=resid), hd, g, branch
     return ops.dropout_f32(branch, k_out, rate, addend=resid, out=branch), hd, g, None
 
-  def fwd(self, y_bf, resid, keep_g=True):
+  def fwd(self, y_bf, resid, keep_g=True, ctx=True):
     """resid + fc2(gelu(fc1(y))) ; returns (out, hd bf16, g bf16 or None).
+
+    ctx = False (a forward that saves nothing: a frozen tower, inference): fc1's epilogue writes gelu(h) only
+    (BV_EPI_GELU_G, bit-identical to the activation the saving epilogues write) and (out, None, None) is returned.
 
     keep_g (full contexts): the fc1 epilogue BV_EPI_GELU_GD evaluates gelu AND its derivative on the fp32
     pre-activation - they share the exp / rcp - and writes g = gelu(h) and hd = gelu'(h); the pre-activation
@@ -441,6 +444,9 @@ class MLP:
     not keep_g (light contexts): hd = the bf16 pre-activation h (BV_EPI_GELU: g is applied to the rounded h
     that is stored) and g is dropped after fc2; the backward re-derives both g and gelu'(h) from h
     (BV_EPI_GELU_BWD_EMIT, bit-identical g)."""
+    if not ctx:
+      g = linear_fwd(y_bf, self.w1, self.b1, out_dtype=BF16, epilogue=ops.EPI_GELU_G)
+      return linear_fwd(g, self.w2, self.b2, out_dtype=resid.dtype, epilogue=ops.EPI_RESIDUAL, aux=resid), None, None
     g = torch.empty((y_bf.shape[0], self.M), device=y_bf.device, dtype=BF16)
     if keep_g:
       hd = torch.empty_like(g)
@@ -487,8 +493,9 @@ class Block:
     self.bo = _W(store, f"{A}/out/bias")
     self.mlp = MLP(store, f"{P}/MlpBlock_0", D, M)
 
-  def fwd(self, x, n, L, light=False, kv_len=None, drop=None, collect=False):
+  def fwd(self, x, n, L, light=False, kv_len=None, drop=None, collect=False, ctx=True):
     """kv_len (int32 [n], optional): key-padding length per sample (NaFlex, naflex_vit.py:84-113).
+    ctx = False: the caller keeps no context of this block (Encoder.fwd with save falsy): the MLP writes gelu(h) only.
     drop (Dropout of THIS block, rate > 0): the dropout sites of vit.py:100,109 and :76, see _fwd_drop.
     light (True, or "g" = only the second item): the saved context drops what the backward can re-derive cheaply - the two
     LayerNorm outputs (re-normalised from x / x1) and gelu(h) (re-emitted by the fc2 dX
@@ -501,7 +508,7 @@ class Block:
     o, lse = ops.attn_fwd(qkv, n, L, H, kv_len=kv_len)
     x1 = linear_fwd(o, self.wo, self.bo, out_dtype=x.dtype, epilogue=ops.EPI_RESIDUAL, aux=x)   # fp32 or bf16 stream
     y1, _, mean1, rstd1 = self.ln1.fwd(x1, T, D)
-    x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light)
+    x2, h, g = self.mlp.fwd(y1, x1, keep_g=not light, ctx=ctx)
     if light is True:     # light == "g": only gelu(h) is dropped, the LayerNorm outputs stay
       y0 = y1 = None
     return x2, (x, mean0, rstd0, y0, qkv, o, lse, x1, mean1, rstd1, y1, h, g)
@@ -621,7 +628,7 @@ class Encoder:
     for i, blk in enumerate(self.blocks):
       x_in = x
       x, s = blk.fwd(x, n, L, light=(True if save == "light" else ("g" if save == "g" else False)), kv_len=kv_len,
-                     drop=(drop.fold("block", i) if dropping else None), collect=out is not None)
+                     drop=(drop.fold("block", i) if dropping else None), collect=out is not None, ctx=bool(save))
       pre = None
       if dropping and out is not None:       # the branch outputs before their dropout leave the context again
         pre, s = s[13][3], s[:13] + (s[13][:3] + (None,),)

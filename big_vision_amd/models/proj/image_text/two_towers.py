@@ -67,6 +67,18 @@ class TwoTowersExec:
     # (collect=True hands nested dicts of intermediate activations to the caller: they stay on one stream)
     return self.streams == 2 and not collect and image is not None and text is not None and text.is_cuda
 
+  def _tower_trainable(self, tower):
+    """False when every parameter of `tower` ("img/" | "txt/") is frozen (config.schedule None: LiT's image tower).  Such a
+    tower's forward keeps NO context whatever `save` asks for - nothing is ever differentiated through it (the trainers
+    hand `bwd` None for its cotangent, inputs take no gradient) - so its MLP writes gelu(h) only (BV_EPI_GELU_G) and its
+    activations are freed as the forward proceeds."""
+    if not hasattr(self, "_trainable"):
+      self._trainable = {}
+    if tower not in self._trainable:     # (the frozen set of a store is fixed at construction)
+      frozen = self.store.frozen
+      self._trainable[tower] = any(n.startswith(f"{self.prefix}{tower}") and n not in frozen for n in self.store.entries)
+    return self._trainable[tower]
+
   def _backward_will_fork(self):
     """False when one of the towers takes no gradient (LiT / a frozen tower: `bwd` then runs the other tower alone on
     the main stream)."""
@@ -88,6 +100,8 @@ class TwoTowersExec:
   def fwd(self, image, text, save=False, collect=False, drop_key=None):
     out, ctx = {}, {}
     zimg = ztxt = None
+    save_img = save if self._tower_trainable("img/") else False
+    save_txt = save if self._tower_trainable("txt/") else False
     tkw = self._drop_kw(self.m.text_tower, "txt", drop_key)
     ikw = self._drop_kw(self.m.image_tower, "img", drop_key)
     # (a saving forward forks even when its backward will not - LiT / a frozen tower: the FORWARD overlap alone is worth
@@ -97,7 +111,7 @@ class TwoTowersExec:
                                                     or os.environ.get("BV_FORK_FWD_TRAINABLE_ONLY") != "1"):
       main, side = self._fork()
       with torch.cuda.stream(side):
-        z, o, c = self.txt.fwd(text, save, collect, **tkw)
+        z, o, c = self.txt.fwd(text, save_txt, collect, **tkw)
         ztxt, norm = ops.l2norm_fwd(z)
       out.update({f"txt/{k}": v for k, v in o.items()})
       out["txt/norm"] = norm.view(-1, 1)
@@ -111,14 +125,14 @@ class TwoTowersExec:
     else:
       join = None
     if text is not None:
-      z, o, c = self.txt.fwd(text, save, collect, **tkw)
+      z, o, c = self.txt.fwd(text, save_txt, collect, **tkw)
       out.update({f"txt/{k}": v for k, v in o.items()})
       ztxt, norm = ops.l2norm_fwd(z)
       out["txt/norm"] = norm.view(-1, 1)
       out["txt/normalized"] = ztxt
       ctx["txt"] = (c, z, norm)
     if image is not None:
-      z, o, c = self.img.fwd(image, save, collect, **ikw)
+      z, o, c = self.img.fwd(image, save_img, collect, **ikw)
       out.update({f"img/{k}": v for k, v in o.items()})
       zimg, norm = ops.l2norm_fwd(z)
       out["img/norm"] = norm.view(-1, 1)
@@ -162,6 +176,10 @@ class TwoTowersExec:
     GEMMs), the rest of the text tower (embedding table, final norm, head) when the text backward
     is done, the image tower's final norm / MAP head together with its last block; what is left
     (stem, position embedding, t, b) is reduced by sync.finish()."""
+    if dzimg is not None and "img" in ctx and ctx["img"][0] is None:   # a frozen tower kept no context: nothing to differentiate
+      dzimg = None
+    if dztxt is not None and "txt" in ctx and ctx["txt"][0] is None:
+      dztxt = None
     two = self.streams == 2 and dztxt is not None and dzimg is not None and "txt" in ctx and "img" in ctx and dztxt.is_cuda
     if two:
       main, side = self._fork()

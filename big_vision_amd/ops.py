@@ -9,7 +9,7 @@ import torch
 
 from big_vision_amd import _lib
 from big_vision_amd._lib import (EPI_NONE, EPI_RESIDUAL, EPI_POS, EPI_GELU, EPI_GELU_BWD,
-                                 EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL)
+                                 EPI_ATOMIC, EPI_GELU_BWD_EMIT, EPI_GELU_GD, EPI_MUL, EPI_GELU_G)
 
 BF16 = torch.bfloat16
 F32 = torch.float32

@@ -133,6 +133,9 @@ long bv_gemm_workspace_bytes(int M, int N, int K);
                              (vit.py:75 and its derivative in ONE forward epilogue: the pre-activation
                              is not stored; the backward multiplies by C2 with BV_EPI_MUL)        */
 #define BV_EPI_MUL 8      /* C(bf16) *= aux(bf16)[m,n]  (dH = dG o gelu'(h), gelu' kept by GELU_GD) */
+#define BV_EPI_GELU_G 9   /* C(bf16) = gelu_tanh(h), h = the bf16-rounded result; nothing else is written (C2 ignored):
+                             the MLP of a forward that saves no context - a frozen tower, inference (vit.py:75).
+                             Bit-identical to the C2 of BV_EPI_GELU / the C of BV_EPI_GELU_GD                      */
 int bv_gemm_bf16(int a_kmajor, int b_kmajor, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, int out_f32, int M, int N, int K, int epilogue,
                  const float* bias, const void* aux, long ldaux, int aux_rows, void* C2,

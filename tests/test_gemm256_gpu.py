@@ -214,6 +214,8 @@ def test_rolling_epilogue_kernel_matches_the_full_epilogue_kernel(dev, fast, M, 
     h = ops.gemm(a, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g, **kw)
     y1 = ops.gemm(a, w, bias=b, out_dtype=F32, epilogue=ops.EPI_RESIDUAL, aux=res, **kw)
     y2 = ops.gemm(a, w, out_dtype=BF16, alpha=0.5, **kw)          # no bias, alpha != 1
+    g1 = ops.gemm(a, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU_G, **kw)   # gelu(h) alone (context-free forward)
+    assert torch.equal(g1, g), "BV_EPI_GELU_G differs from the activation BV_EPI_GELU writes (256 x 256 kernel)"
     return y0, h, g, y1, y2
 
   with ops.option("gemm_roll", 0):

@@ -89,6 +89,9 @@ def test_gemm_epilogues(dev):
   h = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU, out2=g)
   assert_close(h, pre, 1e-2, 1e-2, "gelu pre")
   assert_close(g, torch.nn.functional.gelu(pre, approximate="tanh"), 1e-2, 1e-2, "gelu out")
+  # the single-output epilogue of a forward that saves no context writes the same activation bits and nothing else
+  g1 = ops.gemm(x, w, bias=b, out_dtype=BF16, epilogue=ops.EPI_GELU_G)
+  assert torch.equal(g1, g), "BV_EPI_GELU_G differs from the activation BV_EPI_GELU writes"
   # gelu backward epilogue: dH = (dG W2^T) * gelu'(h)
   dg_in = rnd((M, K), dev, 13, dtype=BF16)
   w2 = rnd((N, K), dev, 14, 0.1, dtype=BF16)

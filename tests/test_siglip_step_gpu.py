@@ -503,3 +503,30 @@ def test_scan_layout_model_steps_like_the_pyloop_model(dev):
     for k in fa:
       assert fa[k].shape == fb[k].shape, k
       assert float(np.linalg.norm(fa[k] - fb[k])) <= 1e-5 * max(float(np.linalg.norm(fa[k])), 1e-3 * gn), k
+
+
+
+def test_frozen_tower_keeps_no_context(dev):
+  """LiT: the frozen image tower's forward runs context-free inside a SAVING step (single-output GELU epilogue, activations
+  freed as it goes): its context slot is empty, its embeddings are the bits of a saving forward of the same tower, and a
+  cotangent handed to `bwd` for it is ignored instead of differentiating through nothing."""
+  import bv_oracle as O
+  from big_vision_amd import ops
+  from big_vision_amd.models.proj.image_text import two_towers
+  from big_vision_amd.trainers.proj.image_text import siglip
+  image_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, patch_size=(16, 16), pool_type="map")
+  text_cfg = dict(width=128, depth=2, mlp_dim=256, num_heads=2, vocab_size=100)
+  image, text = O.synthetic_batch(1, 8, 64, 16, 100)
+  image, text = image.to(dev), text.to(dev)
+  for name, schedule in (("lit", LIT_SCHEDULE), ("all", dict(decay_type="cosine", warmup_steps=2))):
+    model = two_towers.Model(image=image_cfg, text=text_cfg, out_dim=(None, 128), temperature_init=10.0, bias_init=-10.0)
+    config = _cfg(schedule=schedule)
+    state, _ = siglip.make_train_state(model, config, tuple(image.shape), tuple(text.shape), rng=0, total_steps=config.total_steps)
+    ex = model.executor(state["params"].store, "", tuple(image.shape), tuple(text.shape))
+    zimg, ztxt, _, ctx = ex.fwd(image, text, save=True)
+    assert (ctx["img"][0] is None) == (name == "lit") and ctx["txt"][0] is not None
+    z, _, c = ex.img.fwd(image, True, False)        # the same tower, saving (two-output GELU epilogue)
+    assert c is not None and torch.equal(ops.l2norm_fwd(z)[0], zimg), name
+    if name == "lit":
+      ex.bwd(ctx, torch.ones_like(zimg), torch.ones_like(ztxt))     # the image cotangent is dropped, the text tower differentiates
+    torch.cuda.synchronize()
