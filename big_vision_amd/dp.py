@@ -130,6 +130,16 @@ class Comm:
       dist.barrier(group=self.group)
 
 
+_COLLECTIVE_STREAMS = {}
+
+
+def _collective_stream(device):
+  key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+  if key not in _COLLECTIVE_STREAMS:
+    _COLLECTIVE_STREAMS[key] = torch.cuda.Stream(device=device)
+  return _COLLECTIVE_STREAMS[key]
+
+
 class GradSync:
   """Overlaps the gradient all-reduce with the backward pass.
 
@@ -144,7 +154,10 @@ class GradSync:
   def __init__(self, comm: Comm, flat: torch.Tensor, bucket_bytes: int = 256 << 20):
     self.comm, self.flat, self.bucket_bytes = comm, flat, bucket_bytes
     self.done = []   # disjoint [lo, hi) already handed to the collective
-    self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and comm.active) else None
+    # ONE collective stream per device and process (a GradSync is built every step: torch.cuda.Stream() would walk its pool
+    # of 32 streams, which HIP maps onto a handful of hardware queues - a step whose collective stream shares a queue with the
+    # text tower's side stream serialises its all-reduces behind that tower's kernels)
+    self.stream = _collective_stream(flat.device) if (flat.is_cuda and comm.active) else None
 
   def launch(self, lo: int, hi: int):
     lo, hi = max(0, int(lo)), min(int(hi), self.flat.numel())

@@ -24,6 +24,9 @@ F32 = torch.float32
 MODELS_PKG = "big_vision_amd.models"
 
 
+_SIDE_STREAMS = {}
+
+
 class TwoTowersExec:
   def __init__(self, m: "Model", store: ParamStore, prefix: str, hw, seq_len):
     self.m, self.store = m, store
@@ -55,7 +58,13 @@ class TwoTowersExec:
     if self._side is None:
       # BV_SIDE_STREAM_PRIORITY (A/B knob, tools/stream_priority_ab.py): HIP priority of the text tower's stream
       # (-1 = high, 0 = the default); within the noise: 512 pairs +-0.2 %, headline -0.4 +- 0.4 % (profiles/r06_stream_priority_ab.txt)
-      self._side = torch.cuda.Stream(device=self.store.device, priority=int(os.environ.get("BV_SIDE_STREAM_PRIORITY", "0")))
+      # (one side stream per device and process, shared by every executor: see dp._collective_stream for why streams are not
+      #  drawn from torch's pool again and again)
+      prio = int(os.environ.get("BV_SIDE_STREAM_PRIORITY", "0"))
+      key = (torch.device(self.store.device).index, prio)
+      if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.store.device, priority=prio)
+      self._side = _SIDE_STREAMS[key]
     E.refresh_twins(self.store)
     mc = ops.ctx()
     with torch.cuda.stream(self._side):
