@@ -150,3 +150,18 @@ def test_python_contexts_are_per_stream_and_options_restore(lib, monkeypatch):
   stream["id"] = 13
   c = ops.ctx()
   assert c.get("gemm_nt") == 1 and c.get("gemm_group_n") == 4 and a.get("gemm_nt") == 0
+
+
+def test_epilogue_and_option_codes_match_the_header():
+  """The ctypes side spells the epilogue / option codes as Python constants: every BV_EPI_* and BV_OPT_* of
+  include/bvhip.h has the same value in big_vision_amd/_lib.py (BV_EPI_GELU_G = 9 joined in round 6)."""
+  import re
+  from big_vision_amd import _lib
+  hdr = open(os.path.join(ROOT, "include", "bvhip.h")).read()
+  epi = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define BV_EPI_(\w+)\s+(\d+)", hdr)}
+  assert len(epi) >= 10 and epi["GELU_G"] == 9
+  for name, val in epi.items():
+    assert getattr(_lib, f"EPI_{name}") == val, name
+  opt = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define BV_OPT_(\w+)\s+(\d+)", hdr) if m.group(1) != "COUNT"}
+  for name, val in opt.items():
+    assert _lib.OPTS[name] == val, name
